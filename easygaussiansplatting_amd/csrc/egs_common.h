@@ -1,0 +1,95 @@
+// Shared host/device helpers of libegs_hip.so (gfx950 / CDNA4 only: wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stddef.h>
+
+#include "../../include/egs_hip.h"
+
+#define EGS_MIN_DEPTH 0.2f   // reference kernel.cu:10
+#define EGS_BAD_MARKER (-1.f) // reference kernel.cu:11
+#define EGS_TILE 16          // reference common.cuh:12 (BLOCK)
+#define EGS_WAVE 64
+
+namespace egs {
+
+// ---- error reporting --------------------------------------------------------
+void set_error(int code, const char* what, const char* file, int line);
+
+#define EGS_CHECK_ARG(cond)                                                      \
+  do {                                                                           \
+    if (!(cond)) {                                                               \
+      ::egs::set_error(EGS_ERR_BAD_ARG, "bad argument: " #cond, __FILE__, __LINE__); \
+      return EGS_ERR_BAD_ARG;                                                    \
+    }                                                                            \
+  } while (0)
+
+#define EGS_HIP(expr)                                                            \
+  do {                                                                           \
+    hipError_t e__ = (expr);                                                     \
+    if (e__ != hipSuccess) {                                                     \
+      ::egs::set_error((int)e__, hipGetErrorString(e__), __FILE__, __LINE__);    \
+      return (int)e__;                                                           \
+    }                                                                            \
+  } while (0)
+
+// after a <<<>>> launch: catches launch-configuration errors without syncing
+#define EGS_LAUNCH_OK() EGS_HIP(hipGetLastError())
+
+static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// bump allocator over a caller-supplied workspace (256-B aligned pieces)
+struct Carver {
+  char* base;
+  size_t off;
+  size_t cap;
+  Carver(void* p, size_t bytes) : base((char*)p), off(0), cap(bytes) {}
+  template <typename T>
+  T* take(size_t count) {
+    size_t start = align_up(off, 256);
+    off = start + count * sizeof(T);
+    return (T*)(base + start);
+  }
+  bool ok() const { return off <= cap; }
+};
+
+// ---- device helpers ---------------------------------------------------------
+#ifdef __HIPCC__
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }
+
+// inclusive scan across the 64 lanes of a wave
+__device__ __forceinline__ uint32_t wave_inclusive_scan(uint32_t v) {
+  const int lane = lane_id();
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    uint32_t t = __shfl_up(v, d, 64);
+    if (lane >= d) v += t;
+  }
+  return v;
+}
+
+// exclusive scan over a 256-thread block; `total` receives the block sum.
+// `smem` must hold >= 4 uint32 and is reused on return after a barrier.
+__device__ __forceinline__ uint32_t block256_exclusive_scan(uint32_t v, uint32_t* smem, uint32_t* total) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint32_t inc = wave_inclusive_scan(v);
+  if (lane == 63) smem[wave] = inc;
+  __syncthreads();
+  uint32_t s0 = smem[0], s1 = smem[1], s2 = smem[2], s3 = smem[3];
+  uint32_t off = (wave > 0 ? s0 : 0u) + (wave > 1 ? s1 : 0u) + (wave > 2 ? s2 : 0u);
+  if (total) *total = s0 + s1 + s2 + s3;
+  __syncthreads();
+  return off + inc - v;
+}
+
+// sum over the 64 lanes of a wave; result valid in every lane
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+#endif
+
+}  // namespace egs

@@ -1,0 +1,820 @@
+// Tile binning, stable radix sort, prefix sum, and the per-tile alpha-blend
+// forward / backward kernels for gfx950 (CDNA4, wave64).
+//
+// What the reference does (gsplatcu/gausplat.cu:24-159, kernel.cu:13-271,809-950)
+// and how this differs by design:
+//   * reference: expand (tile<<32|depth_mm) keys for all P patches, one 64-bit
+//     thrust sort of P pairs.  Here: sort the N Gaussians by depth key (32-bit
+//     keys, N pairs), expand patches in that order, then ONE-OR-TWO stable 8-bit
+//     passes over P (tile id only).  Same final order (ties in Gaussian-index
+//     order), ~2x less sort traffic at P/N ~ 4.
+//   * reference draw: 256 threads per 16x16 tile, block barrier + vote per
+//     Gaussian, 4 separate gathers per entry.  Here: ONE wave64 per tile, 4
+//     pixels per lane, 64-entry chunks of packed 48-B records staged in LDS and
+//     read back as wave-uniform (broadcast) ds_read_b128 -- no cross-wave
+//     barrier in the blend loop, early exit by a wave vote.
+//   * reference drawB: 9 same-address float atomics per (pixel, Gaussian).
+//     Here: 4 pixels summed in-lane, DPP wave reduction, one lane issues the 9
+//     atomics per (tile, Gaussian): 256x fewer atomics.
+#include "egs_common.h"
+
+namespace egs {
+
+// ============================================================================
+// stable LSD radix sort, 8-bit digits, (u32 key, u32 value)
+// ============================================================================
+constexpr int RS_THREADS = 256;
+constexpr int RS_IPT = 16;                         // items per thread
+constexpr int RS_TILE = RS_THREADS * RS_IPT;       // 4096 items per workgroup
+constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // 1024 contiguous items per wave
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
+                                                           int shift, int nblocks,
+                                                           uint32_t* __restrict__ hist) {
+  __shared__ uint32_t h[256];
+  const int tid = threadIdx.x;
+  h[tid] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int64_t idx = base + r * RS_THREADS + tid;
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 0xFFu], 1u);
+  }
+  __syncthreads();
+  hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];  // digit-major: row = digit
+}
+
+// one workgroup per digit: exclusive scan of that digit's per-block counts (in
+// place) and the digit total.
+__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, int nblocks,
+                                                       uint32_t* __restrict__ totals) {
+  __shared__ uint32_t sm[4];
+  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
+  uint32_t carry = 0;
+  for (int base = 0; base < nblocks; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = (i < nblocks) ? row[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block256_exclusive_scan(v, sm, &tot);
+    if (i < nblocks) row[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+}
+
+__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
+    const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, int nblocks,
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+  __shared__ uint32_t wcount[4][256];  // per-wave running digit counters -> per-wave offsets
+  __shared__ uint32_t gbase[256];
+  __shared__ uint32_t sm[4];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
+  // global base of digit `tid` = (sum of totals of smaller digits) + (same digit in earlier blocks)
+  const uint32_t dig_ex = block256_exclusive_scan(totals[tid], sm, nullptr);
+  gbase[tid] = dig_ex + hist[(size_t)tid * nblocks + blockIdx.x];
+  __syncthreads();
+
+  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_ITEMS;
+  uint32_t key[RS_IPT], rank[RS_IPT];
+  volatile uint32_t* wc = wcount[wave];
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int64_t idx = base + r * EGS_WAVE + lane;
+    const bool valid = idx < n;
+    const uint32_t k = valid ? keys_in[idx] : 0u;
+    const uint32_t d = (k >> shift) & 0xFFu;
+    // peers = lanes of this wave holding the same digit (multi-split by ballots)
+    uint64_t peers = __ballot(valid);
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const bool bit = (d >> b) & 1u;
+      const uint64_t bal = __ballot(bit);
+      peers &= bit ? bal : ~bal;
+    }
+    uint32_t prev = 0;
+    if (valid) prev = wc[d];
+    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
+    if (valid && below == 0) wc[d] = prev + (uint32_t)__popcll(peers);  // lowest peer updates
+    key[r] = k;
+    rank[r] = prev + below;
+  }
+  __syncthreads();
+  {  // digit `tid`: exclusive scan of its per-wave counts
+    uint32_t off = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const uint32_t c = wcount[w][tid];
+      wcount[w][tid] = off;
+      off += c;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int64_t idx = base + r * EGS_WAVE + lane;
+    if (idx < n) {
+      const uint32_t d = (key[r] >> shift) & 0xFFu;
+      const uint32_t pos = gbase[d] + wcount[wave][d] + rank[r];
+      keys_out[pos] = key[r];
+      vals_out[pos] = vals_in[idx];
+    }
+  }
+}
+
+struct SortWs {
+  uint32_t* hist;
+  uint32_t* totals;
+  int nblocks;
+};
+static size_t sort_ws_bytes(int64_t n) {
+  const int nb = n > 0 ? div_up(n, RS_TILE) : 1;
+  return align_up((size_t)256 * nb * 4, 256) + 256 * 4 + 512;
+}
+static bool sort_ws_carve(Carver& cv, int64_t n, SortWs* w) {
+  w->nblocks = n > 0 ? div_up(n, RS_TILE) : 1;
+  w->hist = cv.take<uint32_t>((size_t)256 * w->nblocks);
+  w->totals = cv.take<uint32_t>(256);
+  return cv.ok();
+}
+static int sort_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
+
+// enqueue all passes; result ends in (keys,vals) if the pass count is even
+static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                      int begin_bit, int end_bit, const SortWs& w, hipStream_t s) {
+  if (n <= 0) return 0;
+  uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
+  for (int shift = begin_bit; shift < end_bit; shift += 8) {
+    hipLaunchKernelGGL(k_radix_hist, dim3(w.nblocks), dim3(RS_THREADS), 0, s, ki, n, shift, w.nblocks, w.hist);
+    hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, w.hist, w.nblocks, w.totals);
+    hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblocks), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift,
+                       w.nblocks, w.hist, w.totals);
+    uint32_t* t = ki; ki = ko; ko = t;
+    t = vi; vi = vo; vo = t;
+  }
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// ============================================================================
+// exclusive prefix sum of u32 with optional gather: out[i] = sum_{j<i} in[g[j]]
+// ============================================================================
+constexpr int SC_IPT = 8;
+constexpr int SC_TILE = 256 * SC_IPT;
+
+__global__ __launch_bounds__(256) void k_scan_partials(const uint32_t* __restrict__ in,
+                                                       const uint32_t* __restrict__ gather, int64_t n,
+                                                       uint32_t* __restrict__ partials) {
+  __shared__ uint32_t sm[4];
+  const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {
+    const int64_t i = base + k;
+    if (i < n) s += in[gather ? gather[i] : i];
+  }
+  s = wave_inclusive_scan(s);
+  if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void k_scan_spine(uint32_t* __restrict__ partials, int nparts,
+                                                    uint32_t* __restrict__ total) {
+  __shared__ uint32_t sm[4];
+  uint32_t carry = 0;
+  for (int base = 0; base < nparts; base += 256) {
+    const int i = base + threadIdx.x;
+    const uint32_t v = (i < nparts) ? partials[i] : 0u;
+    uint32_t tot;
+    const uint32_t ex = block256_exclusive_scan(v, sm, &tot);
+    if (i < nparts) partials[i] = carry + ex;
+    carry += tot;
+  }
+  if (threadIdx.x == 0 && total) *total = carry;
+}
+
+__global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in,
+                                                    const uint32_t* __restrict__ gather, int64_t n,
+                                                    const uint32_t* __restrict__ partials,
+                                                    uint32_t* __restrict__ out) {
+  __shared__ uint32_t sm[4];
+  const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
+  uint32_t v[SC_IPT];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {
+    const int64_t i = base + k;
+    v[k] = (i < n) ? in[gather ? gather[i] : i] : 0u;
+    s += v[k];
+  }
+  uint32_t ex = block256_exclusive_scan(s, sm, nullptr) + partials[blockIdx.x];
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {
+    const int64_t i = base + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+  }
+}
+
+static size_t scan_ws_bytes(int64_t n) { return align_up((size_t)(n > 0 ? div_up(n, SC_TILE) : 1) * 4, 256) + 256; }
+
+static int exclusive_scan(int64_t n, const uint32_t* in, const uint32_t* gather, uint32_t* out, uint32_t* total,
+                          uint32_t* partials, hipStream_t s) {
+  if (n <= 0) {
+    if (total) EGS_HIP(hipMemsetAsync(total, 0, 4, s));
+    return 0;
+  }
+  const int nb = div_up(n, SC_TILE);
+  hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(256), 0, s, in, gather, n, partials);
+  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(256), 0, s, partials, nb, total);
+  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, gather, n, partials, out);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// ============================================================================
+// binning
+// ============================================================================
+struct BinParams {
+  int W, H, gx, gy;
+  int footprint, far_cull, depth_key, mutate;
+};
+
+// saturating float -> int (v_cvt_i32_f32 semantics; NaN -> 0), explicit for clarity
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+
+// pixel box of gausplat.py:212-215
+__device__ __forceinline__ void pixel_box(float ux, float uy, float rx, float ry, int W, int H, int& x0,
+                                          int& x1, int& y0, int& y1) {
+  x0 = f2i(fmaxf(fminf(ux - rx, (float)W), 0.f));
+  x1 = f2i(fmaxf(fminf(ux + rx, (float)W), 0.f));
+  y0 = f2i(fmaxf(fminf(uy - ry, (float)H), 0.f));
+  y1 = f2i(fmaxf(fminf(uy + ry, (float)H), 0.f));
+}
+
+// getRects (reference kernel.cu:82-122) + the depth key of createKeys (kernel.cu:73)
+__global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const float* __restrict__ us,
+                                                   int32_t* __restrict__ areas, float* __restrict__ depths,
+                                                   uint4* __restrict__ rects, uint32_t* __restrict__ counts,
+                                                   uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  ids[i] = (uint32_t)i;
+  uint32_t cnt = 0, key = 0xFFFFFFFFu;
+  uint4 rect = {0u, 0u, 0u, 0u};
+  const float depth = depths[i];
+  const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
+  const float xs = (float)areas[2 * (size_t)i], ys = (float)areas[2 * (size_t)i + 1];
+  if (p.footprint == 0) {
+    if (!(depth < EGS_MIN_DEPTH)) {
+      const float B = (float)EGS_TILE;
+      const int x0 = min(p.gx, max(0, f2i((ux - xs) / B)));
+      const int y0 = min(p.gy, max(0, f2i((uy - ys) / B)));
+      const int x1 = min(p.gx, max(0, f2i((ux + xs + B - 1.f) / B)));  // DIV_ROUND_UP in float (common.cuh:14)
+      const int y1 = min(p.gy, max(0, f2i((uy + ys + B - 1.f) / B)));
+      // (a reversed rect -- only possible with negative radii fed by the caller --
+      //  would wrap in the reference's unsigned product; it is treated as empty)
+      cnt = (x1 > x0 && y1 > y0) ? (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0) : 0u;
+      if (cnt == 0) {
+        if (p.mutate) {  // the in-place contract of the reference (kernel.cu:114-119)
+          depths[i] = EGS_BAD_MARKER;
+          areas[2 * (size_t)i] = 0;
+          areas[2 * (size_t)i + 1] = 0;
+        }
+      } else {
+        rect = {(uint32_t)x0, (uint32_t)y0, (uint32_t)x1, (uint32_t)y1};
+      }
+    }
+  } else {
+    bool vis = !(depth < 0.2f || depth > 100.f);                                    // gausplat.py:204
+    vis = vis && !(fabsf(ux / (float)p.W) > 1.3f) && !(fabsf(uy / (float)p.H) > 1.3f);  // gausplat.py:208
+    if (vis) {
+      int x0, x1, y0, y1;
+      pixel_box(ux, uy, xs, ys, p.W, p.H, x0, x1, y0, y1);
+      if ((x1 - x0) * (y1 - y0) != 0 && x1 > x0 && y1 > y0) {
+        rect = {(uint32_t)(x0 / EGS_TILE), (uint32_t)(y0 / EGS_TILE), (uint32_t)((x1 + EGS_TILE - 1) / EGS_TILE),
+                (uint32_t)((y1 + EGS_TILE - 1) / EGS_TILE)};
+        cnt = (rect.w - rect.y) * (rect.z - rect.x);
+      }
+    }
+  }
+  if (cnt != 0) key = (p.depth_key == 0) ? (uint32_t)(depth * 1000.f) : __float_as_uint(depth);
+  rects[i] = rect;
+  counts[i] = cnt;
+  dkeys[i] = key;
+}
+
+// createKeys (reference kernel.cu:46-80) in depth-sorted Gaussian order; the
+// depth half of the key is implicit in the emission order.
+__global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t* __restrict__ ids,
+                                                  const uint32_t* __restrict__ offsets,
+                                                  const uint4* __restrict__ rects,
+                                                  uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= n) return;
+  const uint32_t g = ids[j];
+  const uint4 r = rects[g];
+  if (r.z <= r.x || r.w <= r.y) return;
+  uint32_t off = offsets[j];
+  for (uint32_t y = r.y; y < r.w; ++y)
+    for (uint32_t x = r.x; x < r.z; ++x) {
+      tkeys[off] = y * (uint32_t)gx + x;
+      gsid[off] = g;
+      ++off;
+    }
+}
+
+// getRanges (reference kernel.cu:125-150; its P==1 hole is closed here)
+__global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* __restrict__ tkeys,
+                                                     int32_t* __restrict__ ranges) {
+  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (p >= P) return;
+  const uint32_t cur = tkeys[p];
+  if (p == 0) ranges[2 * (size_t)cur] = 0;
+  else {
+    const uint32_t prv = tkeys[p - 1];
+    if (prv != cur) {
+      ranges[2 * (size_t)prv + 1] = (int32_t)p;
+      ranges[2 * (size_t)cur] = (int32_t)p;
+    }
+  }
+  if (p == P - 1) ranges[2 * (size_t)cur + 1] = (int32_t)P;
+}
+
+// 48-byte packed 2D record per Gaussian: one aligned gather (3 x dwordx4)
+// instead of the reference's four (fetch2shared, kernel.cu:13-44).
+//   A = {u.x, u.y, cinv.x, cinv.y}  B = {cinv.z, alpha, col.r, col.g}  C = {col.b, box_x, box_y, 0}
+// box_x = x0 | x1<<16, box_y = y0 | y1<<16 (policy forward_cpu only)
+__global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int footprint,
+                                                      const float* __restrict__ us,
+                                                      const float* __restrict__ cinv,
+                                                      const float* __restrict__ alphas,
+                                                      const float* __restrict__ colors,
+                                                      const int32_t* __restrict__ areas,
+                                                      float4* __restrict__ rec) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
+  const float c0 = cinv[3 * (size_t)i], c1 = cinv[3 * (size_t)i + 1], c2 = cinv[3 * (size_t)i + 2];
+  const float r = colors[3 * (size_t)i], g = colors[3 * (size_t)i + 1], b = colors[3 * (size_t)i + 2];
+  uint32_t bx = 0, by = 0;
+  if (footprint == 1) {
+    int x0, x1, y0, y1;
+    pixel_box(ux, uy, (float)areas[2 * (size_t)i], (float)areas[2 * (size_t)i + 1], W, H, x0, x1, y0, y1);
+    bx = (uint32_t)x0 | ((uint32_t)x1 << 16);
+    by = (uint32_t)y0 | ((uint32_t)y1 << 16);
+  }
+  rec[3 * (size_t)i + 0] = make_float4(ux, uy, c0, c1);
+  rec[3 * (size_t)i + 1] = make_float4(c2, alphas[i], r, g);
+  rec[3 * (size_t)i + 2] = make_float4(b, __uint_as_float(bx), __uint_as_float(by), 0.f);
+}
+
+// ============================================================================
+// draw: per-tile front-to-back blend                   (reference kernel.cu:152-271)
+// ============================================================================
+struct DrawParams {
+  int W, H, gx, T;
+  float alpha_skip, tau_stop;
+  int maha_floor, alpha_clamp;
+};
+
+// Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
+// XCD a contiguous band of tiles so that its private 4-MiB L2 serves 1/8 of the
+// Gaussian records instead of all of them.  Bijective for any T.
+__device__ __forceinline__ int xcd_tile(int b, int T) {
+  const int q = T >> 3, r = T & 7, xcd = b & 7, k = b >> 3;
+  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+}
+
+template <bool BOX>
+__global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
+                                             const int32_t* __restrict__ gsid,
+                                             const float4* __restrict__ rec, float* __restrict__ image,
+                                             int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
+  __shared__ float4 sA[64], sB[64], sC[64];
+  const int tile = xcd_tile(blockIdx.x, p.T);
+  const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
+  const int n = r1 - r0;
+  if (n <= 0) return;  // empty tile: outputs stay 0 (final_tau = 0, as the reference leaves it)
+  const int lane = threadIdx.x;
+  const int px = (tile % p.gx) * EGS_TILE + (lane & 15);
+  const int py0 = (tile / p.gx) * EGS_TILE + (lane >> 4);  // rows py0 + 4k
+  const float fpx = (float)px;
+  float tau[4], cr[4], cg[4], cb[4], fpy[4];
+  int cont[4];
+  bool live[4];
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    fpy[k] = (float)py;
+    live[k] = (px < p.W) && (py < p.H);
+    tau[k] = 1.f; cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f; cont[k] = 0;
+  }
+  for (int base = 0; base < n; base += 64) {
+    __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
+    if (base + lane < n) {
+      const int g = gsid[r0 + base + lane];
+      sA[lane] = rec[3 * (size_t)g];
+      sB[lane] = rec[3 * (size_t)g + 1];
+      sC[lane] = rec[3 * (size_t)g + 2];
+    }
+    __syncthreads();
+    const int m = min(64, n - base);
+    for (int j = 0; j < m; ++j) {
+      const float4 A = sA[j], B = sB[j], C = sC[j];  // wave-uniform address: LDS broadcast
+      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+      if (BOX) {
+        const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+        x0 = bx & 0xFFFF; x1 = bx >> 16; y0 = by & 0xFFFF; y1 = by >> 16;
+      }
+      const float dx = A.x - fpx;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float dy = A.y - fpy[k];
+        float maha = A.z * dx * dx + B.x * dy * dy + 2 * A.w * dx * dy;  // F.5.1, common.cuh:85-88
+        if (p.maha_floor) maha = fmaxf(0.f, maha);
+        float ap = B.y * __expf(-0.5f * maha);
+        if (p.alpha_clamp) ap = fminf(0.99f, ap);
+        bool hit = live[k] && !(ap < p.alpha_skip);
+        if (BOX) hit = hit && (px >= x0) && (px < x1) && (py0 + 4 * k >= y0) && (py0 + 4 * k < y1);
+        if (hit) {
+          const float w = tau[k] * ap;  // F.5
+          cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
+          cont[k] = base + j + 1;
+          tau[k] = tau[k] * (1.f - ap);  // F.5.2
+          if (tau[k] < p.tau_stop) live[k] = false;
+        }
+      }
+      if (!__any(live[0] || live[1] || live[2] || live[3])) goto done;
+    }
+  }
+done:
+  const size_t HW = (size_t)p.W * p.H;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    if (px < p.W && py < p.H) {
+      const size_t pix = (size_t)py * p.W + px;
+      image[pix] = cr[k];
+      image[HW + pix] = cg[k];
+      image[2 * HW + pix] = cb[k];
+      contrib[pix] = cont[k];
+      final_tau[pix] = tau[k];
+    }
+  }
+}
+
+// ============================================================================
+// draw backward: per-tile back-to-front gradients        (reference kernel.cu:809-950)
+// ============================================================================
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  return v + __int_as_float(t);
+}
+// wave64 sum; the total is valid in lanes 48..63 (read lane 63)
+__device__ __forceinline__ float wave_reduce_to_last(float v) {
+  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
+  v = dpp_add<0x140, 0xF>(v);  // row_mirror
+  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
+  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+  return v;
+}
+
+template <bool BOX>
+__global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __restrict__ ranges,
+                                                 const int32_t* __restrict__ gsid,
+                                                 const float4* __restrict__ rec,
+                                                 const float* __restrict__ final_tau,
+                                                 const int32_t* __restrict__ contrib,
+                                                 const float* __restrict__ dLdg, float* __restrict__ dus,
+                                                 float* __restrict__ dcinv, float* __restrict__ dalpha,
+                                                 float* __restrict__ dcolor) {
+  __shared__ float4 sA[64], sB[64], sC[64];
+  __shared__ int sG[64];
+  const int tile = xcd_tile(blockIdx.x, p.T);
+  const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
+  const int n = r1 - r0;
+  if (n <= 0) return;
+  const int lane = threadIdx.x;
+  const int px = (tile % p.gx) * EGS_TILE + (lane & 15);
+  const int py0 = (tile / p.gx) * EGS_TILE + (lane >> 4);
+  const float fpx = (float)px;
+  const size_t HW = (size_t)p.W * p.H;
+  float tau[4], fpy[4], lr[4], lg[4], lb[4], qr[4], qg[4], qb[4];  // q = gamma_cur2last
+  int cont[4];
+  int maxcont = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int py = py0 + 4 * k;
+    fpy[k] = (float)py;
+    tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f;
+    qr[k] = 0.f; qg[k] = 0.f; qb[k] = 0.f;
+    if (px < p.W && py < p.H) {
+      const size_t pix = (size_t)py * p.W + px;
+      tau[k] = final_tau[pix];
+      cont[k] = contrib[pix];
+      lr[k] = dLdg[pix]; lg[k] = dLdg[HW + pix]; lb[k] = dLdg[2 * HW + pix];
+    }
+    maxcont = max(maxcont, cont[k]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) maxcont = max(maxcont, __shfl_xor(maxcont, d, 64));
+  maxcont = min(maxcont, n);
+  if (maxcont <= 0) return;
+
+  for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
+    __syncthreads();
+    const int idx = c * 64 + lane;
+    if (idx < n) {
+      const int g = gsid[r0 + idx];
+      sG[lane] = g;
+      sA[lane] = rec[3 * (size_t)g];
+      sB[lane] = rec[3 * (size_t)g + 1];
+      sC[lane] = rec[3 * (size_t)g + 2];
+    }
+    __syncthreads();
+    const int jhi = min(63, maxcont - 1 - c * 64);
+    for (int j = jhi; j >= 0; --j) {
+      const int i = c * 64 + j;  // forward index of this entry in the tile list
+      const float4 A = sA[j], B = sB[j], C = sC[j];
+      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+      if (BOX) {
+        const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+        x0 = bx & 0xFFFF; x1 = bx >> 16; y0 = by & 0xFFFF; y1 = by >> 16;
+      }
+      const float dx = A.x - fpx;
+      float a_al = 0.f, a_cr = 0.f, a_cg = 0.f, a_cb = 0.f, a_ux = 0.f, a_uy = 0.f, a_c0 = 0.f, a_c1 = 0.f,
+            a_c2 = 0.f;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (i >= cont[k]) continue;  // this pixel never reached entry i (kernel.cu:899)
+        const float dy = A.y - fpy[k];
+        float maha = A.z * dx * dx + B.x * dy * dy + 2 * A.w * dx * dy;
+        if (p.maha_floor) maha = fmaxf(0.f, maha);
+        const float g = __expf(-0.5f * maha);
+        float ap = B.y * g;
+        if (p.alpha_clamp) ap = fminf(0.99f, ap);
+        if (BOX && !((px >= x0) && (px < x1) && (py0 + 4 * k >= y0) && (py0 + 4 * k < y1))) continue;
+        if (ap < p.alpha_skip) continue;
+        tau[k] = tau[k] / (1.f - ap);  // undo F.5.2
+        const float tk = tau[k];
+        // B.5a: dgamma/dalpha' = tau (color - gamma_cur2last)
+        const float dl_dap = lr[k] * (tk * (B.z - qr[k])) + lg[k] * (tk * (B.w - qg[k])) + lb[k] * (tk * (C.x - qb[k]));
+        a_al += dl_dap * g;  // B.5.1a: dalpha'/dalpha = g (also where the clamp binds, kernel.cu:921)
+        const float wgt = ap * tk;  // B.5b
+        a_cr += lr[k] * wgt; a_cg += lg[k] * wgt; a_cb += lb[k] * wgt;
+        a_ux += dl_dap * ((-A.z * dx - A.w * dy) * ap);  // B.5.2b
+        a_uy += dl_dap * ((-A.w * dx - B.x * dy) * ap);
+        a_c0 += dl_dap * (-0.5f * ap * (dx * dx));  // B.5.2c
+        a_c1 += dl_dap * (-1.0f * ap * (dx * dy));
+        a_c2 += dl_dap * (-0.5f * ap * (dy * dy));
+        qr[k] = ap * B.z + (1.f - ap) * qr[k];
+        qg[k] = ap * B.w + (1.f - ap) * qg[k];
+        qb[k] = ap * C.x + (1.f - ap) * qb[k];
+        any = true;
+      }
+      if (__any(any)) {  // wave-uniform
+        a_al = wave_reduce_to_last(a_al);
+        a_cr = wave_reduce_to_last(a_cr); a_cg = wave_reduce_to_last(a_cg); a_cb = wave_reduce_to_last(a_cb);
+        a_ux = wave_reduce_to_last(a_ux); a_uy = wave_reduce_to_last(a_uy);
+        a_c0 = wave_reduce_to_last(a_c0); a_c1 = wave_reduce_to_last(a_c1); a_c2 = wave_reduce_to_last(a_c2);
+        if (lane == 63) {  // one atomic set per (tile, Gaussian)
+          const size_t g = (size_t)sG[j];
+          unsafeAtomicAdd(dalpha + g, a_al);
+          unsafeAtomicAdd(dcolor + 3 * g, a_cr);
+          unsafeAtomicAdd(dcolor + 3 * g + 1, a_cg);
+          unsafeAtomicAdd(dcolor + 3 * g + 2, a_cb);
+          unsafeAtomicAdd(dus + 2 * g, a_ux);
+          unsafeAtomicAdd(dus + 2 * g + 1, a_uy);
+          unsafeAtomicAdd(dcinv + 3 * g, a_c0);
+          unsafeAtomicAdd(dcinv + 3 * g + 1, a_c1);
+          unsafeAtomicAdd(dcinv + 3 * g + 2, a_c2);
+        }
+      }
+    }
+  }
+}
+
+// ============================================================================
+// host orchestration
+// ============================================================================
+struct BinLayout {
+  uint4* rects;
+  uint32_t *counts, *dkeys, *dkeys_alt, *ids, *ids_alt, *offsets, *scan_partials;
+  SortWs sort;
+};
+static size_t bin_ws_bytes(int n) {
+  const size_t N = (size_t)(n > 0 ? n : 1);
+  return align_up(N * 16, 256) + 6 * align_up(N * 4, 256) + scan_ws_bytes(n) + sort_ws_bytes(n) + 4096;
+}
+static bool bin_carve(void* ws, size_t bytes, int n, BinLayout* L) {
+  Carver cv(ws, bytes);
+  const size_t N = (size_t)(n > 0 ? n : 1);
+  L->rects = cv.take<uint4>(N);
+  L->counts = cv.take<uint32_t>(N);
+  L->dkeys = cv.take<uint32_t>(N);
+  L->dkeys_alt = cv.take<uint32_t>(N);
+  L->ids = cv.take<uint32_t>(N);
+  L->ids_alt = cv.take<uint32_t>(N);
+  L->offsets = cv.take<uint32_t>(N);
+  L->scan_partials = cv.take<uint32_t>(scan_ws_bytes(n) / 4);
+  return sort_ws_carve(cv, n, &L->sort) && cv.ok();
+}
+
+static int tile_bits(int T) {
+  int b = 1;
+  while ((1 << b) < T) ++b;
+  return b;
+}
+
+struct DrawLayout {
+  uint32_t *tkeys, *tkeys_alt, *gsid_alt;
+  float4* rec;
+  SortWs sort;
+};
+static size_t draw_ws_bytes(int n, int64_t P) {
+  const size_t N = (size_t)(n > 0 ? n : 1), PP = (size_t)(P > 0 ? P : 1);
+  return 3 * align_up(PP * 4, 256) + align_up(N * 48, 256) + sort_ws_bytes(P) + 4096;
+}
+static bool draw_carve(void* ws, size_t bytes, int n, int64_t P, DrawLayout* L) {
+  Carver cv(ws, bytes);
+  const size_t N = (size_t)(n > 0 ? n : 1), PP = (size_t)(P > 0 ? P : 1);
+  L->tkeys = cv.take<uint32_t>(PP);
+  L->tkeys_alt = cv.take<uint32_t>(PP);
+  L->gsid_alt = cv.take<uint32_t>(PP);
+  L->rec = cv.take<float4>(3 * N);
+  return sort_ws_carve(cv, P, &L->sort) && cv.ok();
+}
+
+static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol) {
+  DrawParams p;
+  p.W = W; p.H = H;
+  p.gx = div_up(W, EGS_TILE);
+  p.T = p.gx * div_up(H, EGS_TILE);
+  p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
+  p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
+  return p;
+}
+
+}  // namespace egs
+
+using namespace egs;
+
+extern "C" size_t egs_sort_pairs_ws_bytes(int64_t n) { return sort_ws_bytes(n); }
+
+extern "C" int egs_sort_pairs(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                              int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_in_alt_host,
+                              void* stream) {
+  EGS_CHECK_ARG(n >= 0 && begin_bit >= 0 && end_bit <= 32 && begin_bit <= end_bit);
+  if (result_in_alt_host) *result_in_alt_host = (n > 0) ? (sort_passes(begin_bit, end_bit) & 1) : 0;
+  if (n == 0 || begin_bit == end_bit) {
+    if (result_in_alt_host) *result_in_alt_host = 0;
+    return 0;
+  }
+  EGS_CHECK_ARG(keys && vals && keys_alt && vals_alt && ws);
+  Carver cv(ws, ws_bytes);
+  SortWs w;
+  if (!sort_ws_carve(cv, n, &w)) {
+    set_error(EGS_ERR_WORKSPACE, "sort workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  return radix_sort(n, keys, vals, keys_alt, vals_alt, begin_bit, end_bit, w, (hipStream_t)stream);
+}
+
+extern "C" size_t egs_scan_ws_bytes(int64_t n) { return scan_ws_bytes(n); }
+
+extern "C" int egs_exclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* gather, uint32_t* out,
+                                      uint32_t* total, void* ws, size_t ws_bytes, void* stream) {
+  EGS_CHECK_ARG(n >= 0);
+  EGS_CHECK_ARG(n == 0 || (in && out && ws));
+  if (ws_bytes < scan_ws_bytes(n)) {
+    set_error(EGS_ERR_WORKSPACE, "scan workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  return exclusive_scan(n, in, gather, out, total, (uint32_t*)ws, (hipStream_t)stream);
+}
+
+extern "C" size_t egs_splat_bin_ws_bytes(int n) { return bin_ws_bytes(n); }
+extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height) {
+  (void)width; (void)height;
+  return draw_ws_bytes(n, patches);
+}
+
+extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas, float* depths,
+                             const EgsPolicy* pol, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                             void* stream) {
+  EGS_CHECK_ARG(n >= 0 && width > 0 && height > 0 && pol && total_patches);
+  EGS_CHECK_ARG(width < 32768 && height < 32768);
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {  // the reference dereferences patch_offset_per_gs[-1] here (gausplat.cu:67)
+    EGS_HIP(hipMemsetAsync(total_patches, 0, 4, s));
+    return 0;
+  }
+  EGS_CHECK_ARG(us && areas && depths && ws_bin);
+  BinLayout L;
+  if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) {
+    set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  BinParams p;
+  p.W = width; p.H = height;
+  p.gx = div_up(width, EGS_TILE); p.gy = div_up(height, EGS_TILE);
+  p.footprint = pol->footprint; p.far_cull = pol->far_cull; p.depth_key = pol->depth_key;
+  p.mutate = (pol->footprint == 0);
+  hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, s, n, p, us, areas, depths, L.rects,
+                     L.counts, L.dkeys, L.ids);
+  EGS_LAUNCH_OK();
+  // 4 passes (even): the sorted (dkeys, ids) end up in the primary buffers
+  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, 32, L.sort, s);
+  if (rc) return rc;
+  return exclusive_scan(n, L.counts, L.ids, L.offsets, total_patches, L.scan_partials, s);
+}
+
+extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, const float* us,
+                              const float* cinv2ds, const float* alphas, const float* colors,
+                              const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                              size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                              int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+  EGS_CHECK_ARG(n >= 0 && patches >= 0 && patches < (int64_t)0x7FFFFFFF && width > 0 && height > 0 && pol);
+  EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
+  hipStream_t s = (hipStream_t)stream;
+  const DrawParams dp = make_draw_params(width, height, pol);
+  EGS_HIP(hipMemsetAsync(patch_range_per_tile, 0, (size_t)dp.T * 8, s));
+  if (n == 0 || patches == 0) return 0;  // nothing to draw: outputs stay zero
+  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && areas && ws_bin && ws_draw && gsid_per_patch);
+  BinLayout B;
+  if (!bin_carve(const_cast<void*>(ws_bin), bin_ws_bytes(n), n, &B)) return EGS_ERR_WORKSPACE;
+  DrawLayout D;
+  if (!draw_carve(ws_draw, ws_draw_bytes, n, patches, &D)) {
+    set_error(EGS_ERR_WORKSPACE, "draw workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  const int tb = tile_bits(dp.T);
+  const int passes = sort_passes(0, tb);
+  uint32_t* gs_primary = (uint32_t*)gsid_per_patch;
+  // choose the emission buffers so that the sorted result lands in the primary ones
+  uint32_t* k0 = (passes & 1) ? D.tkeys_alt : D.tkeys;
+  uint32_t* k1 = (passes & 1) ? D.tkeys : D.tkeys_alt;
+  uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
+  uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
+  hipLaunchKernelGGL(k_bin_emit, dim3(div_up(n, 256)), dim3(256), 0, s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
+                     v0);
+  hipLaunchKernelGGL(k_pack_records, dim3(div_up(n, 256)), dim3(256), 0, s, n, width, height, pol->footprint, us,
+                     cinv2ds, alphas, colors, areas, D.rec);
+  EGS_LAUNCH_OK();
+  int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), 0, s, patches, D.tkeys,
+                     patch_range_per_tile);
+  if (pol->footprint == 1)
+    hipLaunchKernelGGL(k_draw<true>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
+                       image, contrib, final_tau);
+  else
+    hipLaunchKernelGGL(k_draw<false>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
+                       image, contrib, final_tau);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" size_t egs_splat_bwd_ws_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * 48, 256) + 256; }
+
+extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, const float* us,
+                             const float* cinv2ds, const float* alphas, const float* colors,
+                             const int32_t* areas, const EgsPolicy* pol, const int32_t* contrib,
+                             const float* final_tau, const int32_t* patch_range_per_tile,
+                             const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                             float* dloss_dus, float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors,
+                             void* stream) {
+  EGS_CHECK_ARG(n >= 0 && patches >= 0 && width > 0 && height > 0 && pol);
+  if (n == 0 || patches == 0) return 0;
+  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && contrib && final_tau && patch_range_per_tile &&
+                gsid_per_patch && dloss_dgammas && ws && dloss_dus && dloss_dcinv2ds && dloss_dalphas &&
+                dloss_dcolors);
+  EGS_CHECK_ARG(pol->footprint == 0 || areas);
+  if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
+    set_error(EGS_ERR_WORKSPACE, "splat_bwd workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  float4* rec = (float4*)ws;
+  const DrawParams dp = make_draw_params(width, height, pol);
+  hipLaunchKernelGGL(k_pack_records, dim3(div_up(n, 256)), dim3(256), 0, s, n, width, height, pol->footprint, us,
+                     cinv2ds, alphas, colors, areas, rec);
+  if (pol->footprint == 1)
+    hipLaunchKernelGGL(k_draw_bwd<true>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, rec,
+                       final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
+  else
+    hipLaunchKernelGGL(k_draw_bwd<false>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, rec,
+                       final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
+  EGS_LAUNCH_OK();
+  return 0;
+}

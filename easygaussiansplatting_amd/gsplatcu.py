@@ -1,0 +1,308 @@
+"""Drop-in replacement of the reference's CUDA extension module ``gsplatcu``.
+
+Same seven ops, same positional signatures, same return lists as the pybind11
+module built from reference gsplatcu/ext.cpp:68-77 (host wrappers
+gsplatcu/gausplat.cu), so the reference's callers -- forward_gpu.py:47-60,
+backward_gpu.py:81-138, gsplat/gsmodel.py:21-39,67-69 -- run unmodified with
+
+    import easygaussiansplatting_amd.gsplatcu as gsc      # or: import gsplatcu as gsc
+
+Underneath, every op is one (or a few) hand-written HIP kernels for gfx950 in
+``libegs_hip.so`` reached through the C ABI of include/egs_hip.h; this module is
+only host plumbing: validation, output allocation from torch's caching
+allocator, the current HIP stream.  Differences from the reference, all
+supersets:
+
+* work is enqueued on ``torch.cuda.current_stream()`` with no device-wide
+  synchronisation (the reference syncs after every kernel, common.cuh:16-24);
+  ``splat`` performs exactly one 4-byte device->host read (the patch count),
+  where the reference has one too (gausplat.cu:67);
+* bad dtype / device / shape raise ``ValueError``/``TypeError`` instead of
+  reading out of bounds; HIP errors raise ``RuntimeError``;
+* ``N == 0`` and ``P == 0`` are legal (the reference crashes at gausplat.cu:67);
+* the raster policy is module state: ``set_policy("gsplatcu")``
+  (default, the CUDA extension's semantics) or ``set_policy("forward_cpu")``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import EgsPolicy
+
+__all__ = ["project", "computeCov3D", "computeCov2D", "sh2Color", "inverseCov2D", "splat", "splatB",
+           "set_policy", "get_policy", "chain_rule"]
+
+_policy_name = "gsplatcu"
+_policy = None
+
+
+def _pol() -> EgsPolicy:
+    global _policy
+    if _policy is None:
+        set_policy(_policy_name)
+    return _policy
+
+
+def set_policy(name: str) -> None:
+    """Select which of the reference's pipeline definitions the ops follow:
+    ``"gsplatcu"`` (gsplatcu/kernel.cu; default) or ``"forward_cpu"``
+    (gsplat/gausplat.py as driven by forward_cpu.py)."""
+    global _policy, _policy_name
+    lib = _lib.load()
+    p = EgsPolicy()
+    if name == "gsplatcu":
+        lib.egs_policy_gsplatcu(C.byref(p))
+    elif name == "forward_cpu":
+        lib.egs_policy_forward_cpu(C.byref(p))
+    else:
+        raise ValueError("unknown raster policy %r (expected 'gsplatcu' or 'forward_cpu')" % (name,))
+    _policy, _policy_name = p, name
+
+
+def get_policy() -> str:
+    return _policy_name
+
+
+# ------------------------------------------------------------------ helpers
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _chk(t, name, dtype, shape):
+    """dtype/device/shape validation; returns a contiguous tensor (a copy only
+    if the caller's tensor was not contiguous, like the reference's .contiguous())."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError("%s must be a torch.Tensor, got %s" % (name, type(t).__name__))
+    if not t.is_cuda:
+        raise ValueError("%s must live on the GPU (got device %s)" % (name, t.device))
+    if t.dtype != dtype:
+        raise ValueError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if len(shape) != t.dim() or any(s is not None and s != d for s, d in zip(shape, t.shape)):
+        raise ValueError("%s must have shape %s, got %s" % (name, list(shape), list(t.shape)))
+    return t.contiguous()
+
+
+def _zeros(shape, like, dtype=torch.float32):
+    return torch.zeros(shape, dtype=dtype, device=like.device)
+
+
+def _lib_on(t):
+    lib = _lib.load()
+    if t.device.index is not None and t.device.index != torch.cuda.current_device():
+        raise ValueError("tensors live on %s but the current device is cuda:%d"
+                         % (t.device, torch.cuda.current_device()))
+    return lib
+
+
+# ------------------------------------------------------------------ the seven ops
+def project(pws, Rcw, tcw, focal_x, focal_y, center_x, center_y, calc_J):
+    """-> [us[N,2], pcs[N,3], depths[N]] (+ [du_dpcs[N,2,3]] if calc_J).
+    Reference: ext.cpp:54-61, gausplat.cu:253-296, kernel.cu:553-617."""
+    pws = _chk(pws, "pws", torch.float32, (None, 3))
+    Rcw = _chk(Rcw, "Rcw", torch.float32, (3, 3))
+    tcw = _chk(tcw, "tcw", torch.float32, (3,))
+    lib = _lib_on(pws)
+    n = pws.shape[0]
+    us = _zeros((n, 2), pws); pcs = _zeros((n, 3), pws); depths = _zeros((n,), pws)
+    J = _zeros((n, 2, 3), pws) if calc_J else None
+    _lib.check(lib.egs_project(n, _ptr(pws), _ptr(Rcw), _ptr(tcw), float(focal_x), float(focal_y),
+                               float(center_x), float(center_y), C.byref(_pol()), _ptr(us), _ptr(pcs),
+                               _ptr(depths), _ptr(J), _stream()))
+    return [us, pcs, depths, J] if calc_J else [us, pcs, depths]
+
+
+def computeCov3D(rots, scales, depths, calc_J):
+    """-> [cov3ds[N,6]] (+ [dcov3d_drots[N,6,4], dcov3d_dscales[N,6,3]]).
+    Reference: ext.cpp:39-42, gausplat.cu:162-199, kernel.cu:326-423."""
+    rots = _chk(rots, "rots", torch.float32, (None, 4))
+    n = rots.shape[0]
+    scales = _chk(scales, "scales", torch.float32, (n, 3))
+    depths = _chk(depths, "depths", torch.float32, (n,))
+    lib = _lib_on(rots)
+    cov3ds = _zeros((n, 6), rots)
+    dq = _zeros((n, 6, 4), rots) if calc_J else None
+    ds = _zeros((n, 6, 3), rots) if calc_J else None
+    _lib.check(lib.egs_cov3d(n, _ptr(rots), _ptr(scales), _ptr(depths), C.byref(_pol()), _ptr(cov3ds),
+                             _ptr(dq), _ptr(ds), _stream()))
+    return [cov3ds, dq, ds] if calc_J else [cov3ds]
+
+
+def computeCov2D(cov3ds, pcs, Rcw, depths, focal_x, focal_y, width, height, calc_J):
+    """-> [cov2ds[N,3]] (+ [dcov2d_dcov3ds[N,3,6], dcov2d_dpcs[N,3,3]]).
+    NOTE the argument order ``width, height`` (ext.cpp:44-52); the reference's
+    forward_gpu.py:53 passes them swapped.  Reference: gausplat.cu:201-251,
+    kernel.cu:425-551."""
+    pcs = _chk(pcs, "pcs", torch.float32, (None, 3))
+    n = pcs.shape[0]
+    cov3ds = _chk(cov3ds, "cov3ds", torch.float32, (n, 6))
+    Rcw = _chk(Rcw, "Rcw", torch.float32, (3, 3))
+    depths = _chk(depths, "depths", torch.float32, (n,))
+    lib = _lib_on(pcs)
+    cov2ds = _zeros((n, 3), pcs)
+    d3 = _zeros((n, 3, 6), pcs) if calc_J else None
+    dpc = _zeros((n, 3, 3), pcs) if calc_J else None
+    _lib.check(lib.egs_cov2d(n, _ptr(cov3ds), _ptr(pcs), _ptr(Rcw), _ptr(depths), float(focal_x),
+                             float(focal_y), float(width), float(height), C.byref(_pol()), _ptr(cov2ds),
+                             _ptr(d3), _ptr(dpc), _stream()))
+    return [cov2ds, d3, dpc] if calc_J else [cov2ds]
+
+
+def sh2Color(shs, pws, twc, calc_J):
+    """-> [colors[N,3]] (+ [dcolor_dshs[N,1,K/3], dcolor_dpws[N,3,3]]).
+    shs[N,K], K in {3,12,27,48}, layout sh[i, 3*c + rgb].
+    Reference: ext.cpp:63-66, gausplat.cu:298-338, kernel.cu:619-807."""
+    pws = _chk(pws, "pws", torch.float32, (None, 3))
+    n = pws.shape[0]
+    shs = _chk(shs, "shs", torch.float32, (n, None))
+    K = shs.shape[1]
+    if K not in (3, 12, 27, 48):
+        raise ValueError("shs must have 3, 12, 27 or 48 columns (SH degree 0..3), got %d" % K)
+    twc = _chk(twc, "twc", torch.float32, (3,))
+    lib = _lib_on(pws)
+    colors = _zeros((n, 3), pws)
+    dsh = _zeros((n, 1, K // 3), pws) if calc_J else None
+    dpw = _zeros((n, 3, 3), pws) if calc_J else None
+    _lib.check(lib.egs_sh2color(n, K, _ptr(shs), _ptr(pws), _ptr(twc), _ptr(colors), _ptr(dsh), _ptr(dpw),
+                                _stream()))
+    return [colors, dsh, dpw] if calc_J else [colors]
+
+
+def inverseCov2D(cov2ds, depths, calc_J):
+    """-> [cinv2ds[N,3], areas[N,2] int32] (+ [dcinv2d_dcov2ds[N,3,3]]).
+    ``depths`` is updated IN PLACE (NaN determinant -> -1) as in the reference
+    (kernel.cu:300-305).  Reference: ext.cpp:34-36, gausplat.cu:340-373."""
+    cov2ds = _chk(cov2ds, "cov2ds", torch.float32, (None, 3))
+    n = cov2ds.shape[0]
+    depths = _chk(depths, "depths", torch.float32, (n,))
+    lib = _lib_on(cov2ds)
+    cinv = _zeros((n, 3), cov2ds)
+    areas = _zeros((n, 2), cov2ds, torch.int32)
+    J = _zeros((n, 3, 3), cov2ds) if calc_J else None
+    _lib.check(lib.egs_inv_cov2d(n, _ptr(cov2ds), _ptr(depths), C.byref(_pol()), _ptr(cinv), _ptr(areas),
+                                 _ptr(J), _stream()))
+    return [cinv, areas, J] if calc_J else [cinv, areas]
+
+
+def _tiles(width, height):
+    return ((width + 15) // 16) * ((height + 15) // 16)
+
+
+def _alphas(alphas, n):
+    if not isinstance(alphas, torch.Tensor) or alphas.numel() != n:
+        raise ValueError("alphas must be a tensor of shape [N] or [N,1] with N=%d" % n)
+    return _chk(alphas.reshape(n), "alphas", torch.float32, (n,))
+
+
+def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
+    """-> [image[3,H,W], contrib[H,W] int32, final_tau[H,W],
+           patch_range_per_tile[T,2] int32, gsid_per_patch[P] int32].
+    ``depths`` and ``areas`` are updated IN PLACE for Gaussians whose tile rect is
+    empty (kernel.cu:114-119).  Reference: ext.cpp:10-18, gausplat.cu:24-112."""
+    height, width = int(height), int(width)
+    if height <= 0 or width <= 0:
+        raise ValueError("height and width must be positive")
+    us = _chk(us, "us", torch.float32, (None, 2))
+    n = us.shape[0]
+    cinv2ds = _chk(cinv2ds, "cinv2ds", torch.float32, (n, 3))
+    alphas = _alphas(alphas, n)
+    depths = _chk(depths, "depths", torch.float32, (n,))
+    colors = _chk(colors, "colors", torch.float32, (n, 3))
+    areas = _chk(areas, "areas", torch.int32, (n, 2))
+    lib = _lib_on(us)
+    dev = us.device
+    pol = C.byref(_pol())
+    image = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
+    contrib = torch.zeros((height, width), dtype=torch.int32, device=dev)
+    final_tau = torch.zeros((height, width), dtype=torch.float32, device=dev)
+    ranges = torch.empty((_tiles(width, height), 2), dtype=torch.int32, device=dev)
+    ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
+    ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
+    total = torch.empty(1, dtype=torch.int32, device=dev)
+    st = _stream()
+    _lib.check(lib.egs_splat_bin(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, _ptr(ws_bin),
+                                 ws_bin_bytes, _ptr(total), st))
+    patches = int(total.item()) & 0xFFFFFFFF      # the one 4-byte read-back (reference: gausplat.cu:67)
+    if patches >= 2**31:
+        raise RuntimeError("splat: %d tile patches overflow int32 indexing" % patches)
+    gsid = torch.empty(patches, dtype=torch.int32, device=dev)
+    ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
+    ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.egs_splat_draw(n, patches, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                  _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
+                                  _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid), st))
+    return [image, contrib, final_tau, ranges, gsid]
+
+
+def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
+           gsid_per_patch, dloss_dgammas, areas=None):
+    """-> [dloss_dus[N,1,2], dloss_dcinv2ds[N,1,3], dloss_dalphas[N,1,1], dloss_dcolors[N,1,3]].
+    Reference: ext.cpp:20-32, gausplat.cu:114-159, kernel.cu:809-950.  ``areas``
+    is an extension needed only under the forward_cpu policy (pixel boxes)."""
+    height, width = int(height), int(width)
+    us = _chk(us, "us", torch.float32, (None, 2))
+    n = us.shape[0]
+    cinv2ds = _chk(cinv2ds, "cinv2ds", torch.float32, (n, 3))
+    alphas = _alphas(alphas, n)
+    colors = _chk(colors, "colors", torch.float32, (n, 3))
+    contrib = _chk(contrib, "contrib", torch.int32, (height, width))
+    final_tau = _chk(final_tau, "final_tau", torch.float32, (height, width))
+    ranges = _chk(patch_range_per_tile, "patch_range_per_tile", torch.int32, (_tiles(width, height), 2))
+    gsid = _chk(gsid_per_patch, "gsid_per_patch", torch.int32, (None,))
+    dl = _chk(dloss_dgammas, "dloss_dgammas", torch.float32, (3, height, width))
+    pol = _pol()
+    if pol.footprint == 1:
+        if areas is None:
+            raise ValueError("splatB under the forward_cpu policy needs areas= (pixel boxes)")
+        areas = _chk(areas, "areas", torch.int32, (n, 2))
+    lib = _lib_on(us)
+    dev = us.device
+    d_us = torch.zeros((n, 1, 2), dtype=torch.float32, device=dev)
+    d_cinv = torch.zeros((n, 1, 3), dtype=torch.float32, device=dev)
+    d_alpha = torch.zeros((n, 1, 1), dtype=torch.float32, device=dev)
+    d_color = torch.zeros((n, 1, 3), dtype=torch.float32, device=dev)
+    ws_bytes = lib.egs_splat_bwd_ws_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                 _ptr(colors), _ptr(areas), C.byref(pol), _ptr(contrib), _ptr(final_tau),
+                                 _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes, _ptr(d_us), _ptr(d_cinv),
+                                 _ptr(d_alpha), _ptr(d_color), _stream()))
+    return [d_us, d_cinv, d_alpha, d_color]
+
+
+# ------------------------------------------------------------------ fused chain rule (extension)
+def chain_rule(dloss_dus, dloss_dcinv2ds, dloss_dcolors, Rcw, dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots,
+               dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws):
+    """One kernel for the nine batched matmuls of GSFunction.backward
+    (gsmodel.py:71-85 == backward_cpu.py:476-482).
+    -> (dloss_dpws[N,3], dloss_dshs[N,K], dloss_dscales[N,3], dloss_drots[N,4])."""
+    n = dloss_dus.shape[0]
+    g_us = _chk(dloss_dus.reshape(n, 2), "dloss_dus", torch.float32, (n, 2))
+    g_ci = _chk(dloss_dcinv2ds.reshape(n, 3), "dloss_dcinv2ds", torch.float32, (n, 3))
+    g_co = _chk(dloss_dcolors.reshape(n, 3), "dloss_dcolors", torch.float32, (n, 3))
+    Rcw = _chk(Rcw, "Rcw", torch.float32, (3, 3))
+    nc = dcolor_dshs.shape[-1]
+    Js = [_chk(dcinv2d_dcov2ds, "dcinv2d_dcov2ds", torch.float32, (n, 3, 3)),
+          _chk(dcov2d_dcov3ds, "dcov2d_dcov3ds", torch.float32, (n, 3, 6)),
+          _chk(dcov3d_drots, "dcov3d_drots", torch.float32, (n, 6, 4)),
+          _chk(dcov3d_dscales, "dcov3d_dscales", torch.float32, (n, 6, 3)),
+          _chk(dcolor_dshs, "dcolor_dshs", torch.float32, (n, 1, nc)),
+          _chk(du_dpcs, "du_dpcs", torch.float32, (n, 2, 3)),
+          _chk(dcov2d_dpcs, "dcov2d_dpcs", torch.float32, (n, 3, 3)),
+          _chk(dcolor_dpws, "dcolor_dpws", torch.float32, (n, 3, 3))]
+    lib = _lib_on(g_us)
+    dev = g_us.device
+    dpws = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    dshs = torch.empty((n, 3 * nc), dtype=torch.float32, device=dev)
+    dscales = torch.empty((n, 3), dtype=torch.float32, device=dev)
+    drots = torch.empty((n, 4), dtype=torch.float32, device=dev)
+    _lib.check(lib.egs_chain_rule(n, 3 * nc, _ptr(g_us), _ptr(g_ci), _ptr(g_co), _ptr(Rcw),
+                                  *[_ptr(j) for j in Js], _ptr(dpws), _ptr(dshs), _ptr(dscales), _ptr(drots),
+                                  _stream()))
+    return dpws, dshs, dscales, drots

@@ -1,0 +1,169 @@
+/*
+ * egs_hip.h -- C ABI of libegs_hip.so: the MI355X (gfx950) rasterizer hot path
+ * that replaces the reference's CUDA extension `gsplatcu`.
+ *
+ * Drop-in boundary: the reference binds seven torch ops through
+ * pybind11 (reference gsplatcu/ext.cpp:68-77, host wrappers gsplatcu/gausplat.cu).
+ * Here the same seven ops are plain `extern "C"` functions over raw device
+ * pointers + a HIP stream: no torch / pybind types cross this boundary.  The
+ * Python mirror of the reference interface (easygaussiansplatting_amd/gsplatcu.py)
+ * binds them with ctypes; INTEGRATION.md shows the stub a reference maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in `_host`;
+ *   - tensors are fp32 / int32 row-major contiguous, shapes as in SURVEY.md §8b;
+ *   - `stream` is a hipStream_t (passed as void*); every call only ENQUEUES work
+ *     on it -- no device-wide synchronisation, no allocation;
+ *   - Jacobian pointers may be NULL (calc_J = False);
+ *   - outputs must be zero-filled by the caller (the reference allocates them with
+ *     torch::full(.., 0), gausplat.cu:36-38,170,214,265,307,347): culled Gaussians
+ *     are left untouched and therefore read as 0;
+ *   - return value: 0 on success, otherwise a hipError_t (or EGS_ERR_*) and
+ *     egs_last_error_string() describes it.
+ */
+#ifndef EGS_HIP_H_
+#define EGS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define EGS_ABI_VERSION 1
+
+#define EGS_ERR_BAD_ARG 10001
+#define EGS_ERR_WORKSPACE 10002
+
+/* Raster policy: which of the reference's three mutually inconsistent pipeline
+ * definitions to follow.  One kernel family, runtime-uniform
+ * parameters.  egs_policy_gsplatcu() == the CUDA extension (drop-in default),
+ * egs_policy_forward_cpu() == forward_cpu.py / gsplat/gausplat.py. */
+typedef struct EgsPolicy {
+  int32_t near_cull;   /* project: z < 0.2 -> depth = -1, outputs stay 0   (kernel.cu:588)            */
+  int32_t fov_mode;    /* 0: lim = 1.3*W/(2fx) (gausplat.cu:225) 1: 1.3*2*atan(W/(2fx)) (gausplat.py:136) 2: none */
+  float det_eps;       /* added to det(cov2d)                              (gausplat.py:179)          */
+  int32_t nan_cull;    /* inverseCov2D: NaN 1/det -> depth = -1            (kernel.cu:300-305)        */
+  int32_t radius_mode; /* 0: ceil(3 sqrt|a|) (kernel.cu:308)  1: trunc(3 sqrt a) (gausplat.py:181)     */
+  int32_t footprint;   /* 0: every pixel of every tile in the rect (kernel.cu:105-110)
+                          1: the pixel box of gausplat.py:212-215                                      */
+  int32_t far_cull;    /* splat: skip depth<0.2 || depth>100 || |u/[W,H]|>1.3 (gausplat.py:204,208)    */
+  int32_t maha_floor;  /* max(0, m)                                        (kernel.cu:243)            */
+  int32_t alpha_clamp; /* min(0.99, alpha')                                (kernel.cu:245)            */
+  float alpha_skip;    /* skip alpha' < 0.002                              (kernel.cu:246)            */
+  float tau_stop;      /* pixel done when tau < 1e-4                       (kernel.cu:256)            */
+  int32_t depth_key;   /* 0: uint32(depth*1000) (kernel.cu:73)  1: raw fp32 bits (== argsort, gausplat.py:192) */
+} EgsPolicy;
+
+void egs_policy_gsplatcu(EgsPolicy* p);
+void egs_policy_forward_cpu(EgsPolicy* p);
+
+int egs_abi_version(void);
+const char* egs_last_error_string(void);
+
+/* ---- per-Gaussian stages ------------------------------------------------ */
+
+/* gsplatcu.project  (ext.cpp:54-61, gausplat.cu:253-296, kernel.cu:553-617).
+ * pws[N,3], Rcw[9], tcw[3] -> us[N,2], pcs[N,3], depths[N], du_dpcs[N,2,3]|NULL */
+int egs_project(int n, const float* pws, const float* Rcw, const float* tcw, float fx, float fy,
+                float cx, float cy, const EgsPolicy* pol, float* us, float* pcs, float* depths,
+                float* du_dpcs, void* stream);
+
+/* gsplatcu.computeCov3D  (ext.cpp:39-42, gausplat.cu:162-199, kernel.cu:326-423).
+ * rots[N,4] (w,x,y,z), scales[N,3], depths[N] -> cov3ds[N,6], dcov3d_drots[N,6,4], dcov3d_dscales[N,6,3] */
+int egs_cov3d(int n, const float* rots, const float* scales, const float* depths, const EgsPolicy* pol,
+              float* cov3ds, float* dcov3d_drots, float* dcov3d_dscales, void* stream);
+
+/* gsplatcu.computeCov2D  (ext.cpp:44-52, gausplat.cu:201-251, kernel.cu:425-551).
+ * -> cov2ds[N,3], dcov2d_dcov3ds[N,3,6], dcov2d_dpcs[N,3,3] */
+int egs_cov2d(int n, const float* cov3ds, const float* pcs, const float* Rcw, const float* depths,
+              float fx, float fy, float width, float height, const EgsPolicy* pol, float* cov2ds,
+              float* dcov2d_dcov3ds, float* dcov2d_dpcs, void* stream);
+
+/* gsplatcu.sh2Color  (ext.cpp:63-66, gausplat.cu:298-338, kernel.cu:619-807).
+ * shs[N,K] (K in {3,12,27,48}), pws[N,3], twc[3] -> colors[N,3], dcolor_dshs[N,1,K/3], dcolor_dpws[N,3,3] */
+int egs_sh2color(int n, int sh_dim, const float* shs, const float* pws, const float* twc,
+                 float* colors, float* dcolor_dshs, float* dcolor_dpws, void* stream);
+
+/* gsplatcu.inverseCov2D  (ext.cpp:34-36, gausplat.cu:340-373, kernel.cu:274-324).
+ * cov2ds[N,3], depths[N] (IN/OUT: NaN -> -1) -> cinv2ds[N,3], areas[N,2] int32, dcinv2d_dcov2ds[N,3,3] */
+int egs_inv_cov2d(int n, const float* cov2ds, float* depths, const EgsPolicy* pol, float* cinv2ds,
+                  int32_t* areas, float* dcinv2d_dcov2ds, void* stream);
+
+/* ---- splat = binning + sort + draw  (gausplat.cu:24-112) ------------------
+ *
+ * The reference needs P (number of tile-patches) on the host between the prefix
+ * sum and the key expansion (gausplat.cu:67); so does a drop-in that returns
+ * gsid_per_patch[P].  The op is therefore split in two enqueue-only calls with a
+ * single 4-byte read-back between them (done by the caller on its own stream):
+ *
+ *   egs_splat_bin()   getRects (kernel.cu:82-122) + depth-key sort of the N
+ *                     Gaussians + exclusive scan  -> *total_patches (device u32)
+ *   egs_splat_draw()  createKeys (kernel.cu:46-80) in depth order + stable tile
+ *                     sort + getRanges (kernel.cu:125-150) + draw (kernel.cu:152-271)
+ *
+ * Sorting the N Gaussians by depth key first and the P patches by tile id second
+ * (both stable LSD radix) yields exactly the order of the reference's single
+ * sort on (tile<<32 | depth_key): ties in index order.
+ */
+size_t egs_splat_bin_ws_bytes(int n);
+size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height);
+
+/* us[N,2], areas[N,2] (IN/OUT), depths[N] (IN/OUT) ; ws_bin must stay alive until
+ * egs_splat_draw() has been enqueued.  total_patches: device uint32. */
+int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas, float* depths,
+                  const EgsPolicy* pol, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                  void* stream);
+
+/* patches = the value read back from total_patches.  Outputs: image[3,H,W],
+ * contrib[H,W] int32, final_tau[H,W] (zero-filled by the caller),
+ * patch_range_per_tile[T,2] int32 (zeroed here), gsid_per_patch[P] int32. */
+int egs_splat_draw(int n, int64_t patches, int width, int height, const float* us,
+                   const float* cinv2ds, const float* alphas, const float* colors, const int32_t* areas,
+                   const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
+                   float* image, int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
+                   int32_t* gsid_per_patch, void* stream);
+
+/* gsplatcu.splatB  (ext.cpp:20-32, gausplat.cu:114-159, kernel.cu:809-950).
+ * Gradient outputs (zero-filled by the caller): dloss_dus[N,2], dloss_dcinv2ds[N,3],
+ * dloss_dalphas[N], dloss_dcolors[N,3].  ws: egs_splat_bwd_ws_bytes(n). */
+size_t egs_splat_bwd_ws_bytes(int n);
+int egs_splat_bwd(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
+                  const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
+                  const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                  const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                  float* dloss_dus, float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors,
+                  void* stream);
+
+/* ---- building blocks, exported for the parity tests ---------------------- */
+
+/* Stable LSD radix sort of (uint32 key, uint32 value) pairs on key bits
+ * [begin_bit, end_bit).  Replaces thrust::sort_by_key (gausplat.cu:82).
+ * keys/vals are ping-ponged with keys_alt/vals_alt; *result_in_alt_host tells
+ * where the result is (decided on the host from the pass count). */
+size_t egs_sort_pairs_ws_bytes(int64_t n);
+int egs_sort_pairs(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
+                   int begin_bit, int end_bit, void* ws, size_t ws_bytes, int* result_in_alt_host,
+                   void* stream);
+
+/* Exclusive prefix sum of uint32 (replaces thrust::inclusive_scan, gausplat.cu:64);
+ * out[i] = sum_{j<i} in[gather ? gather[j] : j]; *total (device) = sum of all. */
+size_t egs_scan_ws_bytes(int64_t n);
+int egs_exclusive_scan_u32(int64_t n, const uint32_t* in, const uint32_t* gather, uint32_t* out,
+                           uint32_t* total, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fused chain rule --------------------
+ * gsmodel.py:71-85 == backward_cpu.py:476-482 in one pass over the Jacobians. */
+int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss_dcinv2ds,
+                   const float* dloss_dcolors, const float* Rcw, const float* dcinv2d_dcov2ds,
+                   const float* dcov2d_dcov3ds, const float* dcov3d_drots, const float* dcov3d_dscales,
+                   const float* dcolor_dshs, const float* du_dpcs, const float* dcov2d_dpcs,
+                   const float* dcolor_dpws, float* dloss_dpws, float* dloss_dshs, float* dloss_dscales,
+                   float* dloss_drots, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EGS_HIP_H_ */

@@ -42,30 +42,13 @@ import backward_cpu as ref_b  # noqa: E402      (oracle B)
 
 from easygaussiansplatting_amd import scene as S  # noqa: E402
 from oracle import gs_oracle as O  # noqa: E402
+from tests.golden.make_golden_scene import stage_scene  # noqa: E402
 
 
 def save(name, doc, **arrays):
     path = os.path.join(HERE, name)
     np.savez_compressed(path, __doc__=np.array(doc), **arrays)
     print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
-
-
-def stage_scene(n=256, seed=7):
-    """n random Gaussians (SH degree 3) around the frustum of a 640x480 camera:
-    ~15% lie outside the field of view / behind the camera."""
-    u = S.uniform01(seed, 11, (n, 3))
-    pws = np.stack([-6 + 12 * u[:, 0], -4 + 8 * u[:, 1], -1.5 + 9.5 * u[:, 2]], 1)
-    q = S.normal(seed, 12, (n, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
-    s = np.exp(np.log(0.01) + S.uniform01(seed, 13, (n, 3)) * (np.log(0.5) - np.log(0.01)))
-    a = 0.05 + 0.94 * S.uniform01(seed, 14, (n,))
-    sh = 0.3 * S.normal(seed, 15, (n, 48))
-    th = 0.3
-    Rcw = np.array([[np.cos(th), 0, -np.sin(th)], [0, 1, 0], [np.sin(th), 0, np.cos(th)]]) @ \
-        np.array([[1, 0, 0], [0, np.cos(0.1), -np.sin(0.1)], [0, np.sin(0.1), np.cos(0.1)]])
-    tcw = np.array([0.2, -0.1, 1.0])
-    cam = S.Camera(640, 480, 500.0, 480.0, 320.0, 240.0, Rcw, tcw)
-    f = np.float32
-    return S.Scene(pws.astype(f), q.astype(f), s.astype(f), a.astype(f), sh.astype(f), cam)
 
 
 def g1():
