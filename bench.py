@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py -- rendered Mpix/s, forward+backward, 1920x1080, 1 M Gaussians (BASELINE.json).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the rasterizer hot path over one batch of synthetic
+input, exactly as a training step drives it (reference gsplat/gsmodel.py:6-93):
+the six forward ops with calc_J=True, then splatB + the chain rule, producing
+the 59 parameter-gradient floats per Gaussian.  With N > 1 every rank renders
+its own camera view of the same scene (one view per GPU, weak scaling) and the
+step ends with an RCCL all-reduce of the parameter gradients (236 MB at 1 M
+Gaussians); `value` is the whole-job rate: N * W*H / t_step.
+
+Rank 0 prints ONE JSON line carrying, besides the contract fields,
+  roofline     -- the dominant kernel of the timed region (by HIP-event time,
+                  measured on the stream it is launched on), algorithmic bytes per
+                  launch / average launch duration vs the 8 TB/s HBM peak;
+  cpu_baseline -- the reference-equivalent CPU path (oracle/gs_oracle.py policy A
+                  == forward_cpu.py, single thread) timed on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(kernel, N, P, T, HW, K):
+    """Algorithmic HBM bytes of ONE launch of `kernel` (each input read once, each
+    output written once; atomics as read-modify-write)."""
+    nc = K // 3
+    table = {
+        # per-Gaussian stages with Jacobians: inputs + outputs + Jacobians
+        "k_project": N * (12 + 8 + 12 + 4 + 24),
+        "k_cov3d": N * (16 + 12 + 4 + 24 + 96 + 72),
+        "k_cov2d": N * (24 + 12 + 4 + 12 + 72 + 36),
+        "k_sh2color": N * (4 * K + 12 + 12 + 4 * nc + 36),
+        "k_inv_cov2d": N * (12 + 4 + 12 + 8 + 36),
+        "k_bin_count": N * (8 + 8 + 4 + 16 + 4 + 4 + 4),
+        "k_pack_records": N * (36 + 8 + 48),
+        "k_bin_emit": N * (4 + 4 + 16) + P * 8,
+        "k_radix_hist": None, "k_radix_rowscan": None, "k_radix_scatter": None,  # size depends on the pass
+        "k_tile_ranges": P * 4 + T * 8,
+        # draw: gather 40 B per patch (u 8, cinv 12, alpha 4, color 12, gsid 4) + ranges + 20 B per pixel out
+        "k_draw": 40 * P + 8 * T + 20 * HW,
+        # drawB: same gather + 9 fp32 atomics (RMW = 72 B) per patch + 20 B per pixel in
+        "k_draw_bwd": 112 * P + 8 * T + 20 * HW,
+        "k_chain_rule": N * (436 - 24 + 24 + 36 + 4 * (3 + 3 * nc + 3 + 4)),
+    }
+    return table.get(kernel)
+
+
+def parse_report(txt):
+    out = {}
+    for ln in txt.splitlines():
+        parts = ln.split()
+        if len(parts) == 3:
+            out[parts[0]] = (int(parts[1]), float(parts[2]))
+    return out
+
+
+def cpu_baseline(scene, sample_n):
+    """forward_cpu.py-equivalent (oracle policy A: vectorised stages + the
+    per-Gaussian NumPy patch loop of gsplat/gausplat.py:185-245) on the first
+    `sample_n` Gaussians of the iid scene, full resolution; cost is linear in N."""
+    from oracle import gs_oracle as O
+    sub = scene.subsample(slice(0, sample_n))
+    cam = sub.cam
+    t0 = time.perf_counter()
+    P = O.POLICY_A
+    us, pcs, depths = O.project(sub.pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P)
+    cov3ds = O.compute_cov3d(sub.rots, sub.scales, depths, P)
+    cov2ds = O.compute_cov2d(cov3ds, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, P)
+    colors = O.sh2color(sub.shs, sub.pws, cam.twc)
+    cinv2ds, areas = O.inverse_cov2d(cov2ds, depths, P)
+    O.splat_forward_cpu(cam.height, cam.width, us, cinv2ds, sub.alphas.astype(np.float64), depths, colors, areas)
+    dt = time.perf_counter() - t0
+    full = dt * scene.n / sample_n
+    return {"value": round(cam.width * cam.height / full / 1e6, 5), "unit": "Mpix/s (forward only)",
+            "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
+            "sample": "first %d of %d iid Gaussians at %dx%d, %.1f s measured, x%.0f linear extrapolation; "
+                      "single-threaded NumPy patch loop == reference forward_cpu.py"
+                      % (sample_n, scene.n, cam.width, cam.height, dt, scene.n / sample_n)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gaussians", type=int, default=1_000_000)
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--sh-dim", type=int, default=48)
+    ap.add_argument("--cpu-sample", type=int, default=250_000, help="Gaussians in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from easygaussiansplatting_amd import _lib, scene as S
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    from easygaussiansplatting_amd.function import Camera, GSFunction, render
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus != world:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
+                             % (a.gpus, a.gpus))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+
+    lib = _lib.load()
+    gsc.set_policy("gsplatcu")
+    sc = S.big_scene(a.gaussians, a.width, a.height, a.sh_dim)
+    cams = S.ring_cameras(sc.cam, max(8, world))
+    cam = Camera.from_scene(cams[rank % len(cams)], dev)   # one view per GPU; view 0 = the BASELINE camera
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    params = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1), scales=t(sc.scales),
+                  rots=t(sc.rots))
+    for p in params.values():
+        p.requires_grad_(True)
+    us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)   # gsmodel.py:198-199
+    HW = a.width * a.height
+    dl = torch.from_numpy(S.normal(1, 77, (3, a.height, a.width)).astype(np.float32)).to(dev) / (3 * HW)
+    order = ("pws", "shs", "alphas", "scales", "rots")
+
+    def step():
+        for p in params.values():
+            p.grad = None
+        us0.grad = None
+        image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
+                                       params["rots"], us0, cam)
+        image.backward(dl)
+        if world > 1:  # gradient exchange: 59 floats per Gaussian, SUM then mean
+            hs = [dist.all_reduce(params[k].grad, op=dist.ReduceOp.SUM, async_op=True) for k in order]
+            for h in hs:
+                h.wait()
+            for k in order:
+                params[k].grad.div_(world)
+        return image
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    sync()
+    prof = not a.no_prof
+    if prof:
+        lib.egs_prof_reset()
+        lib.egs_prof_enable(1)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        image = step()
+    sync()
+    dt = time.perf_counter() - t0
+    if prof:
+        lib.egs_prof_enable(0)
+    dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
+    dt = float(dt_t.item())
+    ms = dt / a.steps * 1e3
+
+    # realised scene statistics (bytes depend on them)
+    with torch.no_grad():
+        out = render(params["pws"].detach(), params["shs"].detach(), params["alphas"].detach(),
+                     params["scales"].detach(), params["rots"].detach(), cam)
+        ranges, gsid = out[3], out[4]
+        lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64)
+        P = int(gsid.shape[0]); T = int(ranges.shape[0])
+        max_len = int(lens.max().item())
+        pairs = int(lens.sum().item()) * 256
+        # forward-only rate (BASELINE configs[1]), untimed by the headline
+        torch.cuda.synchronize()
+        tf0 = time.perf_counter()
+        nf = max(3, a.steps // 2)
+        for _ in range(nf):
+            render(params["pws"].detach(), params["shs"].detach(), params["alphas"].detach(),
+                   params["scales"].detach(), params["rots"].detach(), cam)
+        torch.cuda.synchronize()
+        fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
+
+    roofline = None
+    kernels = {}
+    if prof:
+        need = lib.egs_prof_report(None, 0)
+        import ctypes
+        buf = ctypes.create_string_buffer(need + 16)
+        lib.egs_prof_report(buf, need + 16)
+        rep = parse_report(buf.value.decode())
+        kernels = {k: {"launches": c, "avg_us": round(tot / c * 1e3, 2), "ms_per_step": round(tot / a.steps, 4)}
+                   for k, (c, tot) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+        dom = max(rep.items(), key=lambda kv: kv[1][1])[0]
+        cnt, tot = rep[dom]
+        avg_s = tot / cnt * 1e-3
+        ab = algorithmic_bytes(dom, sc.n, P, T, HW, a.sh_dim)
+        if ab is not None:
+            ach = ab / avg_s / 1e9
+            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+                        "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 1),
+                        "launches": cnt, "share_of_step": round(tot / a.steps / ms, 3)}
+            tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
+            if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/)
+                try:
+                    tj = json.load(open(tpath))
+                    if tj.get("gaussians") == sc.n and tj.get("width") == a.width and dom in tj.get("kernels", {}):
+                        roofline["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                except Exception:
+                    pass
+
+    cpu = None
+    if rank == 0 and world == 1 and a.cpu_sample > 0:
+        cpu = cpu_baseline(sc, min(a.cpu_sample, sc.n))
+
+    if rank == 0:
+        value = world * HW / (ms * 1e-3) / 1e6
+        line = {
+            "metric": "rendered Mpix/s fwd+bwd at 1920x1080, 1M Gaussians", "value": round(value, 2),
+            "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "1 MI355X per view: %d synthetic Gaussians, %dx%d, SH degree %d, "
+                                   "forward+backward (6 ops calc_J=True + splatB + chain rule)%s"
+                                   % (sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim],
+                                      ", RCCL all-reduce of 59 fp32 grads/Gaussian" if world > 1 else ""),
+                       "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
+                       "views_per_step": world, "policy": "gsplatcu",
+                       "patches": P, "tiles": T, "max_list_len": max_len, "pixel_gaussian_pairs": pairs},
+            "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+        }
+        if cpu:
+            line["fwd_speedup_vs_cpu"] = round(line["fwd_only"]["Mpix/s"] / cpu["value"], 1)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

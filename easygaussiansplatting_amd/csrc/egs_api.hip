@@ -4,6 +4,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
 namespace egs {
 static thread_local char g_err[512] = "no error";
 
@@ -11,7 +16,83 @@ void set_error(int code, const char* what, const char* file, int line) {
   const char* base = strrchr(file, '/');
   snprintf(g_err, sizeof(g_err), "egs error %d: %s (%s:%d)", code, what ? what : "?", base ? base + 1 : file, line);
 }
+
+// ---- per-kernel timing ------------------------------------------------------
+struct ProfRec {
+  const char* name;
+  hipEvent_t a, b;
+};
+static std::mutex g_prof_mu;
+static bool g_prof_enabled = false;
+static std::vector<ProfRec> g_prof_recs;
+static std::vector<hipEvent_t> g_prof_pool;
+
+static hipEvent_t prof_event() {
+  if (!g_prof_pool.empty()) {
+    hipEvent_t e = g_prof_pool.back();
+    g_prof_pool.pop_back();
+    return e;
+  }
+  hipEvent_t e = nullptr;
+  (void)hipEventCreate(&e);
+  return e;
+}
+
+bool prof_on() { return g_prof_enabled; }
+
+void prof_begin(const char* name, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  ProfRec r{name, prof_event(), prof_event()};
+  (void)hipEventRecord(r.a, s);
+  g_prof_recs.push_back(r);
+}
+
+void prof_end(hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_prof_mu);
+  if (!g_prof_recs.empty()) (void)hipEventRecord(g_prof_recs.back().b, s);
+}
 }  // namespace egs
+
+extern "C" int egs_prof_enable(int on) {
+  std::lock_guard<std::mutex> lk(egs::g_prof_mu);
+  const int prev = egs::g_prof_enabled;
+  egs::g_prof_enabled = on != 0;
+  return prev;
+}
+
+extern "C" void egs_prof_reset(void) {
+  std::lock_guard<std::mutex> lk(egs::g_prof_mu);
+  for (auto& r : egs::g_prof_recs) {
+    egs::g_prof_pool.push_back(r.a);
+    egs::g_prof_pool.push_back(r.b);
+  }
+  egs::g_prof_recs.clear();
+}
+
+extern "C" int egs_prof_report(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(egs::g_prof_mu);
+  std::map<std::string, std::pair<int, double>> agg;
+  for (auto& r : egs::g_prof_recs) {
+    float ms = 0.f;
+    if (hipEventSynchronize(r.b) == hipSuccess && hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+      auto& e = agg[r.name];
+      e.first += 1;
+      e.second += ms;
+    }
+  }
+  std::string out;
+  char line[256];
+  for (auto& kv : agg) {
+    snprintf(line, sizeof(line), "%s %d %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+    out += line;
+  }
+  if (buf && cap > 0) {
+    const size_t nb = out.size() < cap - 1 ? out.size() : cap - 1;
+    memcpy(buf, out.data(), nb);
+    buf[nb] = 0;
+  }
+  return (int)out.size();
+}
 
 extern "C" const char* egs_last_error_string(void) { return egs::g_err; }
 extern "C" int egs_abi_version(void) { return EGS_ABI_VERSION; }

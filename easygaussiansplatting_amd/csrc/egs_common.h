@@ -37,6 +37,27 @@ void set_error(int code, const char* what, const char* file, int line);
 // after a <<<>>> launch: catches launch-configuration errors without syncing
 #define EGS_LAUNCH_OK() EGS_HIP(hipGetLastError())
 
+// ---- optional per-kernel timing (egs_prof_* in the C ABI) -------------------
+bool prof_on();
+void prof_begin(const char* name, hipStream_t s);
+void prof_end(hipStream_t s);
+struct ProfScope {
+  hipStream_t s;
+  bool on;
+  ProfScope(const char* name, hipStream_t st) : s(st), on(prof_on()) {
+    if (on) prof_begin(name, s);
+  }
+  ~ProfScope() {
+    if (on) prof_end(s);
+  }
+};
+// launch `kern` on `stream`, bracketed by events when profiling is enabled
+#define EGS_LAUNCH(name, kern, grid, block, stream, ...)                 \
+  do {                                                                   \
+    ::egs::ProfScope ps__(name, stream);                                 \
+    hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);       \
+  } while (0)
+
 static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 

@@ -429,7 +429,7 @@ extern "C" int egs_project(int n, const float* pws, const float* Rcw, const floa
   EGS_CHECK_ARG(n >= 0 && pol);
   if (n == 0) return 0;
   EGS_CHECK_ARG(pws && Rcw && tcw && us && pcs && depths);
-  hipLaunchKernelGGL(k_project, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, pws, Rcw, tcw, fx,
+  EGS_LAUNCH("k_project", k_project, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, pws, Rcw, tcw, fx,
                      fy, cx, cy, pol->near_cull, us, pcs, depths, du_dpcs);
   EGS_LAUNCH_OK();
   return 0;
@@ -443,7 +443,7 @@ extern "C" int egs_cov3d(int n, const float* rots, const float* scales, const fl
   EGS_CHECK_ARG(rots && scales && depths && cov3ds);
   EGS_CHECK_ARG((dcov3d_drots == nullptr) == (dcov3d_dscales == nullptr));
   EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0);
-  hipLaunchKernelGGL(k_cov3d, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, rots, scales, depths,
+  EGS_LAUNCH("k_cov3d", k_cov3d, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, rots, scales, depths,
                      pol->near_cull, cov3ds, dcov3d_drots, dcov3d_dscales);
   EGS_LAUNCH_OK();
   return 0;
@@ -464,7 +464,7 @@ extern "C" int egs_cov2d(int n, const float* cov3ds, const float* pcs, const flo
     limx = (float)(1.3 * (2 * atan((double)width / (2 * (double)fx))));
     limy = (float)(1.3 * (2 * atan((double)height / (2 * (double)fy))));
   }
-  hipLaunchKernelGGL(k_cov2d, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, cov3ds, pcs, Rcw,
+  EGS_LAUNCH("k_cov2d", k_cov2d, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, cov3ds, pcs, Rcw,
                      depths, fx, fy, limx, limy, pol->fov_mode != 2, pol->near_cull, cov2ds, dcov2d_dcov3ds,
                      dcov2d_dpcs);
   EGS_LAUNCH_OK();
@@ -482,10 +482,10 @@ extern "C" int egs_sh2color(int n, int sh_dim, const float* shs, const float* pw
   dim3 g(div_up(n, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
   switch (sh_dim) {
-    case 3: hipLaunchKernelGGL(k_sh2color<1>, g, b, 0, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
-    case 12: hipLaunchKernelGGL(k_sh2color<4>, g, b, 0, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
-    case 27: hipLaunchKernelGGL(k_sh2color<9>, g, b, 0, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
-    default: hipLaunchKernelGGL(k_sh2color<16>, g, b, 0, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
+    case 3: EGS_LAUNCH("k_sh2color", (k_sh2color<1>), g, b, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
+    case 12: EGS_LAUNCH("k_sh2color", (k_sh2color<4>), g, b, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
+    case 27: EGS_LAUNCH("k_sh2color", (k_sh2color<9>), g, b, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
+    default: EGS_LAUNCH("k_sh2color", (k_sh2color<16>), g, b, s, n, shs, pws, twc, colors, dcolor_dshs, dcolor_dpws); break;
   }
   EGS_LAUNCH_OK();
   return 0;
@@ -496,7 +496,7 @@ extern "C" int egs_inv_cov2d(int n, const float* cov2ds, float* depths, const Eg
   EGS_CHECK_ARG(n >= 0 && pol);
   if (n == 0) return 0;
   EGS_CHECK_ARG(cov2ds && depths && cinv2ds && areas);
-  hipLaunchKernelGGL(k_inv_cov2d, dim3(div_up(n, 256)), dim3(256), 0, (hipStream_t)stream, n, cov2ds, depths,
+  EGS_LAUNCH("k_inv_cov2d", k_inv_cov2d, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, cov2ds, depths,
                      pol->det_eps, pol->near_cull, pol->nan_cull, pol->radius_mode, cinv2ds, areas,
                      dcinv2d_dcov2ds);
   EGS_LAUNCH_OK();
@@ -518,7 +518,7 @@ extern "C" int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const f
   dim3 g(div_up(n, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
 #define EGS_CHAIN(NC)                                                                                        \
-  hipLaunchKernelGGL(k_chain_rule<NC>, g, b, 0, s, n, dloss_dus, dloss_dcinv2ds, dloss_dcolors, Rcw,          \
+  EGS_LAUNCH("k_chain_rule", (k_chain_rule<NC>), g, b, s, n, dloss_dus, dloss_dcinv2ds, dloss_dcolors, Rcw,          \
                      dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs,     \
                      dcov2d_dpcs, dcolor_dpws, dloss_dpws, dloss_dshs, dloss_dscales, dloss_drots)
   switch (sh_dim) {

@@ -29,7 +29,7 @@ constexpr int RS_TILE = RS_THREADS * RS_IPT;       // 4096 items per workgroup
 constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // 1024 contiguous items per wave
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
-                                                           int shift, int nblocks,
+                                                           int shift, uint32_t dmask, int nblocks,
                                                            uint32_t* __restrict__ hist) {
   __shared__ uint32_t h[256];
   const int tid = threadIdx.x;
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
 #pragma unroll
   for (int r = 0; r < RS_IPT; ++r) {
     const int64_t idx = base + r * RS_THREADS + tid;
-    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & 0xFFu], 1u);
+    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & dmask], 1u);
   }
   __syncthreads();
   hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];  // digit-major: row = digit
@@ -65,8 +65,8 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
 
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
-    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, int nblocks,
-    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+    uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
+    int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
   __shared__ uint32_t wcount[4][256];  // per-wave running digit counters -> per-wave offsets
   __shared__ uint32_t gbase[256];
   __shared__ uint32_t sm[4];
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const int64_t idx = base + r * EGS_WAVE + lane;
     const bool valid = idx < n;
     const uint32_t k = valid ? keys_in[idx] : 0u;
-    const uint32_t d = (k >> shift) & 0xFFu;
+    const uint32_t d = (k >> shift) & dmask;
     // peers = lanes of this wave holding the same digit (multi-split by ballots)
     uint64_t peers = __ballot(valid);
 #pragma unroll
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
   for (int r = 0; r < RS_IPT; ++r) {
     const int64_t idx = base + r * EGS_WAVE + lane;
     if (idx < n) {
-      const uint32_t d = (key[r] >> shift) & 0xFFu;
+      const uint32_t d = (key[r] >> shift) & dmask;
       const uint32_t pos = gbase[d] + wcount[wave][d] + rank[r];
       keys_out[pos] = key[r];
       vals_out[pos] = vals_in[idx];
@@ -149,9 +149,12 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    hipLaunchKernelGGL(k_radix_hist, dim3(w.nblocks), dim3(RS_THREADS), 0, s, ki, n, shift, w.nblocks, w.hist);
-    hipLaunchKernelGGL(k_radix_rowscan, dim3(256), dim3(256), 0, s, w.hist, w.nblocks, w.totals);
-    hipLaunchKernelGGL(k_radix_scatter, dim3(w.nblocks), dim3(RS_THREADS), 0, s, ki, vi, ko, vo, n, shift,
+    const int nb = end_bit - shift < 8 ? end_bit - shift : 8;  // the last digit may be narrower
+    const uint32_t dmask = (1u << nb) - 1u;
+    EGS_LAUNCH("k_radix_hist", k_radix_hist, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask, w.nblocks,
+                       w.hist);
+    EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals);
+    EGS_LAUNCH("k_radix_scatter", k_radix_scatter, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift, dmask,
                        w.nblocks, w.hist, w.totals);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
@@ -230,9 +233,9 @@ static int exclusive_scan(int64_t n, const uint32_t* in, const uint32_t* gather,
     return 0;
   }
   const int nb = div_up(n, SC_TILE);
-  hipLaunchKernelGGL(k_scan_partials, dim3(nb), dim3(256), 0, s, in, gather, n, partials);
-  hipLaunchKernelGGL(k_scan_spine, dim3(1), dim3(256), 0, s, partials, nb, total);
-  hipLaunchKernelGGL(k_scan_apply, dim3(nb), dim3(256), 0, s, in, gather, n, partials, out);
+  EGS_LAUNCH("k_scan_partials", k_scan_partials, dim3(nb), dim3(256), s, in, gather, n, partials);
+  EGS_LAUNCH("k_scan_spine", k_scan_spine, dim3(1), dim3(256), s, partials, nb, total);
+  EGS_LAUNCH("k_scan_apply", k_scan_apply, dim3(nb), dim3(256), s, in, gather, n, partials, out);
   EGS_LAUNCH_OK();
   return 0;
 }
@@ -730,7 +733,7 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
   p.gx = div_up(width, EGS_TILE); p.gy = div_up(height, EGS_TILE);
   p.footprint = pol->footprint; p.far_cull = pol->far_cull; p.depth_key = pol->depth_key;
   p.mutate = (pol->footprint == 0);
-  hipLaunchKernelGGL(k_bin_count, dim3(div_up(n, 256)), dim3(256), 0, s, n, p, us, areas, depths, L.rects,
+  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rects,
                      L.counts, L.dkeys, L.ids);
   EGS_LAUNCH_OK();
   // 4 passes (even): the sorted (dkeys, ids) end up in the primary buffers
@@ -766,20 +769,20 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   uint32_t* k1 = (passes & 1) ? D.tkeys : D.tkeys_alt;
   uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
-  hipLaunchKernelGGL(k_bin_emit, dim3(div_up(n, 256)), dim3(256), 0, s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
+  EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
                      v0);
-  hipLaunchKernelGGL(k_pack_records, dim3(div_up(n, 256)), dim3(256), 0, s, n, width, height, pol->footprint, us,
+  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint, us,
                      cinv2ds, alphas, colors, areas, D.rec);
   EGS_LAUNCH_OK();
   int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), 0, s, patches, D.tkeys,
+  EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile);
   if (pol->footprint == 1)
-    hipLaunchKernelGGL(k_draw<true>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
+    EGS_LAUNCH("k_draw", (k_draw<true>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
                        image, contrib, final_tau);
   else
-    hipLaunchKernelGGL(k_draw<false>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
+    EGS_LAUNCH("k_draw", (k_draw<false>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
                        image, contrib, final_tau);
   EGS_LAUNCH_OK();
   return 0;
@@ -807,13 +810,13 @@ extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, cons
   hipStream_t s = (hipStream_t)stream;
   float4* rec = (float4*)ws;
   const DrawParams dp = make_draw_params(width, height, pol);
-  hipLaunchKernelGGL(k_pack_records, dim3(div_up(n, 256)), dim3(256), 0, s, n, width, height, pol->footprint, us,
+  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint, us,
                      cinv2ds, alphas, colors, areas, rec);
   if (pol->footprint == 1)
-    hipLaunchKernelGGL(k_draw_bwd<true>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, rec,
+    EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<true>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, rec,
                        final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
   else
-    hipLaunchKernelGGL(k_draw_bwd<false>, dim3(dp.T), dim3(64), 0, s, dp, patch_range_per_tile, gsid_per_patch, rec,
+    EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<false>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, rec,
                        final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
   EGS_LAUNCH_OK();
   return 0;

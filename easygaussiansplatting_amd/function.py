@@ -1,0 +1,91 @@
+"""Autograd boundary: the counterpart of the reference's ``GSFunction``
+(gsplat/gsmodel.py:6-93) on top of the MI355X op surface.
+
+Identical inputs ``(pws, shs, alphas[N,1], scales, rots, us, cam)``, outputs
+``(image[3,H,W], depths > 0.2)`` and gradient tuple order (gsmodel.py:87-93).
+The forward is the same six op calls with ``calc_J=True``; the backward is
+``splatB`` followed by the chain rule -- by default the fused HIP kernel
+(``gsplatcu.chain_rule``), or, with ``GSFunction.use_fused_chain = False``, the
+nine batched matmuls exactly as the reference spells them.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import gsplatcu as gsc
+
+
+class Camera:
+    """Device-side camera, field names of reference gausplat_dataset.py:14-26."""
+
+    def __init__(self, width, height, fx, fy, cx, cy, Rcw, tcw, device="cuda", id=0, path=""):
+        self.id = id
+        self.width = int(width)
+        self.height = int(height)
+        self.fx, self.fy, self.cx, self.cy = float(fx), float(fy), float(cx), float(cy)
+        self.Rcw = torch.as_tensor(Rcw, dtype=torch.float32).to(device).contiguous()
+        self.tcw = torch.as_tensor(tcw, dtype=torch.float32).to(device).contiguous()
+        self.twc = (-torch.linalg.inv(self.Rcw.double().cpu()) @ self.tcw.double().cpu()).float().to(device)
+        self.path = path
+
+    @staticmethod
+    def from_scene(cam, device="cuda"):
+        return Camera(cam.width, cam.height, cam.fx, cam.fy, cam.cx, cam.cy, cam.Rcw, cam.tcw, device)
+
+
+class GSFunction(torch.autograd.Function):
+    use_fused_chain = True
+
+    @staticmethod
+    def forward(ctx, pws, shs, alphas, scales, rots, us, cam):
+        # forward.md steps 1-5 == gsmodel.py:21-39
+        us, pcs, depths, du_dpcs = gsc.project(pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, True)
+        cov3ds, dcov3d_drots, dcov3d_dscales = gsc.computeCov3D(rots, scales, depths, True)
+        cov2ds, dcov2d_dcov3ds, dcov2d_dpcs = gsc.computeCov2D(
+            cov3ds, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, True)
+        colors, dcolor_dshs, dcolor_dpws = gsc.sh2Color(shs, pws, cam.twc, True)
+        cinv2ds, areas, dcinv2d_dcov2ds = gsc.inverseCov2D(cov2ds, depths, True)
+        image, contrib, final_tau, patch_range_per_tile, gsid_per_patch = gsc.splat(
+            cam.height, cam.width, us, cinv2ds, alphas, depths, colors, areas)
+        ctx.cam = cam
+        ctx.save_for_backward(us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
+                              gsid_per_patch, dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales,
+                              dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws)
+        mask = depths > 0.2  # read after the in-place culling of inverseCov2D / splat (gsmodel.py:50)
+        ctx.mark_non_differentiable(mask)
+        return image, mask
+
+    @staticmethod
+    def backward(ctx, dloss_dgammas, _):
+        cam = ctx.cam
+        (us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
+         dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs,
+         dcolor_dpws) = ctx.saved_tensors
+        dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors = gsc.splatB(
+            cam.height, cam.width, us, cinv2ds, alphas, depths, colors, contrib, final_tau,
+            patch_range_per_tile, gsid_per_patch, dloss_dgammas.contiguous())
+        n = us.shape[0]
+        if GSFunction.use_fused_chain:
+            dloss_dpws, dloss_dshs, dloss_dscales, dloss_drots = gsc.chain_rule(
+                dloss_dus, dloss_dcinv2ds, dloss_dcolors, cam.Rcw, dcinv2d_dcov2ds, dcov2d_dcov3ds,
+                dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws)
+        else:  # gsmodel.py:71-85 verbatim structure
+            dpc_dpws = cam.Rcw
+            dloss_dcov2ds = dloss_dcinv2ds @ dcinv2d_dcov2ds
+            dloss_drots = (dloss_dcov2ds @ dcov2d_dcov3ds @ dcov3d_drots).reshape(n, 4)
+            dloss_dscales = (dloss_dcov2ds @ dcov2d_dcov3ds @ dcov3d_dscales).reshape(n, 3)
+            dloss_dshs = (dloss_dcolors.permute(0, 2, 1) @ dcolor_dshs).permute(0, 2, 1).reshape(n, -1)
+            dloss_dpws = (dloss_dus @ du_dpcs @ dpc_dpws + dloss_dcolors @ dcolor_dpws +
+                          dloss_dcov2ds @ dcov2d_dpcs @ dpc_dpws).reshape(n, 3)
+        return (dloss_dpws, dloss_dshs, dloss_dalphas.reshape(n, 1), dloss_dscales, dloss_drots,
+                dloss_dus.reshape(n, 2), None)
+
+
+def render(pws, shs, alphas, scales, rots, cam, calc_J=False):
+    """Inference path of the reference's forward_gpu.py:47-60 (six op calls)."""
+    us, pcs, depths = gsc.project(pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, False)
+    cov3ds = gsc.computeCov3D(rots, scales, depths, False)[0]
+    cov2ds = gsc.computeCov2D(cov3ds, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, False)[0]
+    colors = gsc.sh2Color(shs, pws, cam.twc, False)[0]
+    cinv2ds, areas = gsc.inverseCov2D(cov2ds, depths, False)
+    return gsc.splat(cam.height, cam.width, us, cinv2ds, alphas, depths, colors, areas)

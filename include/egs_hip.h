@@ -163,6 +163,16 @@ int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss
                    const float* dcolor_dpws, float* dloss_dpws, float* dloss_dshs, float* dloss_dscales,
                    float* dloss_drots, void* stream);
 
+/* ---- per-kernel timing with HIP events on the launch stream ---------------
+ * bench.py's `roofline` leg: when enabled, every kernel launch of this library
+ * is bracketed by hipEventRecord on the stream it is launched on.
+ * egs_prof_report() synchronises the recorded events and writes one line per
+ * kernel name: "<name> <launches> <total_ms>\n"; returns the number of bytes
+ * needed (excluding the NUL).  Recording costs ~2 us per launch. */
+int egs_prof_enable(int on);
+void egs_prof_reset(void);
+int egs_prof_report(char* buf, size_t cap);
+
 #ifdef __cplusplus
 }
 #endif
