@@ -1,0 +1,127 @@
+"""CPU-only checks of the drop-in boundary: the C-ABI library loads and exports
+every symbol include/egs_hip.h declares, the ctypes mirror matches the C structs,
+and the host-side validation of the Python op surface.  No GPU compute calls."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from tests.conftest import REPO
+
+HEADER = os.path.join(REPO, "include", "egs_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from easygaussiansplatting_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    return _lib.load()
+
+
+def declared_functions():
+    src = open(HEADER).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(egs_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_header_declares_the_seven_ops_and_cites_the_reference():
+    names = declared_functions()
+    for op in ("egs_project", "egs_cov3d", "egs_cov2d", "egs_sh2color", "egs_inv_cov2d", "egs_splat_bin",
+               "egs_splat_draw", "egs_splat_bwd"):
+        assert op in names
+    txt = open(HEADER).read()
+    for cite in ("ext.cpp:54-61", "ext.cpp:39-42", "ext.cpp:44-52", "ext.cpp:63-66", "ext.cpp:34-36",
+                 "ext.cpp:20-32", "gausplat.cu:24-112"):
+        assert cite in txt, cite
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from easygaussiansplatting_amd import _lib
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    for name in declared_functions():
+        assert name in exported, name
+        assert name in _lib.SIGNATURES, "ctypes signature missing for " + name
+    assert lib.egs_abi_version() == _lib.ABI_VERSION
+
+
+def test_no_torch_or_python_dependency_in_the_shared_library():
+    from easygaussiansplatting_amd import _lib
+    out = subprocess.run(["readelf", "-d", _lib.LIB_PATH], capture_output=True, text=True).stdout
+    needed = re.findall(r"NEEDED.*\[(.*?)\]", out)
+    assert any("amdhip64" in n for n in needed)
+    assert not any(("torch" in n) or ("python" in n) or ("c10" in n) for n in needed), needed
+
+
+def test_policy_struct_layout_and_presets(lib):
+    from easygaussiansplatting_amd._lib import EgsPolicy
+    assert C.sizeof(EgsPolicy) == 48
+    g = EgsPolicy(); lib.egs_policy_gsplatcu(C.byref(g))
+    assert (g.near_cull, g.fov_mode, g.nan_cull, g.radius_mode, g.footprint, g.maha_floor, g.alpha_clamp,
+            g.depth_key) == (1, 0, 1, 0, 0, 1, 1, 0)
+    assert abs(g.alpha_skip - 0.002) < 1e-9 and abs(g.tau_stop - 1e-4) < 1e-10 and g.det_eps == 0
+    a = EgsPolicy(); lib.egs_policy_forward_cpu(C.byref(a))
+    assert (a.near_cull, a.fov_mode, a.nan_cull, a.radius_mode, a.footprint, a.far_cull, a.maha_floor,
+            a.alpha_clamp, a.depth_key) == (0, 1, 0, 1, 1, 1, 0, 1, 1)
+    assert abs(a.det_eps - 1e-6) < 1e-12 and a.alpha_skip == 0 and a.tau_stop == 0
+    # the oracle's policies are the same two rows of SURVEY §8a-R0
+    from oracle import gs_oracle as O
+    for p, o in ((g, O.POLICY_G), (a, O.POLICY_A)):
+        assert (bool(p.near_cull), p.fov_mode, bool(p.nan_cull), p.radius_mode, p.footprint, bool(p.maha_floor),
+                bool(p.alpha_clamp)) == (o.near_cull, o.fov_mode, o.nan_cull, o.radius_mode, o.footprint,
+                                         o.maha_floor, o.alpha_clamp)
+        assert abs(p.alpha_skip - o.alpha_skip) < 1e-9 and abs(p.tau_stop - o.tau_stop) < 1e-9
+        assert p.depth_key == o.depth_key
+
+
+def test_argument_errors_are_reported_not_crashed(lib):
+    from easygaussiansplatting_amd._lib import EgsPolicy
+    p = EgsPolicy(); lib.egs_policy_gsplatcu(C.byref(p))
+    rc = lib.egs_sh2color(4, 5, None, None, None, None, None, None, None)      # bad sh_dim
+    assert rc == 10001 and b"bad argument" in lib.egs_last_error_string()
+    rc = lib.egs_project(-1, None, None, None, 1., 1., 0., 0., C.byref(p), None, None, None, None, None)
+    assert rc == 10001
+    assert lib.egs_project(0, None, None, None, 1., 1., 0., 0., C.byref(p), None, None, None, None, None) == 0
+    # workspace sizes are monotone and cover the documented layout
+    assert lib.egs_splat_bin_ws_bytes(1_000_000) >= 1_000_000 * (16 + 6 * 4)
+    assert lib.egs_splat_draw_ws_bytes(1_000_000, 4_100_000, 1920, 1080) >= 3 * 4 * 4_100_000 + 48 * 1_000_000
+    assert lib.egs_splat_bin_ws_bytes(10) <= lib.egs_splat_bin_ws_bytes(1000)
+
+
+def test_op_surface_validates_before_touching_the_gpu():
+    torch = pytest.importorskip("torch")
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    with pytest.raises(ValueError):      # CPU tensor
+        gsc.project(torch.zeros(4, 3), torch.eye(3), torch.zeros(3), 1., 1., 0., 0., False)
+    with pytest.raises(TypeError):
+        gsc.project(np.zeros((4, 3), np.float32), torch.eye(3), torch.zeros(3), 1., 1., 0., 0., False)
+    with pytest.raises(ValueError):
+        gsc.splat(0, 16, torch.zeros(1, 2), torch.zeros(1, 3), torch.zeros(1), torch.zeros(1), torch.zeros(1, 3),
+                  torch.zeros(1, 2, dtype=torch.int32))
+    assert gsc.get_policy() in ("gsplatcu", "forward_cpu")
+    import gsplatcu as top                 # the literal drop-in module name
+    for f in ("project", "computeCov3D", "computeCov2D", "sh2Color", "inverseCov2D", "splat", "splatB"):
+        assert callable(getattr(top, f))
+
+
+def test_product_path_never_imports_the_oracle():
+    pkg = os.path.join(REPO, "easygaussiansplatting_amd")
+    for root, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                code = "\n".join(ln for ln in src.splitlines() if re.match(r"\s*(from|import)\s", ln))
+                assert "oracle" not in code, f
+    assert "oracle" not in open(os.path.join(REPO, "gsplatcu", "__init__.py")).read()
+
+
+def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
+    from easygaussiansplatting_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(_lib.EgsLibraryError):
+        _lib.load()
