@@ -18,6 +18,8 @@
 //     atomics per (tile, Gaussian): 256x fewer atomics.
 #include "egs_common.h"
 
+#include <stdlib.h>
+
 namespace egs {
 
 // ============================================================================
@@ -351,9 +353,16 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 
 // 48-byte packed 2D record per Gaussian: one aligned gather (3 x dwordx4)
 // instead of the reference's four (fetch2shared, kernel.cu:13-44).
-//   A = {u.x, u.y, cinv.x, cinv.y}  B = {cinv.z, alpha, col.r, col.g}  C = {col.b, box_x, box_y, 0}
-// box_x = x0 | x1<<16, box_y = y0 | y1<<16 (policy forward_cpu only)
-__global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int footprint,
+//   A = {u.x, u.y, cinv.x, cinv.y}  B = {cinv.z, alpha, col.r, col.g}  C = {col.b, c1, c2, 0}
+// tile footprint (gsplatcu):   c1 = ex, c2 = ey -- half extents of the axis-aligned box
+//   around u outside of which alpha' < alpha_skip is CERTAIN:  alpha' >= skip  =>
+//   maha <= m* = 2 ln(alpha/skip) and maha >= dx^2 / Sigma_xx, so |dx| <= sqrt(m* Sigma_xx).
+//   The draw kernels skip whole 8x8 pixel blocks that this box cannot reach; the pixels
+//   skipped are exactly pixels the reference would `continue` on (kernel.cu:246), so the
+//   result is unchanged.  Slack (x1.01 + 0.05 px) covers float rounding; a non positive-
+//   definite cinv or skip == 0 disables the cull (extent = +inf).
+// pixel-box footprint (forward_cpu): c1 = x0 | x1<<16, c2 = y0 | y1<<16 (gausplat.py:212-215)
+__global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int footprint, float alpha_skip,
                                                       const float* __restrict__ us,
                                                       const float* __restrict__ cinv,
                                                       const float* __restrict__ alphas,
@@ -365,59 +374,103 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
   const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
   const float c0 = cinv[3 * (size_t)i], c1 = cinv[3 * (size_t)i + 1], c2 = cinv[3 * (size_t)i + 2];
   const float r = colors[3 * (size_t)i], g = colors[3 * (size_t)i + 1], b = colors[3 * (size_t)i + 2];
-  uint32_t bx = 0, by = 0;
+  const float alpha = alphas[i];
+  float e1, e2;
   if (footprint == 1) {
     int x0, x1, y0, y1;
     pixel_box(ux, uy, (float)areas[2 * (size_t)i], (float)areas[2 * (size_t)i + 1], W, H, x0, x1, y0, y1);
-    bx = (uint32_t)x0 | ((uint32_t)x1 << 16);
-    by = (uint32_t)y0 | ((uint32_t)y1 << 16);
+    e1 = __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16));
+    e2 = __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16));
+  } else {
+    const float inf = __int_as_float(0x7f800000);
+    e1 = inf; e2 = inf;
+    const float det = c0 * c2 - c1 * c1;
+    // (det must not be the result of catastrophic cancellation: eigenvalue ratio < 1e4)
+    if (alpha_skip > 0.f && det > 1e-4f * c0 * c2 && c0 > 0.f && c2 > 0.f) {
+      if (alpha > alpha_skip) {
+        const float mstar = 2.f * logf(alpha / alpha_skip);
+        const float sxx = c2 / det, syy = c0 / det;  // Sigma = cinv^-1
+        e1 = sqrtf(mstar * sxx) * 1.01f + 0.05f;
+        e2 = sqrtf(mstar * syy) * 1.01f + 0.05f;
+      } else if (alpha <= alpha_skip * 0.999f) {
+        e1 = -inf; e2 = -inf;  // alpha' <= alpha < skip everywhere: never contributes
+      }
+    }
+    if (!(e1 == e1) || !(e2 == e2)) { e1 = inf; e2 = inf; }  // NaN guard
   }
   rec[3 * (size_t)i + 0] = make_float4(ux, uy, c0, c1);
-  rec[3 * (size_t)i + 1] = make_float4(c2, alphas[i], r, g);
-  rec[3 * (size_t)i + 2] = make_float4(b, __uint_as_float(bx), __uint_as_float(by), 0.f);
+  rec[3 * (size_t)i + 1] = make_float4(c2, alpha, r, g);
+  rec[3 * (size_t)i + 2] = make_float4(b, e1, e2, 0.f);
 }
 
 // ============================================================================
 // draw: per-tile front-to-back blend                   (reference kernel.cu:152-271)
 // ============================================================================
 struct DrawParams {
-  int W, H, gx, T;
+  int W, H, gx, gy, T;
   float alpha_skip, tau_stop;
   int maha_floor, alpha_clamp;
+  int map_mode;  // 0: tile = block; 1: contiguous band per XCD; 2: tile rows interleaved over XCDs
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
 // XCD a contiguous band of tiles so that its private 4-MiB L2 serves 1/8 of the
 // Gaussian records instead of all of them.  Bijective for any T.
-__device__ __forceinline__ int xcd_tile(int b, int T) {
-  const int q = T >> 3, r = T & 7, xcd = b & 7, k = b >> 3;
-  return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+__device__ __forceinline__ int xcd_tile(int b, const DrawParams& p) {
+  if (p.map_mode == 0) return b < p.T ? b : -1;
+  const int xcd = b & 7, k = b >> 3;
+  if (p.map_mode == 1) {
+    if (b >= p.T) return -1;
+    const int q = p.T >> 3, r = p.T & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + k;
+  }
+  // mode 2: tile row ty belongs to XCD ty % 8 (balanced when list lengths vary smoothly
+  // over the image, still row-coherent inside one L2); the grid is padded to
+  // 8 * ceil(gy/8) * gx blocks and the surplus blocks exit.
+  const int ty = xcd + 8 * (k / p.gx), tx = k % p.gx;
+  return ty < p.gy ? ty * p.gx + tx : -1;
 }
+static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(p.gy, 8) * p.gx : p.T; }
 
-template <bool BOX>
+// Policy is compiled in (BOX: pixel-box footprint; FLOOR: max(0,m); CLAMP: min(0.99,.));
+// the two thresholds stay runtime scalars (SGPR operands of the compares).
+//
+// One wave64 per 16x16 tile.  The tile is walked as four 8x8 pixel blocks
+// (k = 0..3, block (k&1, k>>1)); lane l owns pixel (l&7, l>>3) of each block.  Per
+// list entry a block is skipped outright when the entry's certain-miss box (pack
+// kernel) or pixel box does not reach it -- a wave-uniform branch.  The quadratic
+// form is evaluated separably: cxx[bx] + cyy[by] + cxy[bx]*dy[by].
+// A pixel that is finished (tau < tau_stop) or outside the image carries the
+// sign bit in `cont`, so "still live" is one v_cmp_ge_i32 and "whole tile
+// finished" is the sign of the AND of the four counters.
+template <bool BOX, bool FLOOR, bool CLAMP>
 __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
   __shared__ float4 sA[64], sB[64], sC[64];
-  const int tile = xcd_tile(blockIdx.x, p.T);
+  const int tile = xcd_tile(blockIdx.x, p);
+  if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
   const int n = r1 - r0;
   if (n <= 0) return;  // empty tile: outputs stay 0 (final_tau = 0, as the reference leaves it)
   const int lane = threadIdx.x;
-  const int px = (tile % p.gx) * EGS_TILE + (lane & 15);
-  const int py0 = (tile / p.gx) * EGS_TILE + (lane >> 4);  // rows py0 + 4k
-  const float fpx = (float)px;
-  float tau[4], cr[4], cg[4], cb[4], fpy[4];
+  const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
+  const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
+  const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
+  const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
+  const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
+  const float bcx[2] = {(float)tx0 + 3.5f, (float)tx0 + 11.5f};  // block centres
+  const float bcy[2] = {(float)ty0 + 3.5f, (float)ty0 + 11.5f};
+  constexpr int DONE = (int)0x80000000;
+  float tau[4], cr[4], cg[4], cb[4];
   int cont[4];
-  bool live[4];
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int py = py0 + 4 * k;
-    fpy[k] = (float)py;
-    live[k] = (px < p.W) && (py < p.H);
-    tau[k] = 1.f; cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f; cont[k] = 0;
+    cont[k] = ((pxb[k & 1] < p.W) && (pyb[k >> 1] < p.H)) ? 0 : DONE;
+    tau[k] = 1.f; cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f;
   }
+  const float skip = p.alpha_skip, stop = p.tau_stop;
   for (int base = 0; base < n; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     if (base + lane < n) {
@@ -430,43 +483,69 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
     const int m = min(64, n - base);
     for (int j = 0; j < m; ++j) {
       const float4 A = sA[j], B = sB[j], C = sC[j];  // wave-uniform address: LDS broadcast
-      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
+      bool okx[2], oky[2], inx[2] = {true, true}, iny[2] = {true, true};
       if (BOX) {
         const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
-        x0 = bx & 0xFFFF; x1 = bx >> 16; y0 = by & 0xFFFF; y1 = by >> 16;
-      }
-      const float dx = A.x - fpx;
+        const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const float dy = A.y - fpy[k];
-        float maha = A.z * dx * dx + B.x * dy * dy + 2 * A.w * dx * dy;  // F.5.1, common.cuh:85-88
-        if (p.maha_floor) maha = fmaxf(0.f, maha);
-        float ap = B.y * __expf(-0.5f * maha);
-        if (p.alpha_clamp) ap = fminf(0.99f, ap);
-        bool hit = live[k] && !(ap < p.alpha_skip);
-        if (BOX) hit = hit && (px >= x0) && (px < x1) && (py0 + 4 * k >= y0) && (py0 + 4 * k < y1);
-        if (hit) {
-          const float w = tau[k] * ap;  // F.5
-          cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
-          cont[k] = base + j + 1;
-          tau[k] = tau[k] * (1.f - ap);  // F.5.2
-          if (tau[k] < p.tau_stop) live[k] = false;
+        for (int b = 0; b < 2; ++b) {
+          okx[b] = (x0 < tx0 + 8 * b + 8) && (x1 > tx0 + 8 * b);
+          oky[b] = (y0 < ty0 + 8 * b + 8) && (y1 > ty0 + 8 * b);
+          inx[b] = (pxb[b] >= x0) && (pxb[b] < x1);
+          iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
+        }
+      } else {
+        const float rx = C.y + 3.5f, ry = C.z + 3.5f;
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          okx[b] = fabsf(A.x - bcx[b]) <= rx;
+          oky[b] = fabsf(A.y - bcy[b]) <= ry;
         }
       }
-      if (!__any(live[0] || live[1] || live[2] || live[3])) goto done;
+      float cxx[2], cxy[2], cyy[2], dy[2];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float dx = A.x - fpx[b];
+        cxx[b] = A.z * dx * dx;   // cinv.x dx dx
+        cxy[b] = 2.f * A.w * dx;  // 2 cinv.y dx
+        dy[b] = A.y - fpy[b];
+        cyy[b] = B.x * dy[b] * dy[b];  // cinv.z dy dy
+      }
+      const int idx = base + j + 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const int bx = k & 1, by = k >> 1;
+        if (okx[bx] && oky[by]) {  // wave-uniform: the whole 8x8 block is in reach
+          float maha = cxx[bx] + cyy[by] + cxy[bx] * dy[by];  // F.5.1 (common.cuh:85-88)
+          if (FLOOR) maha = fmaxf(0.f, maha);
+          float ap = B.y * __builtin_amdgcn_exp2f(maha * -0.72134752044f);  // alpha exp(-maha/2)
+          if (CLAMP) ap = fminf(0.99f, ap);
+          bool hit = (cont[k] >= 0) && !(ap < skip);
+          if (BOX) hit = hit && inx[bx] && iny[by];
+          if (hit) {
+            const float w = tau[k] * ap;  // F.5
+            cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
+            const float t = tau[k] * (1.f - ap);  // F.5.2
+            tau[k] = t;
+            cont[k] = (t < stop) ? (idx | DONE) : idx;
+          }
+        }
+      }
+      // wave-uniform exit: every pixel of the tile is finished (all four sign bits in all lanes)
+      if (__all((cont[0] & cont[1] & cont[2] & cont[3]) < 0)) goto done;
     }
   }
 done:
   const size_t HW = (size_t)p.W * p.H;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int py = py0 + 4 * k;
+    const int px = pxb[k & 1], py = pyb[k >> 1];
     if (px < p.W && py < p.H) {
       const size_t pix = (size_t)py * p.W + px;
       image[pix] = cr[k];
       image[HW + pix] = cg[k];
       image[2 * HW + pix] = cb[k];
-      contrib[pix] = cont[k];
+      contrib[pix] = cont[k] & 0x7FFFFFFF;
       final_tau[pix] = tau[k];
     }
   }
@@ -475,23 +554,50 @@ done:
 // ============================================================================
 // draw backward: per-tile back-to-front gradients        (reference kernel.cu:809-950)
 // ============================================================================
-template <int CTRL, int ROW_MASK>
+template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, false);
+  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
   return v + __int_as_float(t);
 }
-// wave64 sum; the total is valid in lanes 48..63 (read lane 63)
-__device__ __forceinline__ float wave_reduce_to_last(float v) {
-  v = dpp_add<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141, 0xF>(v);  // row_half_mirror
-  v = dpp_add<0x140, 0xF>(v);  // row_mirror
-  v = dpp_add<0x142, 0xA>(v);  // row_bcast15 -> rows 1,3
-  v = dpp_add<0x143, 0xC>(v);  // row_bcast31 -> rows 2,3
+// sum over each row of 16 lanes; every lane of a row ends up with its row's total
+__device__ __forceinline__ float row_sum16(float v) {
+  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
+  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
+  v = dpp_add<0x141>(v);  // row_half_mirror
+  v = dpp_add<0x140>(v);  // row_mirror
   return v;
 }
+// gfx950 cross-half / cross-row swaps (v_permlane32_swap_b32, v_permlane16_swap_b32)
+__device__ __forceinline__ void swap32(float& a, float& b) {  // a[32..63] <-> b[0..31]
+  auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+__device__ __forceinline__ void swap16(float& a, float& b) {  // odd rows of a <-> even rows of b
+  auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+  a = __uint_as_float(r[0]);
+  b = __uint_as_float(r[1]);
+}
+// Four per-lane partials (one per list entry e0..e3) -> one register whose rows of 16
+// lanes hold the four wave totals in the order [e0, e2, e1, e3]: 3 swaps + 3 adds + 4 DPP
+// adds instead of 4 x 6 DPP adds.
+__device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3) {
+  swap32(e0, e1);
+  const float s01 = e0 + e1;  // lanes 0-31: e0 halves, lanes 32-63: e1 halves
+  swap32(e2, e3);
+  const float s23 = e2 + e3;
+  float a = s01, b = s23;
+  swap16(a, b);               // rows of a: [e0, e2, e1, e3]; rows of b: the other halves
+  return row_sum16(a + b);
+}
 
-template <bool BOX>
+// Per-tile back-to-front gradient pass.  One wave64 per 16x16 tile walked as four 8x8
+// pixel blocks exactly like k_draw (same block cull).  Entries are visited in descending
+// list order in groups of four; the 9 gradient partials of each entry (dalpha,
+// dcolor[3], du[2], dcinv[3]) are summed in-lane over the 4 pixels, reduced across the
+// wave 4 entries at a time (reduce4), and one lane per entry issues the 9 atomics: one
+// atomic set per (tile, Gaussian).
+template <bool BOX, bool FLOOR, bool CLAMP>
 __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __restrict__ ranges,
                                                  const int32_t* __restrict__ gsid,
                                                  const float4* __restrict__ rec,
@@ -502,22 +608,26 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
                                                  float* __restrict__ dcolor) {
   __shared__ float4 sA[64], sB[64], sC[64];
   __shared__ int sG[64];
-  const int tile = xcd_tile(blockIdx.x, p.T);
+  const int tile = xcd_tile(blockIdx.x, p);
+  if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
   const int n = r1 - r0;
   if (n <= 0) return;
   const int lane = threadIdx.x;
-  const int px = (tile % p.gx) * EGS_TILE + (lane & 15);
-  const int py0 = (tile / p.gx) * EGS_TILE + (lane >> 4);
-  const float fpx = (float)px;
+  const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
+  const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
+  const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
+  const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
+  const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
+  const float bcx[2] = {(float)tx0 + 3.5f, (float)tx0 + 11.5f};
+  const float bcy[2] = {(float)ty0 + 3.5f, (float)ty0 + 11.5f};
   const size_t HW = (size_t)p.W * p.H;
-  float tau[4], fpy[4], lr[4], lg[4], lb[4], qr[4], qg[4], qb[4];  // q = gamma_cur2last
+  float tau[4], lr[4], lg[4], lb[4], qr[4], qg[4], qb[4];  // q = gamma_cur2last
   int cont[4];
   int maxcont = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    const int py = py0 + 4 * k;
-    fpy[k] = (float)py;
+    const int px = pxb[k & 1], py = pyb[k >> 1];
     tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f;
     qr[k] = 0.f; qg[k] = 0.f; qb[k] = 0.f;
     if (px < p.W && py < p.H) {
@@ -532,6 +642,8 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
   for (int d = 32; d >= 1; d >>= 1) maxcont = max(maxcont, __shfl_xor(maxcont, d, 64));
   maxcont = min(maxcont, n);
   if (maxcont <= 0) return;
+  const float skip = p.alpha_skip;
+  constexpr float NHL2E = -0.72134752044f;  // -0.5 * log2(e)
 
   for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
     __syncthreads();
@@ -545,62 +657,94 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
     }
     __syncthreads();
     const int jhi = min(63, maxcont - 1 - c * 64);
-    for (int j = jhi; j >= 0; --j) {
-      const int i = c * 64 + j;  // forward index of this entry in the tile list
-      const float4 A = sA[j], B = sB[j], C = sC[j];
-      int x0 = 0, x1 = 0, y0 = 0, y1 = 0;
-      if (BOX) {
-        const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
-        x0 = bx & 0xFFFF; x1 = bx >> 16; y0 = by & 0xFFFF; y1 = by >> 16;
-      }
-      const float dx = A.x - fpx;
-      float a_al = 0.f, a_cr = 0.f, a_cg = 0.f, a_cb = 0.f, a_ux = 0.f, a_uy = 0.f, a_c0 = 0.f, a_c1 = 0.f,
-            a_c2 = 0.f;
+    for (int jj = jhi; jj >= 0; jj -= 4) {  // entries jj, jj-1, jj-2, jj-3 (descending list order)
+      float acc[4][9];
       bool any = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (i >= cont[k]) continue;  // this pixel never reached entry i (kernel.cu:899)
-        const float dy = A.y - fpy[k];
-        float maha = A.z * dx * dx + B.x * dy * dy + 2 * A.w * dx * dy;
-        if (p.maha_floor) maha = fmaxf(0.f, maha);
-        const float g = __expf(-0.5f * maha);
-        float ap = B.y * g;
-        if (p.alpha_clamp) ap = fminf(0.99f, ap);
-        if (BOX && !((px >= x0) && (px < x1) && (py0 + 4 * k >= y0) && (py0 + 4 * k < y1))) continue;
-        if (ap < p.alpha_skip) continue;
-        tau[k] = tau[k] / (1.f - ap);  // undo F.5.2
-        const float tk = tau[k];
-        // B.5a: dgamma/dalpha' = tau (color - gamma_cur2last)
-        const float dl_dap = lr[k] * (tk * (B.z - qr[k])) + lg[k] * (tk * (B.w - qg[k])) + lb[k] * (tk * (C.x - qb[k]));
-        a_al += dl_dap * g;  // B.5.1a: dalpha'/dalpha = g (also where the clamp binds, kernel.cu:921)
-        const float wgt = ap * tk;  // B.5b
-        a_cr += lr[k] * wgt; a_cg += lg[k] * wgt; a_cb += lb[k] * wgt;
-        a_ux += dl_dap * ((-A.z * dx - A.w * dy) * ap);  // B.5.2b
-        a_uy += dl_dap * ((-A.w * dx - B.x * dy) * ap);
-        a_c0 += dl_dap * (-0.5f * ap * (dx * dx));  // B.5.2c
-        a_c1 += dl_dap * (-1.0f * ap * (dx * dy));
-        a_c2 += dl_dap * (-0.5f * ap * (dy * dy));
-        qr[k] = ap * B.z + (1.f - ap) * qr[k];
-        qg[k] = ap * B.w + (1.f - ap) * qg[k];
-        qb[k] = ap * C.x + (1.f - ap) * qb[k];
-        any = true;
+      for (int e = 0; e < 4; ++e) {
+#pragma unroll
+        for (int q = 0; q < 9; ++q) acc[e][q] = 0.f;
+        const int j = jj - e;
+        if (j < 0) continue;  // wave-uniform
+        const int i = c * 64 + j;  // forward index of this entry in the tile list
+        const float4 A = sA[j], B = sB[j], C = sC[j];
+        bool okx[2], oky[2], inx[2] = {true, true}, iny[2] = {true, true};
+        if (BOX) {
+          const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+          const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            okx[b] = (x0 < tx0 + 8 * b + 8) && (x1 > tx0 + 8 * b);
+            oky[b] = (y0 < ty0 + 8 * b + 8) && (y1 > ty0 + 8 * b);
+            inx[b] = (pxb[b] >= x0) && (pxb[b] < x1);
+            iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
+          }
+        } else {
+          const float rx = C.y + 3.5f, ry = C.z + 3.5f;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            okx[b] = fabsf(A.x - bcx[b]) <= rx;
+            oky[b] = fabsf(A.y - bcy[b]) <= ry;
+          }
+        }
+        float dx[2], dy[2], cxx[2], cxy[2], cyy[2];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          dx[b] = A.x - fpx[b];
+          cxx[b] = A.z * dx[b] * dx[b];
+          cxy[b] = 2.f * A.w * dx[b];
+          dy[b] = A.y - fpy[b];
+          cyy[b] = B.x * dy[b] * dy[b];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const int bx = k & 1, by = k >> 1;
+          if (!(okx[bx] && oky[by])) continue;  // wave-uniform block cull
+          float maha = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
+          if (FLOOR) maha = fmaxf(0.f, maha);
+          const float g = __builtin_amdgcn_exp2f(maha * NHL2E);
+          float ap = B.y * g;
+          if (CLAMP) ap = fminf(0.99f, ap);
+          bool hit = (i < cont[k]) && !(ap < skip);  // kernel.cu:899,913
+          if (BOX) hit = hit && inx[bx] && iny[by];
+          if (hit) {
+            const float tk = tau[k] * __builtin_amdgcn_rcpf(1.f - ap);  // undo F.5.2
+            tau[k] = tk;
+            const float dr = B.z - qr[k], dg = B.w - qg[k], db = C.x - qb[k];
+            const float dl_dap = tk * (lr[k] * dr + lg[k] * dg + lb[k] * db);  // B.5a
+            acc[e][0] += dl_dap * g;  // B.5.1a: dalpha'/dalpha = g (also where the clamp binds)
+            const float wgt = ap * tk;  // B.5b
+            acc[e][1] += lr[k] * wgt; acc[e][2] += lg[k] * wgt; acc[e][3] += lb[k] * wgt;
+            const float w = dl_dap * ap;
+            acc[e][4] -= w * (A.z * dx[bx] + A.w * dy[by]);  // B.5.2b
+            acc[e][5] -= w * (A.w * dx[bx] + B.x * dy[by]);
+            acc[e][6] -= w * (0.5f * dx[bx] * dx[bx]);       // B.5.2c
+            acc[e][7] -= w * (dx[bx] * dy[by]);
+            acc[e][8] -= w * (0.5f * dy[by] * dy[by]);
+            qr[k] += ap * dr; qg[k] += ap * dg; qb[k] += ap * db;  // gamma_cur2last
+            any = true;
+          }
+        }
       }
       if (__any(any)) {  // wave-uniform
-        a_al = wave_reduce_to_last(a_al);
-        a_cr = wave_reduce_to_last(a_cr); a_cg = wave_reduce_to_last(a_cg); a_cb = wave_reduce_to_last(a_cb);
-        a_ux = wave_reduce_to_last(a_ux); a_uy = wave_reduce_to_last(a_uy);
-        a_c0 = wave_reduce_to_last(a_c0); a_c1 = wave_reduce_to_last(a_c1); a_c2 = wave_reduce_to_last(a_c2);
-        if (lane == 63) {  // one atomic set per (tile, Gaussian)
-          const size_t g = (size_t)sG[j];
-          unsafeAtomicAdd(dalpha + g, a_al);
-          unsafeAtomicAdd(dcolor + 3 * g, a_cr);
-          unsafeAtomicAdd(dcolor + 3 * g + 1, a_cg);
-          unsafeAtomicAdd(dcolor + 3 * g + 2, a_cb);
-          unsafeAtomicAdd(dus + 2 * g, a_ux);
-          unsafeAtomicAdd(dus + 2 * g + 1, a_uy);
-          unsafeAtomicAdd(dcinv + 3 * g, a_c0);
-          unsafeAtomicAdd(dcinv + 3 * g + 1, a_c1);
-          unsafeAtomicAdd(dcinv + 3 * g + 2, a_c2);
+        float tot[9];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) tot[q] = reduce4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
+        // row r of the wave now holds the totals of entry e = {0,2,1,3}[r]
+        const int row = lane >> 4;
+        const int e = ((row & 1) << 1) | (row >> 1);
+        const int j = jj - e;
+        if ((lane & 15) == 0 && j >= 0 && (tot[0] != 0.f || tot[1] != 0.f || tot[2] != 0.f || tot[3] != 0.f)) {
+          const size_t g = (size_t)sG[j];  // one atomic set per (tile, Gaussian)
+          unsafeAtomicAdd(dalpha + g, tot[0]);
+          unsafeAtomicAdd(dcolor + 3 * g, tot[1]);
+          unsafeAtomicAdd(dcolor + 3 * g + 1, tot[2]);
+          unsafeAtomicAdd(dcolor + 3 * g + 2, tot[3]);
+          unsafeAtomicAdd(dus + 2 * g, tot[4]);
+          unsafeAtomicAdd(dus + 2 * g + 1, tot[5]);
+          unsafeAtomicAdd(dcinv + 3 * g, tot[6]);
+          unsafeAtomicAdd(dcinv + 3 * g + 1, tot[7]);
+          unsafeAtomicAdd(dcinv + 3 * g + 2, tot[8]);
         }
       }
     }
@@ -662,7 +806,13 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol) {
   DrawParams p;
   p.W = W; p.H = H;
   p.gx = div_up(W, EGS_TILE);
-  p.T = p.gx * div_up(H, EGS_TILE);
+  p.gy = div_up(H, EGS_TILE);
+  p.T = p.gx * p.gy;
+  static const int mode = [] {  // tuning knob (EGS_TILE_MAP=0|1|2), default chosen by measurement
+    const char* e = getenv("EGS_TILE_MAP");
+    return e ? atoi(e) : 2;
+  }();
+  p.map_mode = mode;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
   return p;
@@ -771,19 +921,30 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
   EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
                      v0);
-  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint, us,
+  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
+             pol->alpha_skip, us,
                      cinv2ds, alphas, colors, areas, D.rec);
   EGS_LAUNCH_OK();
   int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s);
   if (rc) return rc;
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile);
-  if (pol->footprint == 1)
-    EGS_LAUNCH("k_draw", (k_draw<true>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
-                       image, contrib, final_tau);
-  else
-    EGS_LAUNCH("k_draw", (k_draw<false>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, D.rec,
-                       image, contrib, final_tau);
+  // policy -> template instance (compile-time footprint / floor / clamp)
+#define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                        \
+  EGS_LAUNCH("k_draw", (k_draw<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile,     \
+             gsid_per_patch, D.rec, image, contrib, final_tau)
+  const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
+  switch (sel) {
+    case 0: EGS_DRAW(false, false, false); break;
+    case 1: EGS_DRAW(false, false, true); break;
+    case 2: EGS_DRAW(false, true, false); break;
+    case 3: EGS_DRAW(false, true, true); break;
+    case 4: EGS_DRAW(true, false, false); break;
+    case 5: EGS_DRAW(true, false, true); break;
+    case 6: EGS_DRAW(true, true, false); break;
+    default: EGS_DRAW(true, true, true); break;
+  }
+#undef EGS_DRAW
   EGS_LAUNCH_OK();
   return 0;
 }
@@ -810,14 +971,25 @@ extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, cons
   hipStream_t s = (hipStream_t)stream;
   float4* rec = (float4*)ws;
   const DrawParams dp = make_draw_params(width, height, pol);
-  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint, us,
+  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
+             pol->alpha_skip, us,
                      cinv2ds, alphas, colors, areas, rec);
-  if (pol->footprint == 1)
-    EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<true>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, rec,
-                       final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
-  else
-    EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<false>), dim3(dp.T), dim3(64), s, dp, patch_range_per_tile, gsid_per_patch, rec,
-                       final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
+#define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
+  EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile, \
+             gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, \
+             dloss_dcolors)
+  const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
+  switch (sel) {
+    case 0: EGS_DRAWB(false, false, false); break;
+    case 1: EGS_DRAWB(false, false, true); break;
+    case 2: EGS_DRAWB(false, true, false); break;
+    case 3: EGS_DRAWB(false, true, true); break;
+    case 4: EGS_DRAWB(true, false, false); break;
+    case 5: EGS_DRAWB(true, false, true); break;
+    case 6: EGS_DRAWB(true, true, false); break;
+    default: EGS_DRAWB(true, true, true); break;
+  }
+#undef EGS_DRAWB
   EGS_LAUNCH_OK();
   return 0;
 }

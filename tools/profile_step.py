@@ -1,0 +1,44 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3: a few forward+backward steps of the bench
+workload (same code path as bench.py's step) so the trace / counter output stays
+small.   rocprofv3 --kernel-trace --stats [--pmc ...] -- python tools/profile_step.py"""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--gaussians", type=int, default=1_000_000)
+ap.add_argument("--width", type=int, default=1920)
+ap.add_argument("--height", type=int, default=1080)
+ap.add_argument("--fwd-only", action="store_true")
+a = ap.parse_args()
+
+import torch
+from easygaussiansplatting_amd import scene as S
+from easygaussiansplatting_amd.function import Camera, GSFunction, render
+
+dev = torch.device("cuda", 0)
+sc = S.big_scene(a.gaussians, a.width, a.height, 48)
+cam = Camera.from_scene(sc.cam, dev)
+t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+P = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1), scales=t(sc.scales), rots=t(sc.rots))
+for p in P.values():
+    p.requires_grad_(True)
+us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+dl = torch.from_numpy(S.normal(1, 77, (3, a.height, a.width)).astype(np.float32)).to(dev) / (3 * a.width * a.height)
+for _ in range(a.steps):
+    if a.fwd_only:
+        with torch.no_grad():
+            render(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam)
+    else:
+        for p in P.values():
+            p.grad = None
+        img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+        img.backward(dl)
+torch.cuda.synchronize()
+print("done")
