@@ -56,6 +56,11 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         # drawB: same gather + 9 fp32 atomics (RMW = 72 B) per patch + 20 B per pixel in
         "k_draw_bwd": 112 * P + 8 * T + 20 * HW,
         "k_chain_rule": N * (436 - 24 + 24 + 36 + 4 * (3 + 3 * nc + 3 + 4)),
+        # fused path: parameters in (pw 12, rot 16, scale 12, sh 4K) + 2D records out (44 B)
+        "k_preprocess_fwd": N * (40 + 4 * K + 44),
+        # parameters + depth + packed gradient record in, 59 gradient floats + du out
+        "k_preprocess_bwd": N * (40 + 4 * K + 4 + 48 + 4 * (3 + K + 1 + 3 + 4 + 2)),
+        "k_unpack_grads": N * (48 + 36),
     }
     return table.get(kernel)
 
@@ -104,6 +109,8 @@ def main():
     ap.add_argument("--sh-dim", type=int, default=48)
     ap.add_argument("--cpu-sample", type=int, default=250_000, help="Gaussians in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--mode", default="fused", choices=["fused", "ops", "ops_bmm"],
+                    help="GSFunction evaluation: fused kernels (default) or the reference's 7-op structure")
     a = ap.parse_args()
 
     import torch
@@ -127,6 +134,17 @@ def main():
 
     lib = _lib.load()
     gsc.set_policy("gsplatcu")
+    GSFunction.mode = a.mode
+    from easygaussiansplatting_amd import fused as fused_path
+
+    def forward_only():
+        with torch.no_grad():
+            d = {k: v.detach() for k, v in params.items()}
+            if a.mode == "fused":
+                img, _, st = fused_path.forward(d["pws"], d["shs"], d["alphas"], d["scales"], d["rots"], cam)
+                return img, st.ranges, st.gsid
+            out = render(d["pws"], d["shs"], d["alphas"], d["scales"], d["rots"], cam)
+            return out[0], out[3], out[4]
     sc = S.big_scene(a.gaussians, a.width, a.height, a.sh_dim)
     cams = S.ring_cameras(sc.cam, max(8, world))
     cam = Camera.from_scene(cams[rank % len(cams)], dev)   # one view per GPU; view 0 = the BASELINE camera
@@ -182,9 +200,7 @@ def main():
 
     # realised scene statistics (bytes depend on them)
     with torch.no_grad():
-        out = render(params["pws"].detach(), params["shs"].detach(), params["alphas"].detach(),
-                     params["scales"].detach(), params["rots"].detach(), cam)
-        ranges, gsid = out[3], out[4]
+        _, ranges, gsid = forward_only()
         lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64)
         P = int(gsid.shape[0]); T = int(ranges.shape[0])
         max_len = int(lens.max().item())
@@ -194,8 +210,7 @@ def main():
         tf0 = time.perf_counter()
         nf = max(3, a.steps // 2)
         for _ in range(nf):
-            render(params["pws"].detach(), params["shs"].detach(), params["alphas"].detach(),
-                   params["scales"].detach(), params["rots"].detach(), cam)
+            forward_only()
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
 
@@ -240,11 +255,11 @@ def main():
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "1 MI355X per view: %d synthetic Gaussians, %dx%d, SH degree %d, "
-                                   "forward+backward (6 ops calc_J=True + splatB + chain rule)%s"
-                                   % (sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim],
+                                   "forward+backward (GSFunction, mode=%s)%s"
+                                   % (sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim], a.mode,
                                       ", RCCL all-reduce of 59 fp32 grads/Gaussian" if world > 1 else ""),
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
-                       "views_per_step": world, "policy": "gsplatcu",
+                       "views_per_step": world, "policy": "gsplatcu", "mode": a.mode,
                        "patches": P, "tiles": T, "max_list_len": max_len, "pixel_gaussian_pairs": pairs},
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,

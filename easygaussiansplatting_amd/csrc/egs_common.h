@@ -76,6 +76,14 @@ struct Carver {
   bool ok() const { return off <= cap; }
 };
 
+// splatB's draw pass into the packed [N][12] gradient records (egs_raster.hip); *gpack
+// points into `ws`.  Shared by egs_splat_bwd (+unpack) and egs_fused_backward.
+int splat_bwd_packed(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
+                     const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
+                     const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                     const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                     float** gpack, void* stream);
+
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63u); }

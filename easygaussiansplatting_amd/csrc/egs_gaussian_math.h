@@ -1,0 +1,335 @@
+// Per-Gaussian math of the splatting pipeline as register-resident device
+// functions: values AND Jacobians (F.1-F.5.3, B.1.2-B.5.3 of the reference's
+// docs/forward.md, docs/backward.md; behaviour of gsplatcu/kernel.cu:274-807).
+// One source of truth for the seven-op surface (egs_preprocess.hip, Jacobians
+// stored to HBM as the reference's ops do) and for the fused training path
+// (Jacobians never leave registers).
+//
+// The reference multiplies dense Matrix<6,9>x<9,4> objects that are mostly zeros
+// (kernel.cu:382-409, 512-537); here the block structure of those Jacobians is
+// applied directly.
+#pragma once
+#include "egs_common.h"
+
+namespace egs {
+
+struct f3 { float x, y, z; };
+struct q4 { float w, x, y, z; };
+__device__ __forceinline__ f3 ld3(const float* p) { return {p[0], p[1], p[2]}; }
+__device__ __forceinline__ void st3(float* p, f3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
+__device__ __forceinline__ f3 operator*(float s, f3 a) { return {s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ f3 operator+(f3 a, f3 b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ float dot(f3 a, f3 b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+__device__ __forceinline__ f3 had(f3 a, f3 b) { return {a.x * b.x, a.y * b.y, a.z * b.z}; }
+// row-vector (3) times a 3x4 block given as three q4 rows
+__device__ __forceinline__ q4 vm(f3 v, q4 r0, q4 r1, q4 r2) {
+  return {v.x * r0.w + v.y * r1.w + v.z * r2.w, v.x * r0.x + v.y * r1.x + v.z * r2.x,
+          v.x * r0.y + v.y * r1.y + v.z * r2.y, v.x * r0.z + v.y * r1.z + v.z * r2.z};
+}
+__device__ __forceinline__ q4 operator+(q4 a, q4 b) { return {a.w + b.w, a.x + b.x, a.y + b.y, a.z + b.z}; }
+__device__ __forceinline__ q4 operator*(float s, q4 a) { return {s * a.w, s * a.x, s * a.y, s * a.z}; }
+__device__ __forceinline__ void st4(float* p, q4 v) { p[0] = v.w; p[1] = v.x; p[2] = v.y; p[3] = v.z; }
+
+// ---- project: F.1.1 / F.1.2, B.1.2                     (reference kernel.cu:553-617)
+struct Proj {
+  f3 pc;
+  float u0, u1, z_inv;
+};
+__device__ __forceinline__ Proj project_f(f3 pw, const float* __restrict__ Rcw,
+                                          const float* __restrict__ tcw, float fx, float fy, float cx,
+                                          float cy) {
+  Proj o;
+  o.pc.x = Rcw[0] * pw.x + Rcw[1] * pw.y + Rcw[2] * pw.z + tcw[0];
+  o.pc.y = Rcw[3] * pw.x + Rcw[4] * pw.y + Rcw[5] * pw.z + tcw[1];
+  o.pc.z = Rcw[6] * pw.x + Rcw[7] * pw.y + Rcw[8] * pw.z + tcw[2];
+  o.z_inv = 1.f / o.pc.z;
+  o.u0 = (o.pc.x * fx) * o.z_inv + cx;
+  o.u1 = (o.pc.y * fy) * o.z_inv + cy;
+  return o;
+}
+// du/dpc (2x3): J = [j00 0 j02; 0 j11 j12]
+__device__ __forceinline__ void project_jac(const Proj& p, float fx, float fy, float& j00, float& j02,
+                                            float& j11, float& j12) {
+  const float z2_inv = p.z_inv * p.z_inv;
+  j00 = fx * p.z_inv;
+  j02 = -(p.pc.x * fx) * z2_inv;
+  j11 = fy * p.z_inv;
+  j12 = -(p.pc.y * fy) * z2_inv;
+}
+
+// ---- cov3d: F.2, B.2a, B.2b                             (reference kernel.cu:326-423)
+struct Cov3 {
+  f3 R0, R1, R2;  // rotation from the (un-normalised) quaternion
+  f3 M0, M1, M2;  // M = R diag(s)
+  float c[6];     // upper triangle of M M^T
+};
+__device__ __forceinline__ Cov3 cov3d_f(float4 q, f3 s) {
+  const float w = q.x, x = q.y, y = q.z, z = q.w;  // (w,x,y,z); NOT normalised (kernel.cu:342-347)
+  const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, xz = x * z, yz = y * z;
+  const float xw = x * w, yw = y * w, zw = z * w;
+  Cov3 o;
+  o.R0 = {1.f - 2.f * (yy + zz), 2.f * (xy - zw), 2.f * (xz + yw)};
+  o.R1 = {2.f * (xy + zw), 1.f - 2.f * (xx + zz), 2.f * (yz - xw)};
+  o.R2 = {2.f * (xz - yw), 2.f * (yz + xw), 1.f - 2.f * (xx + yy)};
+  o.M0 = had(o.R0, s); o.M1 = had(o.R1, s); o.M2 = had(o.R2, s);
+  o.c[0] = dot(o.M0, o.M0); o.c[1] = dot(o.M0, o.M1); o.c[2] = dot(o.M0, o.M2);
+  o.c[3] = dot(o.M1, o.M1); o.c[4] = dot(o.M1, o.M2); o.c[5] = dot(o.M2, o.M2);
+  return o;
+}
+// dM/dq as three 3x4 blocks (rows of M); columns d/dw d/dx d/dy d/dz   (kernel.cu:388-396)
+struct DMdq { q4 A0, A1, A2, B0, B1, B2, C0, C1, C2; };
+__device__ __forceinline__ DMdq dm_dq(float4 q, f3 s) {
+  const float w = q.x, x = q.y, y = q.z, z = q.w;
+  const float s0 = s.x, s1 = s.y, s2 = s.z;
+  DMdq d;
+  d.A0 = {0.f, 0.f, -4 * s0 * y, -4 * s0 * z};
+  d.A1 = {-2 * s1 * z, 2 * s1 * y, 2 * s1 * x, -2 * s1 * w};
+  d.A2 = {2 * s2 * y, 2 * s2 * z, 2 * s2 * w, 2 * s2 * x};
+  d.B0 = {2 * s0 * z, 2 * s0 * y, 2 * s0 * x, 2 * s0 * w};
+  d.B1 = {0.f, -4 * s1 * x, 0.f, -4 * s1 * z};
+  d.B2 = {-2 * s2 * x, -2 * s2 * w, 2 * s2 * z, 2 * s2 * y};
+  d.C0 = {-2 * s0 * y, 2 * s0 * z, -2 * s0 * w, 2 * s0 * x};
+  d.C1 = {2 * s1 * x, 2 * s1 * w, 2 * s1 * z, 2 * s1 * y};
+  d.C2 = {0.f, -4 * s2 * x, -4 * s2 * y, 0.f};
+  return d;
+}
+// full Jacobians dcov3d/dq [6x4] and dcov3d/ds [6x3], row-major
+// d(MM^T)/dM has the block rows [2M0,0,0] [M1,M0,0] [M2,0,M0] [0,2M1,0] [0,M2,M1] [0,0,2M2]
+__device__ __forceinline__ void cov3d_jac(const Cov3& c, float4 q, f3 s, float* dq /*24*/, float* ds /*18*/) {
+  const DMdq d = dm_dq(q, s);
+  st4(dq + 0, 2.f * vm(c.M0, d.A0, d.A1, d.A2));
+  st4(dq + 4, vm(c.M1, d.A0, d.A1, d.A2) + vm(c.M0, d.B0, d.B1, d.B2));
+  st4(dq + 8, vm(c.M2, d.A0, d.A1, d.A2) + vm(c.M0, d.C0, d.C1, d.C2));
+  st4(dq + 12, 2.f * vm(c.M1, d.B0, d.B1, d.B2));
+  st4(dq + 16, vm(c.M2, d.B0, d.B1, d.B2) + vm(c.M1, d.C0, d.C1, d.C2));
+  st4(dq + 20, 2.f * vm(c.M2, d.C0, d.C1, d.C2));
+  // dM/ds = diag(R0) | diag(R1) | diag(R2)                               (kernel.cu:397-405)
+  st3(ds + 0, 2.f * had(c.M0, c.R0));
+  st3(ds + 3, had(c.M1, c.R0) + had(c.M0, c.R1));
+  st3(ds + 6, had(c.M2, c.R0) + had(c.M0, c.R2));
+  st3(ds + 9, 2.f * had(c.M1, c.R1));
+  st3(ds + 12, had(c.M2, c.R1) + had(c.M1, c.R2));
+  st3(ds + 15, 2.f * had(c.M2, c.R2));
+}
+// vector-Jacobian product: g[6] = dL/dcov3d  ->  dL/dq, dL/ds, without forming the Jacobians:
+// dL/dM rows = gA, gB, gC;  dL/dq = sum_rows vm(.,block), dL/ds = sum_rows had(., R_row)
+__device__ __forceinline__ void cov3d_vjp(const Cov3& c, float4 q, f3 s, const float* g, q4& gq, f3& gs) {
+  const f3 gA = (2.f * g[0]) * c.M0 + g[1] * c.M1 + g[2] * c.M2;
+  const f3 gB = g[1] * c.M0 + (2.f * g[3]) * c.M1 + g[4] * c.M2;
+  const f3 gC = g[2] * c.M0 + g[4] * c.M1 + (2.f * g[5]) * c.M2;
+  const DMdq d = dm_dq(q, s);
+  gq = vm(gA, d.A0, d.A1, d.A2) + vm(gB, d.B0, d.B1, d.B2) + vm(gC, d.C0, d.C1, d.C2);
+  gs = had(gA, c.R0) + had(gB, c.R1) + had(gC, c.R2);
+}
+
+// ---- cov2d: F.3 (+0.3), B.3a, B.3b                      (reference kernel.cu:425-551)
+struct Cov2 {
+  f3 M0, M1;   // M = J Rcw (2x3)
+  f3 v0, v1;   // Sigma M^T columns
+  float x, y;  // the (fov-clamped) camera-space x, y the Jacobians use
+  float c[3];  // cov2d incl. the +0.3
+};
+__device__ __forceinline__ Cov2 cov2d_f(const float* cv, f3 pc, const float* __restrict__ Rcw, float fx,
+                                        float fy, float limx, float limy, int clamp_fov) {
+  Cov2 o;
+  o.x = pc.x; o.y = pc.y;
+  const float z = pc.z;
+  if (clamp_fov) {
+    o.x = fminf(limx, fmaxf(-limx, o.x / z)) * z;
+    o.y = fminf(limy, fmaxf(-limy, o.y / z)) * z;
+  }
+  const float z2 = z * z;
+  const f3 R0 = ld3(Rcw), R1 = ld3(Rcw + 3), R2 = ld3(Rcw + 6);
+  const float j00 = fx / z, j02 = -(fx * o.x) / z2, j11 = fy / z, j12 = -(fy * o.y) / z2;
+  o.M0 = j00 * R0 + j02 * R2;
+  o.M1 = j11 * R1 + j12 * R2;
+  const float a = cv[0], b = cv[1], c = cv[2], d = cv[3], e = cv[4], f = cv[5];
+  o.v0 = {a * o.M0.x + b * o.M0.y + c * o.M0.z, b * o.M0.x + d * o.M0.y + e * o.M0.z,
+          c * o.M0.x + e * o.M0.y + f * o.M0.z};
+  o.v1 = {a * o.M1.x + b * o.M1.y + c * o.M1.z, b * o.M1.x + d * o.M1.y + e * o.M1.z,
+          c * o.M1.x + e * o.M1.y + f * o.M1.z};
+  o.c[0] = dot(o.M0, o.v0) + 0.3f;
+  o.c[1] = dot(o.M0, o.v1);
+  o.c[2] = dot(o.M1, o.v1) + 0.3f;
+  return o;
+}
+// dcov2d/dcov3d [3x6] (B.3a, kernel.cu:493-510) and dcov2d/dpc [3x3] (B.3b, kernel.cu:512-537)
+__device__ __forceinline__ void cov2d_jac(const Cov2& o, float z, const float* __restrict__ Rcw, float fx,
+                                          float fy, float* J3 /*18*/, float* Jp /*9*/) {
+  const f3 M0 = o.M0, M1 = o.M1;
+  J3[0] = M0.x * M0.x; J3[1] = 2 * M0.x * M0.y; J3[2] = 2 * M0.x * M0.z;
+  J3[3] = M0.y * M0.y; J3[4] = 2 * M0.y * M0.z; J3[5] = M0.z * M0.z;
+  J3[6] = M0.x * M1.x; J3[7] = M0.x * M1.y + M0.y * M1.x; J3[8] = M0.x * M1.z + M0.z * M1.x;
+  J3[9] = M0.y * M1.y; J3[10] = M0.y * M1.z + M0.z * M1.y; J3[11] = M0.z * M1.z;
+  J3[12] = M1.x * M1.x; J3[13] = 2 * M1.x * M1.y; J3[14] = 2 * M1.x * M1.z;
+  J3[15] = M1.y * M1.y; J3[16] = 2 * M1.y * M1.z; J3[17] = M1.z * M1.z;
+  // dcov2d/dM = [2v0,0 ; v1,v0 ; 0,2v1],  dM0/dpc = D0, dM1/dpc = D1
+  const f3 R0 = ld3(Rcw), R1 = ld3(Rcw + 3), R2 = ld3(Rcw + 6);
+  const float z2i = 1.f / (z * z), z3i = z2i / z;
+  const f3 d0c0 = (-fx * z2i) * R2;                            // column 0 of D0
+  const f3 d0c2 = (-fx * z2i) * R0 + (2 * fx * o.x * z3i) * R2;  // column 2 of D0
+  const f3 d1c1 = (-fy * z2i) * R2;                            // column 1 of D1
+  const f3 d1c2 = (-fy * z2i) * R1 + (2 * fy * o.y * z3i) * R2;  // column 2 of D1
+  Jp[0] = 2 * dot(o.v0, d0c0); Jp[1] = 0.f;                 Jp[2] = 2 * dot(o.v0, d0c2);
+  Jp[3] = dot(o.v1, d0c0);     Jp[4] = dot(o.v0, d1c1);     Jp[5] = dot(o.v1, d0c2) + dot(o.v0, d1c2);
+  Jp[6] = 0.f;                 Jp[7] = 2 * dot(o.v1, d1c1); Jp[8] = 2 * dot(o.v1, d1c2);
+}
+
+// ---- inverse_cov2d: F.5.3, radius, B.5.3                (reference kernel.cu:274-324)
+__device__ __forceinline__ float inv_cov2d_f(const float* c2, float det_eps, float* cinv) {
+  const float det_inv = 1.f / (c2[0] * c2[2] - c2[1] * c2[1] + det_eps);
+  cinv[0] = det_inv * c2[2]; cinv[1] = -det_inv * c2[1]; cinv[2] = det_inv * c2[0];
+  return det_inv;
+}
+__device__ __forceinline__ void radius_f(const float* c2, int radius_mode, int& rx, int& ry) {
+  if (radius_mode == 0) {  // ceil(3 sqrt|a|)  (kernel.cu:308)
+    rx = (int)ceilf(3.f * sqrtf(fabsf(c2[0])));
+    ry = (int)ceilf(3.f * sqrtf(fabsf(c2[2])));
+  } else {                 // numpy astype(int32): truncation toward zero (gausplat.py:181-182)
+    rx = (int)(3.f * sqrtf(c2[0]));
+    ry = (int)(3.f * sqrtf(c2[2]));
+  }
+}
+__device__ __forceinline__ void inv_cov2d_jac(const float* c2, float det_inv, float* J /*9*/) {
+  const float a = c2[0], b = c2[1], c = c2[2], d2 = det_inv * det_inv;
+  J[0] = -c * c * d2; J[1] = 2 * b * c * d2; J[2] = -a * c * d2 + det_inv;
+  J[3] = b * c * d2; J[4] = -2 * b * b * d2 - det_inv; J[5] = a * b * d2;
+  J[6] = -a * c * d2 + det_inv; J[7] = 2 * a * b * d2; J[8] = -a * a * d2;
+}
+
+// ---- sh2color: F.4 and its Jacobians                    (reference kernel.cu:619-807)
+// constants: reference common.cuh:28-43 == gsplat/sh_coef.py:5-23
+#define SH_C0_0 0.28209479177387814f
+#define SH_C1_0 (-0.4886025119029199f)
+#define SH_C1_1 0.4886025119029199f
+#define SH_C1_2 (-0.4886025119029199f)
+#define SH_C2_0 1.0925484305920792f
+#define SH_C2_1 (-1.0925484305920792f)
+#define SH_C2_2 0.31539156525252005f
+#define SH_C2_3 (-1.0925484305920792f)
+#define SH_C2_4 0.5462742152960396f
+#define SH_C3_0 (-0.5900435899266435f)
+#define SH_C3_1 2.890611442640554f
+#define SH_C3_2 (-0.4570457994644658f)
+#define SH_C3_3 0.3731763325901154f
+#define SH_C3_4 (-0.4570457994644658f)
+#define SH_C3_5 1.445305721320277f
+#define SH_C3_6 (-0.5900435899266435f)
+
+template <int NC>
+struct ShDir {
+  float d0, d1, d2, ninv, x, y, z;
+  float B[NC];  // basis values == dcolor/dsh (shared by r,g,b)
+};
+// NC = number of SH coefficients per colour channel (1, 4, 9, 16)
+template <int NC>
+__device__ __forceinline__ ShDir<NC> sh_basis_f(f3 pw, const float* __restrict__ twc) {
+  ShDir<NC> o;
+  o.d0 = 0; o.d1 = 0; o.d2 = 0; o.ninv = 0; o.x = 0; o.y = 0; o.z = 0;
+  o.B[0] = SH_C0_0;
+  if constexpr (NC > 1) {
+    o.d0 = pw.x - twc[0]; o.d1 = pw.y - twc[1]; o.d2 = pw.z - twc[2];
+    o.ninv = 1.f / sqrtf(o.d0 * o.d0 + o.d1 * o.d1 + o.d2 * o.d2);
+    o.x = o.d0 * o.ninv; o.y = o.d1 * o.ninv; o.z = o.d2 * o.ninv;
+    o.B[1] = SH_C1_0 * o.y; o.B[2] = SH_C1_1 * o.z; o.B[3] = SH_C1_2 * o.x;
+  }
+  if constexpr (NC > 4) {
+    const float x = o.x, y = o.y, z = o.z;
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    o.B[4] = SH_C2_0 * xy; o.B[5] = SH_C2_1 * yz; o.B[6] = SH_C2_2 * (2.0f * zz - xx - yy);
+    o.B[7] = SH_C2_3 * xz; o.B[8] = SH_C2_4 * (xx - yy);
+    if constexpr (NC > 9) {
+      o.B[9] = SH_C3_0 * y * (3.0f * xx - yy);
+      o.B[10] = SH_C3_1 * xy * z;
+      o.B[11] = SH_C3_2 * y * (4.0f * zz - xx - yy);
+      o.B[12] = SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy);
+      o.B[13] = SH_C3_4 * x * (4.0f * zz - xx - yy);
+      o.B[14] = SH_C3_5 * z * (xx - yy);
+      o.B[15] = SH_C3_6 * x * (xx - 3.0f * yy);
+    }
+  }
+  return o;
+}
+template <int NC>
+__device__ __forceinline__ void sh_color_f(const ShDir<NC>& o, const float* sh, float* col) {
+  float cr = 0.5f, cg = 0.5f, cb = 0.5f;  // no clamp to >= 0 (kernel.cu:652,725)
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { cr += o.B[c] * sh[3 * c]; cg += o.B[c] * sh[3 * c + 1]; cb += o.B[c] * sh[3 * c + 2]; }
+  col[0] = cr; col[1] = cg; col[2] = cb;
+}
+// dcolor[rgb]/ddir[xyz] (dr) -- kernel.cu:751-793
+template <int NC>
+__device__ __forceinline__ void sh_dcolor_ddir(const ShDir<NC>& o, const float* sh, float dr[3][3]) {
+  const float x = o.x, y = o.y, z = o.z;
+  float gx[NC], gy[NC], gz[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) { gx[c] = 0.f; gy[c] = 0.f; gz[c] = 0.f; }
+  if constexpr (NC > 1) { gx[3] = SH_C1_2; gy[1] = SH_C1_0; gz[2] = SH_C1_1; }
+  if constexpr (NC > 4) {
+    gx[4] = SH_C2_0 * y; gx[6] = -SH_C2_2 * 2 * x; gx[7] = SH_C2_3 * z; gx[8] = SH_C2_4 * 2 * x;
+    gy[4] = SH_C2_0 * x; gy[5] = SH_C2_1 * z; gy[6] = -SH_C2_2 * 2 * y; gy[8] = -SH_C2_4 * 2 * y;
+    gz[5] = SH_C2_1 * y; gz[6] = SH_C2_2 * 4 * z; gz[7] = SH_C2_3 * x;
+  }
+  if constexpr (NC > 9) {
+    const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+    gx[9] = 6.0f * SH_C3_0 * xy; gx[10] = SH_C3_1 * yz; gx[11] = -2 * SH_C3_2 * xy;
+    gx[12] = -6.0f * SH_C3_3 * xz; gx[13] = SH_C3_4 * (4.0f * zz - 3.0f * xx - yy);
+    gx[14] = 2 * SH_C3_5 * xz; gx[15] = SH_C3_6 * (3 * xx - 3 * yy);
+    gy[9] = SH_C3_0 * (3.0f * xx - 3.0f * yy); gy[10] = SH_C3_1 * xz;
+    gy[11] = SH_C3_2 * (-xx - 3.0f * yy + 4.0f * zz); gy[12] = -6.0f * SH_C3_3 * yz;
+    gy[13] = SH_C3_4 * (-2 * xy); gy[14] = -2 * SH_C3_5 * yz; gy[15] = -6.0f * SH_C3_6 * xy;
+    gz[10] = SH_C3_1 * xy; gz[11] = 8.0f * SH_C3_2 * yz;
+    gz[12] = SH_C3_3 * (-3.0f * xx - 3.0f * yy + 6.0f * zz); gz[13] = 8.0f * SH_C3_4 * xz;
+    gz[14] = SH_C3_5 * (xx - yy);
+  }
+#pragma unroll
+  for (int ch = 0; ch < 3; ++ch) {
+    float sx = 0, sy = 0, sz = 0;
+#pragma unroll
+    for (int c = 1; c < NC; ++c) { sx += gx[c] * sh[3 * c + ch]; sy += gy[c] * sh[3 * c + ch]; sz += gz[c] * sh[3 * c + ch]; }
+    dr[ch][0] = sx; dr[ch][1] = sy; dr[ch][2] = sz;
+  }
+}
+// ddir/dpw (symmetric 3x3; kernel.cu:738-745) as 6 unique entries
+template <int NC>
+__device__ __forceinline__ void sh_ddir_dpw(const ShDir<NC>& o, float& p00, float& p11, float& p22, float& p01,
+                                            float& p02, float& p12) {
+  const float n3 = o.ninv * o.ninv * o.ninv;
+  p00 = -o.d0 * o.d0 * n3 + o.ninv; p11 = -o.d1 * o.d1 * n3 + o.ninv; p22 = -o.d2 * o.d2 * n3 + o.ninv;
+  p01 = -o.d0 * o.d1 * n3; p02 = -o.d0 * o.d2 * n3; p12 = -o.d1 * o.d2 * n3;
+}
+// dcolor/dpw [3x3] row-major
+template <int NC>
+__device__ __forceinline__ void sh_jac_dpw(const ShDir<NC>& o, const float* sh, float* jp /*9*/) {
+  if constexpr (NC == 1) {
+#pragma unroll
+    for (int j = 0; j < 9; ++j) jp[j] = 0.f;
+  } else {
+    float dr[3][3];
+    sh_dcolor_ddir<NC>(o, sh, dr);
+    float p00, p11, p22, p01, p02, p12;
+    sh_ddir_dpw<NC>(o, p00, p11, p22, p01, p02, p12);
+#pragma unroll
+    for (int ch = 0; ch < 3; ++ch) {
+      jp[3 * ch + 0] = dr[ch][0] * p00 + dr[ch][1] * p01 + dr[ch][2] * p02;
+      jp[3 * ch + 1] = dr[ch][0] * p01 + dr[ch][1] * p11 + dr[ch][2] * p12;
+      jp[3 * ch + 2] = dr[ch][0] * p02 + dr[ch][1] * p12 + dr[ch][2] * p22;
+    }
+  }
+}
+
+template <int K>
+__device__ __forceinline__ void load_sh_row(const float* __restrict__ row, float* sh) {
+  if constexpr (K % 4 == 0) {  // 48- or 192-B rows: dwordx4 loads
+#pragma unroll
+    for (int j = 0; j < K / 4; ++j) {
+      const float4 v = reinterpret_cast<const float4*>(row)[j];
+      sh[4 * j] = v.x; sh[4 * j + 1] = v.y; sh[4 * j + 2] = v.z; sh[4 * j + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) sh[j] = row[j];
+  }
+}
+
+}  // namespace egs

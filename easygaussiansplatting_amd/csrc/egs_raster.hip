@@ -353,7 +353,12 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 
 // 48-byte packed 2D record per Gaussian: one aligned gather (3 x dwordx4)
 // instead of the reference's four (fetch2shared, kernel.cu:13-44).
-//   A = {u.x, u.y, cinv.x, cinv.y}  B = {cinv.z, alpha, col.r, col.g}  C = {col.b, c1, c2, 0}
+//   A = {u.x, u.y, qxx, qxy}   B = {qyy, alpha, col.r, col.g}   C = {col.b, c1, c2, thr}
+// (qxx, qxy, qyy) = -0.5*log2(e) * (cinv.x, 2 cinv.y, cinv.z): the conic pre-scaled so that
+//   power = qxx dx dx + qyy dy dy + qxy dx dy = log2 of exp(-maha/2), no per-pixel scaling.
+// thr = log2(alpha_skip / alpha): alpha' = alpha 2^power >= alpha_skip  <=>  power >= thr, so
+//   the skip test of kernel.cu:246 is made BEFORE the exponential and v_exp_f32 (3x the
+//   cost of a plain VALU op on gfx950) is only issued for blocks that do blend.
 // tile footprint (gsplatcu):   c1 = ex, c2 = ey -- half extents of the axis-aligned box
 //   around u outside of which alpha' < alpha_skip is CERTAIN:  alpha' >= skip  =>
 //   maha <= m* = 2 ln(alpha/skip) and maha >= dx^2 / Sigma_xx, so |dx| <= sqrt(m* Sigma_xx).
@@ -362,6 +367,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 //   result is unchanged.  Slack (x1.01 + 0.05 px) covers float rounding; a non positive-
 //   definite cinv or skip == 0 disables the cull (extent = +inf).
 // pixel-box footprint (forward_cpu): c1 = x0 | x1<<16, c2 = y0 | y1<<16 (gausplat.py:212-215)
+#define EGS_NHL2E (-0.72134752044f)  // -0.5 * log2(e)
 __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int footprint, float alpha_skip,
                                                       const float* __restrict__ us,
                                                       const float* __restrict__ cinv,
@@ -375,6 +381,7 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
   const float c0 = cinv[3 * (size_t)i], c1 = cinv[3 * (size_t)i + 1], c2 = cinv[3 * (size_t)i + 2];
   const float r = colors[3 * (size_t)i], g = colors[3 * (size_t)i + 1], b = colors[3 * (size_t)i + 2];
   const float alpha = alphas[i];
+  const float inf = __int_as_float(0x7f800000);
   float e1, e2;
   if (footprint == 1) {
     int x0, x1, y0, y1;
@@ -382,7 +389,6 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
     e1 = __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16));
     e2 = __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16));
   } else {
-    const float inf = __int_as_float(0x7f800000);
     e1 = inf; e2 = inf;
     const float det = c0 * c2 - c1 * c1;
     // (det must not be the result of catastrophic cancellation: eigenvalue ratio < 1e4)
@@ -398,9 +404,13 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
     }
     if (!(e1 == e1) || !(e2 == e2)) { e1 = inf; e2 = inf; }  // NaN guard
   }
-  rec[3 * (size_t)i + 0] = make_float4(ux, uy, c0, c1);
-  rec[3 * (size_t)i + 1] = make_float4(c2, alpha, r, g);
-  rec[3 * (size_t)i + 2] = make_float4(b, e1, e2, 0.f);
+  // skip threshold in the exponent domain
+  float thr;
+  if (alpha_skip > 0.f) thr = (alpha >= alpha_skip) ? log2f(alpha_skip / alpha) : inf;  // alpha < skip never blends
+  else thr = (alpha < 0.f) ? inf : -inf;  // !(alpha' < 0)
+  rec[3 * (size_t)i + 0] = make_float4(ux, uy, EGS_NHL2E * c0, (2.f * EGS_NHL2E) * c1);
+  rec[3 * (size_t)i + 1] = make_float4(EGS_NHL2E * c2, alpha, r, g);
+  rec[3 * (size_t)i + 2] = make_float4(b, e1, e2, thr);
 }
 
 // ============================================================================
@@ -410,6 +420,7 @@ struct DrawParams {
   int W, H, gx, gy, T;
   float alpha_skip, tau_stop;
   int maha_floor, alpha_clamp;
+  int dbg;       // experiment knob (EGS_DBG), 0 in production
   int map_mode;  // 0: tile = block; 1: contiguous band per XCD; 2: tile rows interleaved over XCDs
 };
 
@@ -439,10 +450,17 @@ static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(
 // (k = 0..3, block (k&1, k>>1)); lane l owns pixel (l&7, l>>3) of each block.  Per
 // list entry a block is skipped outright when the entry's certain-miss box (pack
 // kernel) or pixel box does not reach it -- a wave-uniform branch.  The quadratic
-// form is evaluated separably: cxx[bx] + cyy[by] + cxy[bx]*dy[by].
+// form is evaluated separably: cxx[bx] + cyy[by] + cxy[bx]*dy[by].  (Measured on gfx950,
+// tools/ubench_valu.hip: v_pk_*_f32 costs exactly 2x a plain fp32 op, v_exp/v_rcp 3x,
+// v_max/v_cmp->SGPR 1.6x -- so the kernels minimise instruction count, not pack.)
 // A pixel that is finished (tau < tau_stop) or outside the image carries the
 // sign bit in `cont`, so "still live" is one v_cmp_ge_i32 and "whole tile
 // finished" is the sign of the AND of the four counters.
+// min(x, hi) as ONE v_med3_f32 (fminf() costs a canonicalising v_max + v_min in IEEE mode)
+__device__ __forceinline__ float min_hi(float x, float hi) {
+  return __builtin_amdgcn_fmed3f(x, hi, -__builtin_inff());
+}
+
 template <bool BOX, bool FLOOR, bool CLAMP>
 __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
                                              const int32_t* __restrict__ gsid,
@@ -456,6 +474,7 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
   if (n <= 0) return;  // empty tile: outputs stay 0 (final_tau = 0, as the reference leaves it)
   const int lane = threadIdx.x;
   const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
+  // pixel k = 2*by + bx of this lane: (tx0 + (lane&7) + 8 bx, ty0 + (lane>>3) + 8 by)
   const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
   const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
@@ -470,7 +489,7 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
     cont[k] = ((pxb[k & 1] < p.W) && (pyb[k >> 1] < p.H)) ? 0 : DONE;
     tau[k] = 1.f; cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f;
   }
-  const float skip = p.alpha_skip, stop = p.tau_stop;
+  const float stop = p.tau_stop;
   for (int base = 0; base < n; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     if (base + lane < n) {
@@ -506,23 +525,23 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
 #pragma unroll
       for (int b = 0; b < 2; ++b) {
         const float dx = A.x - fpx[b];
-        cxx[b] = A.z * dx * dx;   // cinv.x dx dx
-        cxy[b] = 2.f * A.w * dx;  // 2 cinv.y dx
+        cxx[b] = A.z * dx * dx;  // qxx dx dx
+        cxy[b] = A.w * dx;       // qxy dx
         dy[b] = A.y - fpy[b];
-        cyy[b] = B.x * dy[b] * dy[b];  // cinv.z dy dy
+        cyy[b] = B.x * dy[b] * dy[b];  // qyy dy dy
       }
       const int idx = base + j + 1;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int bx = k & 1, by = k >> 1;
         if (okx[bx] && oky[by]) {  // wave-uniform: the whole 8x8 block is in reach
-          float maha = cxx[bx] + cyy[by] + cxy[bx] * dy[by];  // F.5.1 (common.cuh:85-88)
-          if (FLOOR) maha = fmaxf(0.f, maha);
-          float ap = B.y * __builtin_amdgcn_exp2f(maha * -0.72134752044f);  // alpha exp(-maha/2)
-          if (CLAMP) ap = fminf(0.99f, ap);
-          bool hit = (cont[k] >= 0) && !(ap < skip);
+          // log2 of exp(-maha/2): F.5.1 (common.cuh:85-88) with the pre-scaled conic
+          const float pw = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
+          bool hit = (cont[k] >= 0) && (pw >= C.w);  // alpha' >= alpha_skip  (kernel.cu:246)
           if (BOX) hit = hit && inx[bx] && iny[by];
           if (hit) {
+            float ap = B.y * __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
+            if (CLAMP) ap = min_hi(ap, 0.99f);
             const float w = tau[k] * ap;  // F.5
             cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
             const float t = tau[k] * (1.f - ap);  // F.5.2
@@ -592,22 +611,26 @@ __device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3)
 }
 
 // Per-tile back-to-front gradient pass.  One wave64 per 16x16 tile walked as four 8x8
-// pixel blocks exactly like k_draw (same block cull).  Entries are visited in descending
-// list order in groups of four; the 9 gradient partials of each entry (dalpha,
-// dcolor[3], du[2], dcinv[3]) are summed in-lane over the 4 pixels, reduced across the
-// wave 4 entries at a time (reduce4), and one lane per entry issues the 9 atomics: one
-// atomic set per (tile, Gaussian).
+// pixel blocks exactly like k_draw (same block cull, same exponent-domain skip test).
+// Entries are visited in descending list order in groups of four.  Per entry each lane
+// sums over its 4 pixels nine partials:
+//   S0 = sum dL/dalpha' g                      -> dalpha          (B.5.1a)
+//   S1..S3 = sum dL/dgamma_c alpha' tau        -> dcolor          (B.5b)
+//   with w = dL/dalpha' alpha':  M1x = sum w dx, M1y = sum w dy,
+//   M2xx = sum w dx dx, M2xy = sum w dx dy, M2yy = sum w dy dy    (B.5.2b / B.5.2c as moments:
+//   du = -cinv (M1x, M1y), dcinv = -(M2xx/2, M2xy, M2yy/2), applied once per entry)
+// The 9 partials are reduced across the wave 4 entries at a time (reduce4) and one lane
+// per entry issues the 9 atomics: one atomic set per (tile, Gaussian).
 template <bool BOX, bool FLOOR, bool CLAMP>
 __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __restrict__ ranges,
                                                  const int32_t* __restrict__ gsid,
                                                  const float4* __restrict__ rec,
+                                                 const float* __restrict__ cinv,
                                                  const float* __restrict__ final_tau,
                                                  const int32_t* __restrict__ contrib,
-                                                 const float* __restrict__ dLdg, float* __restrict__ dus,
-                                                 float* __restrict__ dcinv, float* __restrict__ dalpha,
-                                                 float* __restrict__ dcolor) {
-  __shared__ float4 sA[64], sB[64], sC[64];
-  __shared__ int sG[64];
+                                                 const float* __restrict__ dLdg,
+                                                 float* __restrict__ gpack) {
+  __shared__ float4 sA[64], sB[64], sC[64], sD[64];  // sD = {cinv.x, cinv.y, cinv.z, gsid}
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -642,21 +665,22 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
   for (int d = 32; d >= 1; d >>= 1) maxcont = max(maxcont, __shfl_xor(maxcont, d, 64));
   maxcont = min(maxcont, n);
   if (maxcont <= 0) return;
-  const float skip = p.alpha_skip;
-  constexpr float NHL2E = -0.72134752044f;  // -0.5 * log2(e)
 
   for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
     __syncthreads();
     const int idx = c * 64 + lane;
     if (idx < n) {
       const int g = gsid[r0 + idx];
-      sG[lane] = g;
       sA[lane] = rec[3 * (size_t)g];
       sB[lane] = rec[3 * (size_t)g + 1];
       sC[lane] = rec[3 * (size_t)g + 2];
+      sD[lane] = make_float4(cinv[3 * (size_t)g], cinv[3 * (size_t)g + 1], cinv[3 * (size_t)g + 2],
+                             __int_as_float(g));
     }
     __syncthreads();
-    const int jhi = min(63, maxcont - 1 - c * 64);
+    // Groups of four entries aligned to 4 (jj = 4m+3): every j = jj-e is >= 0.  Entries above
+    // maxcont-1 in the top group fail `i < cont[k]` in every lane, so they are inert.
+    const int jhi = min(63, maxcont - 1 - c * 64) | 3;
     for (int jj = jhi; jj >= 0; jj -= 4) {  // entries jj, jj-1, jj-2, jj-3 (descending list order)
       float acc[4][9];
       bool any = false;
@@ -665,7 +689,6 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
 #pragma unroll
         for (int q = 0; q < 9; ++q) acc[e][q] = 0.f;
         const int j = jj - e;
-        if (j < 0) continue;  // wave-uniform
         const int i = c * 64 + j;  // forward index of this entry in the tile list
         const float4 A = sA[j], B = sB[j], C = sC[j];
         bool okx[2], oky[2], inx[2] = {true, true}, iny[2] = {true, true};
@@ -692,7 +715,7 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         for (int b = 0; b < 2; ++b) {
           dx[b] = A.x - fpx[b];
           cxx[b] = A.z * dx[b] * dx[b];
-          cxy[b] = 2.f * A.w * dx[b];
+          cxy[b] = A.w * dx[b];
           dy[b] = A.y - fpy[b];
           cyy[b] = B.x * dy[b] * dy[b];
         }
@@ -700,33 +723,30 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         for (int k = 0; k < 4; ++k) {
           const int bx = k & 1, by = k >> 1;
           if (!(okx[bx] && oky[by])) continue;  // wave-uniform block cull
-          float maha = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
-          if (FLOOR) maha = fmaxf(0.f, maha);
-          const float g = __builtin_amdgcn_exp2f(maha * NHL2E);
-          float ap = B.y * g;
-          if (CLAMP) ap = fminf(0.99f, ap);
-          bool hit = (i < cont[k]) && !(ap < skip);  // kernel.cu:899,913
+          const float pw = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
+          bool hit = (i < cont[k]) && (pw >= C.w);  // kernel.cu:899,913
           if (BOX) hit = hit && inx[bx] && iny[by];
           if (hit) {
+            const float g = __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
+            float ap = B.y * g;
+            if (CLAMP) ap = min_hi(ap, 0.99f);
             const float tk = tau[k] * __builtin_amdgcn_rcpf(1.f - ap);  // undo F.5.2
             tau[k] = tk;
             const float dr = B.z - qr[k], dg = B.w - qg[k], db = C.x - qb[k];
             const float dl_dap = tk * (lr[k] * dr + lg[k] * dg + lb[k] * db);  // B.5a
-            acc[e][0] += dl_dap * g;  // B.5.1a: dalpha'/dalpha = g (also where the clamp binds)
-            const float wgt = ap * tk;  // B.5b
+            acc[e][0] += dl_dap * g;  // dalpha'/dalpha = g, also where the clamp binds (kernel.cu:921)
+            const float wgt = ap * tk;
             acc[e][1] += lr[k] * wgt; acc[e][2] += lg[k] * wgt; acc[e][3] += lb[k] * wgt;
             const float w = dl_dap * ap;
-            acc[e][4] -= w * (A.z * dx[bx] + A.w * dy[by]);  // B.5.2b
-            acc[e][5] -= w * (A.w * dx[bx] + B.x * dy[by]);
-            acc[e][6] -= w * (0.5f * dx[bx] * dx[bx]);       // B.5.2c
-            acc[e][7] -= w * (dx[bx] * dy[by]);
-            acc[e][8] -= w * (0.5f * dy[by] * dy[by]);
+            const float wx = w * dx[bx], wy = w * dy[by];
+            acc[e][4] += wx; acc[e][5] += wy;
+            acc[e][6] += wx * dx[bx]; acc[e][7] += wx * dy[by]; acc[e][8] += wy * dy[by];
             qr[k] += ap * dr; qg[k] += ap * dg; qb[k] += ap * db;  // gamma_cur2last
             any = true;
           }
         }
       }
-      if (__any(any)) {  // wave-uniform
+      if (__any(any) && !(p.dbg & 2)) {  // wave-uniform
         float tot[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) tot[q] = reduce4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
@@ -734,21 +754,44 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         const int row = lane >> 4;
         const int e = ((row & 1) << 1) | (row >> 1);
         const int j = jj - e;
-        if ((lane & 15) == 0 && j >= 0 && (tot[0] != 0.f || tot[1] != 0.f || tot[2] != 0.f || tot[3] != 0.f)) {
-          const size_t g = (size_t)sG[j];  // one atomic set per (tile, Gaussian)
-          unsafeAtomicAdd(dalpha + g, tot[0]);
-          unsafeAtomicAdd(dcolor + 3 * g, tot[1]);
-          unsafeAtomicAdd(dcolor + 3 * g + 1, tot[2]);
-          unsafeAtomicAdd(dcolor + 3 * g + 2, tot[3]);
-          unsafeAtomicAdd(dus + 2 * g, tot[4]);
-          unsafeAtomicAdd(dus + 2 * g + 1, tot[5]);
-          unsafeAtomicAdd(dcinv + 3 * g, tot[6]);
-          unsafeAtomicAdd(dcinv + 3 * g + 1, tot[7]);
-          unsafeAtomicAdd(dcinv + 3 * g + 2, tot[8]);
-        }
+        // entries past the end of the list (top group of the last chunk) have stale LDS slots:
+        // they are inert (all partials exactly 0) and must not touch memory
+        const bool rowact = (c * 64 + j < n) &&
+                            (tot[0] != 0.f || tot[1] != 0.f || tot[2] != 0.f || tot[3] != 0.f || tot[4] != 0.f ||
+                             tot[5] != 0.f || tot[6] != 0.f || tot[7] != 0.f || tot[8] != 0.f);
+        const float4 D = sD[j];
+        // B.5.2b / B.5.2c from the moments, then lane q (0..8) of each row takes quantity q so
+        // that the 9 atomics of an entry are ONE instruction on ONE 48-byte gradient record
+        // (packed order: dalpha, dcolor[3], du[2], dcinv[3]; 36 lanes active per group).
+        const float gux = -(D.x * tot[4] + D.y * tot[5]), guy = -(D.y * tot[4] + D.z * tot[5]);
+        const int q = lane & 15;
+        float v = tot[0];
+        v = (q == 1) ? tot[1] : v;
+        v = (q == 2) ? tot[2] : v;
+        v = (q == 3) ? tot[3] : v;
+        v = (q == 4) ? gux : v;
+        v = (q == 5) ? guy : v;
+        v = (q == 6) ? -0.5f * tot[6] : v;
+        v = (q == 7) ? -tot[7] : v;
+        v = (q == 8) ? -0.5f * tot[8] : v;
+        if (!(p.dbg & 1) && rowact && q < 9 && v != 0.f)
+          unsafeAtomicAdd(gpack + 12 * (size_t)__float_as_int(D.w) + q, v);
       }
     }
   }
+}
+
+// packed [N][12] gradient records -> the four output tensors of splatB
+__global__ __launch_bounds__(256) void k_unpack_grads(int n, const float4* __restrict__ gpack,
+                                                      float* __restrict__ dus, float* __restrict__ dcinv,
+                                                      float* __restrict__ dalpha, float* __restrict__ dcolor) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float4 a = gpack[3 * (size_t)i], b = gpack[3 * (size_t)i + 1], c = gpack[3 * (size_t)i + 2];
+  dalpha[i] = a.x;
+  dcolor[3 * (size_t)i] = a.y; dcolor[3 * (size_t)i + 1] = a.z; dcolor[3 * (size_t)i + 2] = a.w;
+  dus[2 * (size_t)i] = b.x; dus[2 * (size_t)i + 1] = b.y;
+  dcinv[3 * (size_t)i] = b.z; dcinv[3 * (size_t)i + 1] = b.w; dcinv[3 * (size_t)i + 2] = c.x;
 }
 
 // ============================================================================
@@ -813,6 +856,8 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol) {
     return e ? atoi(e) : 2;
   }();
   p.map_mode = mode;
+  static const int dbg = [] { const char* e = getenv("EGS_DBG"); return e ? atoi(e) : 0; }();
+  p.dbg = dbg;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
   return p;
@@ -949,35 +994,30 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   return 0;
 }
 
-extern "C" size_t egs_splat_bwd_ws_bytes(int n) { return align_up((size_t)(n > 0 ? n : 1) * 48, 256) + 256; }
+extern "C" size_t egs_splat_bwd_ws_bytes(int n) { return 2 * align_up((size_t)(n > 0 ? n : 1) * 48, 256) + 256; }
 
-extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, const float* us,
-                             const float* cinv2ds, const float* alphas, const float* colors,
-                             const int32_t* areas, const EgsPolicy* pol, const int32_t* contrib,
-                             const float* final_tau, const int32_t* patch_range_per_tile,
-                             const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                             float* dloss_dus, float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors,
-                             void* stream) {
-  EGS_CHECK_ARG(n >= 0 && patches >= 0 && width > 0 && height > 0 && pol);
-  if (n == 0 || patches == 0) return 0;
-  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && contrib && final_tau && patch_range_per_tile &&
-                gsid_per_patch && dloss_dgammas && ws && dloss_dus && dloss_dcinv2ds && dloss_dalphas &&
-                dloss_dcolors);
-  EGS_CHECK_ARG(pol->footprint == 0 || areas);
-  if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
-    set_error(EGS_ERR_WORKSPACE, "splat_bwd workspace too small", __FILE__, __LINE__);
-    return EGS_ERR_WORKSPACE;
-  }
+namespace egs {
+int splat_bwd_packed(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
+                     const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
+                     const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                     const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                     float** gpack_out, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   float4* rec = (float4*)ws;
+  float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));  // [N][12] packed gradient records
+  *gpack_out = gpack;
+  (void)ws_bytes;
+  EGS_HIP(hipMemsetAsync(gpack, 0, (size_t)n * 48, s));
+  if (patches == 0) return 0;
+  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && contrib && final_tau && patch_range_per_tile &&
+                gsid_per_patch && dloss_dgammas);
+  EGS_CHECK_ARG(pol->footprint == 0 || areas);
   const DrawParams dp = make_draw_params(width, height, pol);
   EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
-             pol->alpha_skip, us,
-                     cinv2ds, alphas, colors, areas, rec);
+             pol->alpha_skip, us, cinv2ds, alphas, colors, areas, rec);
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile, \
-             gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, dloss_dus, dloss_dcinv2ds, dloss_dalphas, \
-             dloss_dcolors)
+             gsid_per_patch, rec, cinv2ds, final_tau, contrib, dloss_dgammas, gpack)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {
     case 0: EGS_DRAWB(false, false, false); break;
@@ -990,6 +1030,32 @@ extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, cons
     default: EGS_DRAWB(true, true, true); break;
   }
 #undef EGS_DRAWB
+  EGS_LAUNCH_OK();
+  return 0;
+}
+}  // namespace egs
+
+extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, const float* us,
+                             const float* cinv2ds, const float* alphas, const float* colors,
+                             const int32_t* areas, const EgsPolicy* pol, const int32_t* contrib,
+                             const float* final_tau, const int32_t* patch_range_per_tile,
+                             const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                             float* dloss_dus, float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors,
+                             void* stream) {
+  EGS_CHECK_ARG(n >= 0 && patches >= 0 && width > 0 && height > 0 && pol);
+  if (n == 0) return 0;
+  EGS_CHECK_ARG(ws && dloss_dus && dloss_dcinv2ds && dloss_dalphas && dloss_dcolors);
+  if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
+    set_error(EGS_ERR_WORKSPACE, "splat_bwd workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  float* gpack = nullptr;
+  int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
+                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,
+             dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
   EGS_LAUNCH_OK();
   return 0;
 }

@@ -3,15 +3,21 @@
 
 Identical inputs ``(pws, shs, alphas[N,1], scales, rots, us, cam)``, outputs
 ``(image[3,H,W], depths > 0.2)`` and gradient tuple order (gsmodel.py:87-93).
-The forward is the same six op calls with ``calc_J=True``; the backward is
-``splatB`` followed by the chain rule -- by default the fused HIP kernel
-(``gsplatcu.chain_rule``), or, with ``GSFunction.use_fused_chain = False``, the
-nine batched matmuls exactly as the reference spells them.
+``GSFunction.mode`` selects how the same function is evaluated:
+
+* ``"fused"`` (default) -- easygaussiansplatting_amd.fused: one preprocess kernel +
+  splat forward; splatB's draw pass + one Jacobian-free chain-rule kernel backward
+  (three C-ABI calls per step, no Jacobians in HBM);
+* ``"ops"``  -- the reference's structure: six op calls with ``calc_J=True``, 17
+  tensors saved, ``splatB`` + the fused chain-rule kernel over the stored Jacobians;
+* ``"ops_bmm"`` -- as ``"ops"`` but the chain rule as the nine batched matmuls
+  exactly as the reference spells them (gsmodel.py:71-85).
 """
 from __future__ import annotations
 
 import torch
 
+from . import fused as _fused
 from . import gsplatcu as gsc
 
 
@@ -34,10 +40,18 @@ class Camera:
 
 
 class GSFunction(torch.autograd.Function):
-    use_fused_chain = True
+    mode = "fused"
 
     @staticmethod
     def forward(ctx, pws, shs, alphas, scales, rots, us, cam):
+        ctx.mode = GSFunction.mode
+        if ctx.mode == "fused":
+            image, mask, state = _fused.forward(pws, shs, alphas, scales, rots, cam)
+            ctx.cam = cam
+            ctx.state = state
+            ctx.save_for_backward(pws, shs, alphas, scales, rots)
+            ctx.mark_non_differentiable(mask)
+            return image, mask
         # forward.md steps 1-5 == gsmodel.py:21-39
         us, pcs, depths, du_dpcs = gsc.project(pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, True)
         cov3ds, dcov3d_drots, dcov3d_dscales = gsc.computeCov3D(rots, scales, depths, True)
@@ -58,6 +72,12 @@ class GSFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss_dgammas, _):
         cam = ctx.cam
+        if ctx.mode == "fused":
+            pws, shs, alphas, scales, rots = ctx.saved_tensors
+            dpws, dshs, dalphas, dscales, drots, dus = _fused.backward(
+                pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous())
+            ctx.state = None
+            return dpws, dshs, dalphas, dscales, drots, dus, None
         (us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
          dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs,
          dcolor_dpws) = ctx.saved_tensors
@@ -65,7 +85,7 @@ class GSFunction(torch.autograd.Function):
             cam.height, cam.width, us, cinv2ds, alphas, depths, colors, contrib, final_tau,
             patch_range_per_tile, gsid_per_patch, dloss_dgammas.contiguous())
         n = us.shape[0]
-        if GSFunction.use_fused_chain:
+        if ctx.mode == "ops":
             dloss_dpws, dloss_dshs, dloss_dscales, dloss_drots = gsc.chain_rule(
                 dloss_dus, dloss_dcinv2ds, dloss_dcolors, cam.Rcw, dcinv2d_dcov2ds, dcov2d_dcov3ds,
                 dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws)

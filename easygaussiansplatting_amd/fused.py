@@ -1,0 +1,112 @@
+"""Fused training path: what the reference's ``GSFunction``
+(gsplat/gsmodel.py:6-93) computes, in three C-ABI calls per step and without the
+436 B/Gaussian of Jacobians ever crossing HBM.
+
+* ``forward``  = project + computeCov3D + computeCov2D + sh2Color + inverseCov2D
+  in ONE kernel, then ``splat`` (bin -> 4-byte read-back -> draw);
+* ``backward`` = ``splatB``'s draw pass into packed per-Gaussian gradient records
+  + ONE kernel that re-derives the Jacobians in registers and applies
+  backward.md eq (3)(4)(5)(7) (gsmodel.py:71-85).
+
+Results equal the seven-op path (same device functions, csrc/egs_gaussian_math.h);
+``tests/test_gpu_parity.py`` checks fused == unfused == oracle.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib
+from .gsplatcu import _alphas, _chk, _lib_on, _pol, _ptr, _stream, _tiles
+
+
+class FusedState:
+    """Tensors the backward pass needs (all produced by ``forward``)."""
+    __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "contrib", "final_tau", "ranges", "gsid",
+                 "width", "height")
+
+
+def forward(pws, shs, alphas, scales, rots, cam):
+    """-> (image[3,H,W], mask[N] bool, state).  ``cam`` carries Rcw/tcw/twc device
+    tensors and fx, fy, cx, cy, width, height (reference gausplat_dataset.py:14-26)."""
+    pws = _chk(pws, "pws", torch.float32, (None, 3))
+    n = pws.shape[0]
+    shs = _chk(shs, "shs", torch.float32, (n, None))
+    K = shs.shape[1]
+    if K not in (3, 12, 27, 48):
+        raise ValueError("shs must have 3, 12, 27 or 48 columns, got %d" % K)
+    alphas = _alphas(alphas, n)
+    scales = _chk(scales, "scales", torch.float32, (n, 3))
+    rots = _chk(rots, "rots", torch.float32, (n, 4))
+    Rcw = _chk(cam.Rcw, "cam.Rcw", torch.float32, (3, 3))
+    tcw = _chk(cam.tcw, "cam.tcw", torch.float32, (3,))
+    twc = _chk(cam.twc, "cam.twc", torch.float32, (3,))
+    W, H = int(cam.width), int(cam.height)
+    lib = _lib_on(pws)
+    dev = pws.device
+    pol = C.byref(_pol())
+    st = _stream()
+    f32, i32 = torch.float32, torch.int32
+    S = FusedState()
+    S.width, S.height = W, H
+    S.us = torch.empty((n, 2), dtype=f32, device=dev)
+    S.depths = torch.empty((n,), dtype=f32, device=dev)
+    S.cinv2ds = torch.empty((n, 3), dtype=f32, device=dev)
+    S.colors = torch.empty((n, 3), dtype=f32, device=dev)
+    S.areas = torch.empty((n, 2), dtype=i32, device=dev)
+    ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
+    ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
+    total = torch.empty(1, dtype=i32, device=dev)
+    _lib.check(lib.egs_fused_forward(n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(Rcw), _ptr(tcw),
+                                     _ptr(twc), float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), W, H,
+                                     pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds), _ptr(S.colors),
+                                     _ptr(S.areas), _ptr(ws_bin), ws_bin_bytes, _ptr(total), st))
+    image = torch.zeros((3, H, W), dtype=f32, device=dev)       # empty tiles are not written (kernel.cu:182)
+    S.contrib = torch.zeros((H, W), dtype=i32, device=dev)
+    S.final_tau = torch.zeros((H, W), dtype=f32, device=dev)
+    S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
+    patches = int(total.item()) & 0xFFFFFFFF                     # the one 4-byte read-back (gausplat.cu:67)
+    if patches >= 2**31:
+        raise RuntimeError("splat: %d tile patches overflow int32 indexing" % patches)
+    S.gsid = torch.empty(patches, dtype=i32, device=dev)
+    ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, W, H)
+    ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.egs_splat_draw(n, patches, W, H, _ptr(S.us), _ptr(S.cinv2ds), _ptr(alphas), _ptr(S.colors),
+                                  _ptr(S.areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes, _ptr(image),
+                                  _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), st))
+    mask = S.depths > 0.2                                        # gsmodel.py:50
+    return image, mask, S
+
+
+def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas):
+    """-> (dloss_dpws[N,3], dloss_dshs[N,K], dloss_dalphas[N,1], dloss_dscales[N,3],
+           dloss_drots[N,4], dloss_dus[N,2])  -- the gradient tuple of gsmodel.py:87-93."""
+    pws = _chk(pws, "pws", torch.float32, (None, 3))
+    n = pws.shape[0]
+    shs = _chk(shs, "shs", torch.float32, (n, None))
+    K = shs.shape[1]
+    alphas = _alphas(alphas, n)
+    scales = _chk(scales, "scales", torch.float32, (n, 3))
+    rots = _chk(rots, "rots", torch.float32, (n, 4))
+    W, H = S.width, S.height
+    dl = _chk(dloss_dgammas, "dloss_dgammas", torch.float32, (3, H, W))
+    lib = _lib_on(pws)
+    dev = pws.device
+    f32 = torch.float32
+    dpws = torch.empty((n, 3), dtype=f32, device=dev)
+    dshs = torch.empty((n, K), dtype=f32, device=dev)
+    dalphas = torch.empty((n, 1), dtype=f32, device=dev)
+    dscales = torch.empty((n, 3), dtype=f32, device=dev)
+    drots = torch.empty((n, 4), dtype=f32, device=dev)
+    dus = torch.empty((n, 2), dtype=f32, device=dev)
+    ws_bytes = lib.egs_fused_backward_ws_bytes(n)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    _lib.check(lib.egs_fused_backward(n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs),
+                                      _ptr(alphas), _ptr(cam.Rcw), _ptr(cam.tcw), _ptr(cam.twc), float(cam.fx),
+                                      float(cam.fy), float(cam.cx), float(cam.cy), C.byref(_pol()), _ptr(S.us),
+                                      _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.depths),
+                                      _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), _ptr(dl),
+                                      _ptr(ws), ws_bytes, _ptr(dpws), _ptr(dshs), _ptr(dalphas), _ptr(dscales),
+                                      _ptr(drots), _ptr(dus), _stream()))
+    return dpws, dshs, dalphas, dscales, drots, dus

@@ -163,6 +163,32 @@ int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss
                    const float* dcolor_dpws, float* dloss_dpws, float* dloss_dshs, float* dloss_dscales,
                    float* dloss_drots, void* stream);
 
+/* ---- fused training path -------------------------------------
+ * What GSFunction.forward / .backward (gsplat/gsmodel.py:6-93) need, without the
+ * 436 B/Gaussian of Jacobians crossing HBM:
+ *   egs_fused_forward   = project + computeCov3D + computeCov2D + sh2Color + inverseCov2D in ONE
+ *                         kernel, followed by egs_splat_bin (then read *total_patches and call
+ *                         egs_splat_draw as for `splat`);
+ *   egs_fused_backward  = splatB's draw pass into packed gradient records + ONE kernel that
+ *                         re-derives the Jacobians in registers and applies backward.md
+ *                         eq (3)(4)(5)(7) (gsmodel.py:71-85).
+ * `depths`/`areas` are the arrays egs_fused_forward produced (incl. the in-place culling). */
+int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
+                      const float* shs, const float* Rcw, const float* tcw, const float* twc, float fx,
+                      float fy, float cx, float cy, int width, int height, const EgsPolicy* pol, float* us,
+                      float* depths, float* cinv2ds, float* colors, int32_t* areas, void* ws_bin,
+                      size_t ws_bin_bytes, uint32_t* total_patches, void* stream);
+size_t egs_fused_backward_ws_bytes(int n);
+int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
+                       const float* rots, const float* scales, const float* shs, const float* alphas,
+                       const float* Rcw, const float* tcw, const float* twc, float fx, float fy, float cx,
+                       float cy, const EgsPolicy* pol, const float* us, const float* cinv2ds,
+                       const float* colors, const int32_t* areas, const float* depths,
+                       const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                       const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                       float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
+                       float* dloss_drots, float* dloss_dus, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream ---------------
  * bench.py's `roofline` leg: when enabled, every kernel launch of this library
  * is bracketed by hipEventRecord on the stream it is launched on.

@@ -385,3 +385,63 @@ def test_non_default_stream_and_determinism(gsc):
     s.synchronize()
     for a, b in zip(ref, out):
         assert torch.equal(a, b)            # forward is bit-deterministic
+
+
+# --------------------------------------------------------------------------- autograd boundary (GSFunction)
+def _oracle_param_grads(sc, cam, dl):
+    P = O.POLICY_G
+    us, pcs, depths, du = O.project(sc.pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P, True)
+    c3, dq, ds = O.compute_cov3d(sc.rots, sc.scales, depths, P, True)
+    c2, d3, dpc = O.compute_cov2d(c3, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, P, True)
+    col, dsh, dpw = O.sh2color(sc.shs, sc.pws, cam.twc, True)
+    ci, areas, dci = O.inverse_cov2d(c2, depths, P, True)
+    img, cont, tau, ranges, gsid = O.splat(cam.height, cam.width, us, ci, sc.alphas, depths, col, areas, P)
+    dus, dcinv, dal, dcol = O.draw_backward(cam.width, cam.height, ranges, gsid, us, ci, sc.alphas, col, cont, tau,
+                                            dl, None, P)
+    J = dict(dcinv2d_dcov2ds=dci, dcov2d_dcov3ds=d3, dcov3d_drots=dq, dcov3d_dscales=ds, dcolor_dshs=dsh,
+             du_dpcs=du, dcov2d_dpcs=dpc, dcolor_dpws=dpw)
+    g = O.chain_rule(dus, dcinv, dal, dcol, cam.Rcw, J)
+    return img, depths > 0.2, dict(pws=g["dpws"], shs=g["dshs"], alphas=g["dalphas"][:, None], scales=g["dscales"],
+                                   rots=g["drots"], us=dus)
+
+
+@pytest.mark.parametrize("K", [48, 3])
+def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
+    """GSFunction counterpart (gsmodel.py:6-93): identical inputs/outputs/gradient
+    order; the fused path, the 7-op path (+HIP chain rule) and the 7-op path with the
+    reference's bmm chain agree, and match the oracle's parameter gradients
+    (backward_cpu.py:476-482) at 1e-4."""
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    gsc.set_policy("gsplatcu")
+    sc = S.small_scene(2500, 112, 80, K, seed=13)
+    sc.pws[:40, 2] = -9.0                      # some Gaussians behind the camera (culled)
+    cam = Camera.from_scene(sc.cam)
+    dl = S.normal(3, 9, (3, sc.cam.height, sc.cam.width)).astype(np.float32) / (3 * sc.cam.height * sc.cam.width)
+    o_img, o_mask, o_g = _oracle_param_grads(sc, sc.cam, dl.astype(np.float64))
+    results = {}
+    for mode in ("fused", "ops", "ops_bmm"):
+        GSFunction.mode = mode
+        P = dict(pws=dev(sc.pws), shs=dev(sc.shs), alphas=dev(sc.alphas).reshape(-1, 1), scales=dev(sc.scales),
+                 rots=dev(sc.rots))
+        for p in P.values():
+            p.requires_grad_(True)
+        us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+        image, mask = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+        assert image.shape == (3, sc.cam.height, sc.cam.width) and mask.dtype == torch.bool
+        image.backward(dev(dl))
+        results[mode] = (host(image), host(mask), {k: host(v.grad) for k, v in P.items()} | {"us": host(us0.grad)})
+    GSFunction.mode = "fused"
+    img_f, mask_f, g_f = results["fused"]
+    assert np.array_equal(mask_f, o_mask)
+    assert np.abs(img_f - o_img).max() < 1e-4
+    for mode in ("ops", "ops_bmm"):
+        img, mask, g = results[mode]
+        # same device functions; only FMA contraction may differ between the fused and staged kernels
+        assert np.abs(img - img_f).max() < 2e-6 and np.array_equal(mask, mask_f)
+        for k in g_f:
+            assert g[k].shape == g_f[k].shape
+            assert close(g[k], g_f[k], 2e-5), (mode, k)                     # atomics order + fma contraction only
+    for k in ("pws", "shs", "alphas", "scales", "rots", "us"):
+        assert g_f[k].shape == (sc.n,) + o_g[k].shape[1:]
+        assert close(g_f[k], o_g[k], 2e-4), (k, np.abs(g_f[k] - o_g[k]).max(), np.abs(o_g[k]).max())
+    assert not g_f["pws"][:40].any() and not g_f["shs"][:40].any()          # culled Gaussians get zero gradients
