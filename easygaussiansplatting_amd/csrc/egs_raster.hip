@@ -456,6 +456,32 @@ static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(
 // A pixel that is finished (tau < tau_stop) or outside the image carries the
 // sign bit in `cont`, so "still live" is one v_cmp_ge_i32 and "whole tile
 // finished" is the sign of the AND of the four counters.
+// 4-bit reach mask of one list entry over the four 8x8 blocks of a tile (bit k = block
+// (k&1, k>>1)).  Computed ONCE per entry by the lane that stages it (64 entries in
+// parallel) instead of by all 64 lanes of the blend loop.
+template <bool BOX>
+__device__ __forceinline__ int reach_mask(const float4& A, const float4& C, int tx0, int ty0) {
+  bool okx[2], oky[2];
+  if (BOX) {  // overlap of the pixel box (gausplat.py:212-215) with the block
+    const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+    const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      okx[b] = (x0 < tx0 + 8 * b + 8) && (x1 > tx0 + 8 * b);
+      oky[b] = (y0 < ty0 + 8 * b + 8) && (y1 > ty0 + 8 * b);
+    }
+  } else {    // certain-miss box (ex, ey) of the pack kernel vs the block (half size 3.5 px)
+    const float rx = C.y + 3.5f, ry = C.z + 3.5f;
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      okx[b] = fabsf(A.x - ((float)tx0 + 3.5f + 8.f * b)) <= rx;
+      oky[b] = fabsf(A.y - ((float)ty0 + 3.5f + 8.f * b)) <= ry;
+    }
+  }
+  return (int)(okx[0] && oky[0]) | ((int)(okx[1] && oky[0]) << 1) | ((int)(okx[0] && oky[1]) << 2) |
+         ((int)(okx[1] && oky[1]) << 3);
+}
+
 // min(x, hi) as ONE v_med3_f32 (fminf() costs a canonicalising v_max + v_min in IEEE mode)
 __device__ __forceinline__ float min_hi(float x, float hi) {
   return __builtin_amdgcn_fmed3f(x, hi, -__builtin_inff());
@@ -466,7 +492,9 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
+  // sC = {col.b, reach mask (int bits), box_y (BOX) , thr}; BOX keeps box_x in sX
   __shared__ float4 sA[64], sB[64], sC[64];
+  __shared__ uint32_t sX[BOX ? 64 : 1];
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -479,46 +507,42 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
   const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
   const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
-  const float bcx[2] = {(float)tx0 + 3.5f, (float)tx0 + 11.5f};  // block centres
-  const float bcy[2] = {(float)ty0 + 3.5f, (float)ty0 + 11.5f};
   constexpr int DONE = (int)0x80000000;
   float tau[4], cr[4], cg[4], cb[4];
   int cont[4];
+  int live = 0;  // wave-uniform: bit k set while block k still has an unfinished pixel
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     cont[k] = ((pxb[k & 1] < p.W) && (pyb[k >> 1] < p.H)) ? 0 : DONE;
     tau[k] = 1.f; cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f;
+    if (__any(cont[k] >= 0)) live |= 1 << k;
   }
   const float stop = p.tau_stop;
-  for (int base = 0; base < n; base += 64) {
+  for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     if (base + lane < n) {
       const int g = gsid[r0 + base + lane];
-      sA[lane] = rec[3 * (size_t)g];
-      sB[lane] = rec[3 * (size_t)g + 1];
-      sC[lane] = rec[3 * (size_t)g + 2];
+      const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+      sA[lane] = A;
+      sB[lane] = B;
+      sC[lane] = make_float4(C.x, __int_as_float(reach_mask<BOX>(A, C, tx0, ty0)), C.z, C.w);
+      if (BOX) sX[lane] = __float_as_uint(C.y);
     }
     __syncthreads();
     const int m = min(64, n - base);
     for (int j = 0; j < m; ++j) {
-      const float4 A = sA[j], B = sB[j], C = sC[j];  // wave-uniform address: LDS broadcast
-      bool okx[2], oky[2], inx[2] = {true, true}, iny[2] = {true, true};
+      const float4 C = sC[j];  // wave-uniform address: LDS broadcast
+      const int reach = __builtin_amdgcn_readfirstlane(__float_as_int(C.y)) & live;
+      if (reach == 0) continue;  // scalar branch: no live block within reach of this entry
+      const float4 A = sA[j], B = sB[j];
+      bool inx[2] = {true, true}, iny[2] = {true, true};
       if (BOX) {
-        const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+        const uint32_t bx = sX[j], by = __float_as_uint(C.z);
         const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          okx[b] = (x0 < tx0 + 8 * b + 8) && (x1 > tx0 + 8 * b);
-          oky[b] = (y0 < ty0 + 8 * b + 8) && (y1 > ty0 + 8 * b);
           inx[b] = (pxb[b] >= x0) && (pxb[b] < x1);
           iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
-        }
-      } else {
-        const float rx = C.y + 3.5f, ry = C.z + 3.5f;
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          okx[b] = fabsf(A.x - bcx[b]) <= rx;
-          oky[b] = fabsf(A.y - bcy[b]) <= ry;
         }
       }
       float cxx[2], cxy[2], cyy[2], dy[2];
@@ -534,11 +558,12 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int bx = k & 1, by = k >> 1;
-        if (okx[bx] && oky[by]) {  // wave-uniform: the whole 8x8 block is in reach
+        if (reach & (1 << k)) {  // scalar branch: the whole 8x8 block is live and in reach
           // log2 of exp(-maha/2): F.5.1 (common.cuh:85-88) with the pre-scaled conic
           const float pw = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
           bool hit = (cont[k] >= 0) && (pw >= C.w);  // alpha' >= alpha_skip  (kernel.cu:246)
           if (BOX) hit = hit && inx[bx] && iny[by];
+          bool fin = false;
           if (hit) {
             float ap = B.y * __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
             if (CLAMP) ap = min_hi(ap, 0.99f);
@@ -546,15 +571,17 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
             cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
             const float t = tau[k] * (1.f - ap);  // F.5.2
             tau[k] = t;
-            cont[k] = (t < stop) ? (idx | DONE) : idx;
+            fin = t < stop;
+            cont[k] = fin ? (idx | DONE) : idx;
+          }
+          if (__any(fin)) {  // some pixel of block k just finished: is the whole block done?
+            if (!__any(cont[k] >= 0)) live &= ~(1 << k);
           }
         }
       }
-      // wave-uniform exit: every pixel of the tile is finished (all four sign bits in all lanes)
-      if (__all((cont[0] & cont[1] & cont[2] & cont[3]) < 0)) goto done;
+      if (live == 0) break;  // scalar exit: every pixel of the tile is finished
     }
   }
-done:
   const size_t HW = (size_t)p.W * p.H;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -630,7 +657,9 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
                                                  const int32_t* __restrict__ contrib,
                                                  const float* __restrict__ dLdg,
                                                  float* __restrict__ gpack) {
-  __shared__ float4 sA[64], sB[64], sC[64], sD[64];  // sD = {cinv.x, cinv.y, cinv.z, gsid}
+  // sC = {col.b, reach mask (int bits), box_y (BOX), thr}; sD = {cinv.x, cinv.y, cinv.z, gsid}
+  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
+  __shared__ uint32_t sX[BOX ? 64 : 1];
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -642,11 +671,10 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
   const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
   const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
-  const float bcx[2] = {(float)tx0 + 3.5f, (float)tx0 + 11.5f};
-  const float bcy[2] = {(float)ty0 + 3.5f, (float)ty0 + 11.5f};
   const size_t HW = (size_t)p.W * p.H;
   float tau[4], lr[4], lg[4], lb[4], qr[4], qg[4], qb[4];  // q = gamma_cur2last
   int cont[4];
+  int bmax[4];  // wave-uniform: largest contrib of block k -> entries >= bmax[k] are inert for it
   int maxcont = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
@@ -659,11 +687,12 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
       cont[k] = contrib[pix];
       lr[k] = dLdg[pix]; lg[k] = dLdg[HW + pix]; lb[k] = dLdg[2 * HW + pix];
     }
-    maxcont = max(maxcont, cont[k]);
-  }
+    int mx = cont[k];
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) maxcont = max(maxcont, __shfl_xor(maxcont, d, 64));
-  maxcont = min(maxcont, n);
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    bmax[k] = __builtin_amdgcn_readfirstlane(min(mx, n));
+    maxcont = max(maxcont, bmax[k]);
+  }
   if (maxcont <= 0) return;
 
   for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
@@ -671,9 +700,11 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
     const int idx = c * 64 + lane;
     if (idx < n) {
       const int g = gsid[r0 + idx];
-      sA[lane] = rec[3 * (size_t)g];
-      sB[lane] = rec[3 * (size_t)g + 1];
-      sC[lane] = rec[3 * (size_t)g + 2];
+      const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+      sA[lane] = A;
+      sB[lane] = B;
+      sC[lane] = make_float4(C.x, __int_as_float(reach_mask<BOX>(A, C, tx0, ty0)), C.z, C.w);
+      if (BOX) sX[lane] = __float_as_uint(C.y);
       sD[lane] = make_float4(cinv[3 * (size_t)g], cinv[3 * (size_t)g + 1], cinv[3 * (size_t)g + 2],
                              __int_as_float(g));
     }
@@ -690,24 +721,21 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         for (int q = 0; q < 9; ++q) acc[e][q] = 0.f;
         const int j = jj - e;
         const int i = c * 64 + j;  // forward index of this entry in the tile list
-        const float4 A = sA[j], B = sB[j], C = sC[j];
-        bool okx[2], oky[2], inx[2] = {true, true}, iny[2] = {true, true};
+        const float4 C = sC[j];
+        int reach = __builtin_amdgcn_readfirstlane(__float_as_int(C.y));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (i >= bmax[k]) reach &= ~(1 << k);  // no pixel of block k ever got this far (kernel.cu:899)
+        if (reach == 0) continue;  // scalar branch (entries past the list end have i >= bmax: inert)
+        const float4 A = sA[j], B = sB[j];
+        bool inx[2] = {true, true}, iny[2] = {true, true};
         if (BOX) {
-          const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+          const uint32_t bx = sX[j], by = __float_as_uint(C.z);
           const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
-            okx[b] = (x0 < tx0 + 8 * b + 8) && (x1 > tx0 + 8 * b);
-            oky[b] = (y0 < ty0 + 8 * b + 8) && (y1 > ty0 + 8 * b);
             inx[b] = (pxb[b] >= x0) && (pxb[b] < x1);
             iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
-          }
-        } else {
-          const float rx = C.y + 3.5f, ry = C.z + 3.5f;
-#pragma unroll
-          for (int b = 0; b < 2; ++b) {
-            okx[b] = fabsf(A.x - bcx[b]) <= rx;
-            oky[b] = fabsf(A.y - bcy[b]) <= ry;
           }
         }
         float dx[2], dy[2], cxx[2], cxy[2], cyy[2];
@@ -722,7 +750,7 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int bx = k & 1, by = k >> 1;
-          if (!(okx[bx] && oky[by])) continue;  // wave-uniform block cull
+          if (!(reach & (1 << k))) continue;  // scalar branch: block culled or past its last contributor
           const float pw = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
           bool hit = (i < cont[k]) && (pw >= C.w);  // kernel.cu:899,913
           if (BOX) hit = hit && inx[bx] && iny[by];
