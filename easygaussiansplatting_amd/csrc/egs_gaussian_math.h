@@ -332,4 +332,51 @@ __device__ __forceinline__ void load_sh_row(const float* __restrict__ row, float
   }
 }
 
+// ---- packed 2D record of the draw kernels (layout: see egs_raster.hip k_pack_records) ----
+#define EGS_NHL2E (-0.72134752044f)  // -0.5 * log2(e)
+// saturating float -> int (v_cvt_i32_f32 semantics; NaN -> 0)
+__device__ __forceinline__ int f2i(float v) { return (int)v; }
+// pixel box of gausplat.py:212-215
+__device__ __forceinline__ void pixel_box(float ux, float uy, float rx, float ry, int W, int H, int& x0,
+                                          int& x1, int& y0, int& y1) {
+  x0 = f2i(fmaxf(fminf(ux - rx, (float)W), 0.f));
+  x1 = f2i(fmaxf(fminf(ux + rx, (float)W), 0.f));
+  y0 = f2i(fmaxf(fminf(uy - ry, (float)H), 0.f));
+  y1 = f2i(fmaxf(fminf(uy + ry, (float)H), 0.f));
+}
+__device__ __forceinline__ void make_record(float ux, float uy, float c0, float c1, float c2, float alpha,
+                                            float r, float g, float b, int area_x, int area_y, int W, int H,
+                                            int footprint, float alpha_skip, float4* __restrict__ out) {
+  const float inf = __int_as_float(0x7f800000);
+  float e1, e2;
+  if (footprint == 1) {
+    int x0, x1, y0, y1;
+    pixel_box(ux, uy, (float)area_x, (float)area_y, W, H, x0, x1, y0, y1);
+    e1 = __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16));
+    e2 = __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16));
+  } else {
+    e1 = inf; e2 = inf;
+    const float det = c0 * c2 - c1 * c1;
+    // (det must not be the result of catastrophic cancellation: eigenvalue ratio < 1e4)
+    if (alpha_skip > 0.f && det > 1e-4f * c0 * c2 && c0 > 0.f && c2 > 0.f) {
+      if (alpha > alpha_skip) {
+        const float mstar = 2.f * logf(alpha / alpha_skip);
+        const float sxx = c2 / det, syy = c0 / det;  // Sigma = cinv^-1
+        e1 = sqrtf(mstar * sxx) * 1.01f + 0.05f;
+        e2 = sqrtf(mstar * syy) * 1.01f + 0.05f;
+      } else if (alpha <= alpha_skip * 0.999f) {
+        e1 = -inf; e2 = -inf;  // alpha' <= alpha < skip everywhere: never contributes
+      }
+    }
+    if (!(e1 == e1) || !(e2 == e2)) { e1 = inf; e2 = inf; }  // NaN guard
+  }
+  // skip threshold in the exponent domain
+  float thr;
+  if (alpha_skip > 0.f) thr = (alpha >= alpha_skip) ? log2f(alpha_skip / alpha) : inf;  // alpha < skip never blends
+  else thr = (alpha < 0.f) ? inf : -inf;  // !(alpha' < 0)
+  out[0] = make_float4(ux, uy, EGS_NHL2E * c0, (2.f * EGS_NHL2E) * c1);
+  out[1] = make_float4(EGS_NHL2E * c2, alpha, r, g);
+  out[2] = make_float4(b, e1, e2, thr);
+}
+
 }  // namespace egs

@@ -228,8 +228,8 @@ __global__ __launch_bounds__(256) void k_chain_rule(
 // fused training path
 // ============================================================================
 struct PreParams {
-  float fx, fy, cx, cy, limx, limy, det_eps;
-  int clamp_fov, near_cull, nan_cull, radius_mode;
+  float fx, fy, cx, cy, limx, limy, det_eps, alpha_skip;
+  int clamp_fov, near_cull, nan_cull, radius_mode, footprint, W, H;
 };
 
 // forward.md steps 1-5 for one Gaussian in one pass (== gsmodel.py:21-35 minus splat):
@@ -239,22 +239,24 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
                                                         const float* __restrict__ rots,
                                                         const float* __restrict__ scales,
                                                         const float* __restrict__ shs,
+                                                        const float* __restrict__ alphas,
                                                         const float* __restrict__ Rcw,
                                                         const float* __restrict__ tcw,
                                                         const float* __restrict__ twc,
                                                         float* __restrict__ us, float* __restrict__ depths,
                                                         float* __restrict__ cinv2ds,
                                                         float* __restrict__ colors,
-                                                        int32_t* __restrict__ areas) {
+                                                        int32_t* __restrict__ areas,
+                                                        float4* __restrict__ rec) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   constexpr int K = 3 * NC;
   const f3 pw = ld3(pws + 3 * (size_t)i);
+  float col[3];
   {  // colour has no depth test in the reference (kernel.cu:619-725)
     float sh[K];
     load_sh_row<K>(shs + (size_t)K * i, sh);
     const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
-    float col[3];
     sh_color_f<NC>(d, sh, col);
     st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
   }
@@ -277,6 +279,10 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
   depths[i] = depth;
   st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
   areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry;
+  // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
+  if (rec)
+    make_record(u0, u1, ci[0], ci[1], ci[2], alphas[i], col[0], col[1], col[2], rx, ry, pp.W, pp.H, pp.footprint,
+                pp.alpha_skip, rec + 3 * (size_t)i);
 }
 
 // backward.md eq (3)(4)(5)(7) == gsmodel.py:71-85 with every Jacobian re-derived in
@@ -478,28 +484,31 @@ static PreParams make_pre_params(const EgsPolicy* pol, float fx, float fy, float
   PreParams pp;
   pp.fx = fx; pp.fy = fy; pp.cx = cx; pp.cy = cy;
   fov_limits(pol, fx, fy, (float)width, (float)height, &pp.limx, &pp.limy);
-  pp.det_eps = pol->det_eps;
+  pp.det_eps = pol->det_eps; pp.alpha_skip = pol->alpha_skip;
+  pp.footprint = pol->footprint; pp.W = width; pp.H = height;
   pp.clamp_fov = pol->fov_mode != 2; pp.near_cull = pol->near_cull; pp.nan_cull = pol->nan_cull;
   pp.radius_mode = pol->radius_mode;
   return pp;
 }
 
 extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
-                                 const float* shs, const float* Rcw, const float* tcw, const float* twc, float fx,
-                                 float fy, float cx, float cy, int width, int height, const EgsPolicy* pol,
-                                 float* us, float* depths, float* cinv2ds, float* colors, int32_t* areas,
-                                 void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+                                 const float* shs, const float* alphas, const float* Rcw, const float* tcw,
+                                 const float* twc, float fx, float fy, float cx, float cy, int width, int height,
+                                 const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
+                                 int32_t* areas, void* rec, void* ws_bin, size_t ws_bin_bytes,
+                                 uint32_t* total_patches, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
   if (n > 0) {
     EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && us && depths && cinv2ds && colors && areas);
+    EGS_CHECK_ARG(!rec || alphas);
     EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0 && (sh_dim % 4 != 0 || ((uintptr_t)shs & 15) == 0));
     const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
     dim3 g(div_up(n, 256)), b(256);
     hipStream_t s = (hipStream_t)stream;
 #define EGS_PRE(NC)                                                                                            \
-  EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC>), g, b, s, n, pp, pws, rots, scales, shs, Rcw, tcw, twc, \
-             us, depths, cinv2ds, colors, areas)
+  EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC>), g, b, s, n, pp, pws, rots, scales, shs, alphas, Rcw,  \
+             tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec)
     switch (sh_dim) {
       case 3: EGS_PRE(1); break;
       case 12: EGS_PRE(4); break;
@@ -518,7 +527,7 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
                                   const float* rots, const float* scales, const float* shs, const float* alphas,
                                   const float* Rcw, const float* tcw, const float* twc, float fx, float fy, float cx,
                                   float cy, const EgsPolicy* pol, const float* us, const float* cinv2ds,
-                                  const float* colors, const int32_t* areas, const float* depths,
+                                  const float* colors, const int32_t* areas, const void* rec, const float* depths,
                                   const int32_t* contrib, const float* final_tau,
                                   const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                   const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
@@ -535,7 +544,7 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
   }
   float* gpack = nullptr;
   int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
-                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream);
+                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec);
   if (rc) return rc;
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
   dim3 g(div_up(n, 256)), b(256);

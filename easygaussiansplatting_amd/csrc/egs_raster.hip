@@ -16,7 +16,7 @@
 //   * reference drawB: 9 same-address float atomics per (pixel, Gaussian).
 //     Here: 4 pixels summed in-lane, DPP wave reduction, one lane issues the 9
 //     atomics per (tile, Gaussian): 256x fewer atomics.
-#include "egs_common.h"
+#include "egs_gaussian_math.h"
 
 #include <stdlib.h>
 
@@ -30,11 +30,16 @@ constexpr int RS_IPT = 16;                         // items per thread
 constexpr int RS_TILE = RS_THREADS * RS_IPT;       // 4096 items per workgroup
 constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // 1024 contiguous items per wave
 
+// `maxkey` (nullable, device): upper bound of all keys.  A pass whose digit is 0 for every key
+// ((*maxkey >> shift) == 0) is the identity permutation: hist/rowscan return at once and
+// scatter degenerates to a coalesced copy.
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
                                                            int shift, uint32_t dmask, int nblocks,
-                                                           uint32_t* __restrict__ hist) {
+                                                           uint32_t* __restrict__ hist,
+                                                           const uint32_t* __restrict__ maxkey) {
   __shared__ uint32_t h[256];
   const int tid = threadIdx.x;
+  if (maxkey && ((*maxkey >> shift) == 0u)) return;
   h[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RS_TILE;
@@ -50,8 +55,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
 // one workgroup per digit: exclusive scan of that digit's per-block counts (in
 // place) and the digit total.
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, int nblocks,
-                                                       uint32_t* __restrict__ totals) {
+                                                       uint32_t* __restrict__ totals, int shift,
+                                                       const uint32_t* __restrict__ maxkey) {
   __shared__ uint32_t sm[4];
+  if (maxkey && ((*maxkey >> shift) == 0u)) return;
   uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
   uint32_t carry = 0;
   for (int base = 0; base < nblocks; base += 256) {
@@ -68,7 +75,17 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
-    int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+    int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+    const uint32_t* __restrict__ maxkey) {
+  if (maxkey && ((*maxkey >> shift) == 0u)) {  // identity pass: plain copy
+    const int64_t b0 = (int64_t)blockIdx.x * RS_TILE;
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+      const int64_t idx = b0 + r * RS_THREADS + threadIdx.x;
+      if (idx < n) { keys_out[idx] = keys_in[idx]; vals_out[idx] = vals_in[idx]; }
+    }
+    return;
+  }
   __shared__ uint32_t wcount[4][256];  // per-wave running digit counters -> per-wave offsets
   __shared__ uint32_t gbase[256];
   __shared__ uint32_t sm[4];
@@ -147,17 +164,19 @@ static int sort_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit
 
 // enqueue all passes; result ends in (keys,vals) if the pass count is even
 static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
-                      int begin_bit, int end_bit, const SortWs& w, hipStream_t s) {
+                      int begin_bit, int end_bit, const SortWs& w, hipStream_t s,
+                      const uint32_t* maxkey = nullptr) {
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     const int nb = end_bit - shift < 8 ? end_bit - shift : 8;  // the last digit may be narrower
     const uint32_t dmask = (1u << nb) - 1u;
     EGS_LAUNCH("k_radix_hist", k_radix_hist, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask, w.nblocks,
-                       w.hist);
-    EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals);
-    EGS_LAUNCH("k_radix_scatter", k_radix_scatter, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift, dmask,
-                       w.nblocks, w.hist, w.totals);
+               w.hist, maxkey);
+    EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals, shift,
+               maxkey);
+    EGS_LAUNCH("k_radix_scatter", k_radix_scatter, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
+               dmask, w.nblocks, w.hist, w.totals, maxkey);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
@@ -250,27 +269,16 @@ struct BinParams {
   int footprint, far_cull, depth_key, mutate;
 };
 
-// saturating float -> int (v_cvt_i32_f32 semantics; NaN -> 0), explicit for clarity
-__device__ __forceinline__ int f2i(float v) { return (int)v; }
-
-// pixel box of gausplat.py:212-215
-__device__ __forceinline__ void pixel_box(float ux, float uy, float rx, float ry, int W, int H, int& x0,
-                                          int& x1, int& y0, int& y1) {
-  x0 = f2i(fmaxf(fminf(ux - rx, (float)W), 0.f));
-  x1 = f2i(fmaxf(fminf(ux + rx, (float)W), 0.f));
-  y0 = f2i(fmaxf(fminf(uy - ry, (float)H), 0.f));
-  y1 = f2i(fmaxf(fminf(uy + ry, (float)H), 0.f));
-}
-
 // getRects (reference kernel.cu:82-122) + the depth key of createKeys (kernel.cu:73)
 __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const float* __restrict__ us,
                                                    int32_t* __restrict__ areas, float* __restrict__ depths,
                                                    uint4* __restrict__ rects, uint32_t* __restrict__ counts,
-                                                   uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids) {
+                                                   uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
+                                                   uint32_t* __restrict__ maxkey) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  uint32_t cnt = 0, key = 0u;  // culled Gaussians emit nothing: any key will do, 0 keeps max small
+  if (i < n) {
   ids[i] = (uint32_t)i;
-  uint32_t cnt = 0, key = 0xFFFFFFFFu;
   uint4 rect = {0u, 0u, 0u, 0u};
   const float depth = depths[i];
   const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
@@ -312,6 +320,28 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
   rects[i] = rect;
   counts[i] = cnt;
   dkeys[i] = key;
+  }
+  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
+  uint32_t mk = key;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
+  // per-workgroup maximum, no atomics (a same-address atomicMax per wave measured +170 us);
+  // k_max_reduce folds the <= 4 K partial maxima
+  __shared__ uint32_t wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
+  __syncthreads();
+  if (threadIdx.x == 0) maxkey[1 + blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+
+__global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __restrict__ maxkey) {
+  __shared__ uint32_t wm[4];
+  uint32_t mk = 0u;
+  for (int i = threadIdx.x; i < nparts; i += 256) mk = max(mk, maxkey[1 + i]);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
+  __syncthreads();
+  if (threadIdx.x == 0) maxkey[0] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
 }
 
 // createKeys (reference kernel.cu:46-80) in depth-sorted Gaussian order; the
@@ -367,7 +397,6 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 //   result is unchanged.  Slack (x1.01 + 0.05 px) covers float rounding; a non positive-
 //   definite cinv or skip == 0 disables the cull (extent = +inf).
 // pixel-box footprint (forward_cpu): c1 = x0 | x1<<16, c2 = y0 | y1<<16 (gausplat.py:212-215)
-#define EGS_NHL2E (-0.72134752044f)  // -0.5 * log2(e)
 __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int footprint, float alpha_skip,
                                                       const float* __restrict__ us,
                                                       const float* __restrict__ cinv,
@@ -377,40 +406,10 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
                                                       float4* __restrict__ rec) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
-  const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
-  const float c0 = cinv[3 * (size_t)i], c1 = cinv[3 * (size_t)i + 1], c2 = cinv[3 * (size_t)i + 2];
-  const float r = colors[3 * (size_t)i], g = colors[3 * (size_t)i + 1], b = colors[3 * (size_t)i + 2];
-  const float alpha = alphas[i];
-  const float inf = __int_as_float(0x7f800000);
-  float e1, e2;
-  if (footprint == 1) {
-    int x0, x1, y0, y1;
-    pixel_box(ux, uy, (float)areas[2 * (size_t)i], (float)areas[2 * (size_t)i + 1], W, H, x0, x1, y0, y1);
-    e1 = __uint_as_float((uint32_t)x0 | ((uint32_t)x1 << 16));
-    e2 = __uint_as_float((uint32_t)y0 | ((uint32_t)y1 << 16));
-  } else {
-    e1 = inf; e2 = inf;
-    const float det = c0 * c2 - c1 * c1;
-    // (det must not be the result of catastrophic cancellation: eigenvalue ratio < 1e4)
-    if (alpha_skip > 0.f && det > 1e-4f * c0 * c2 && c0 > 0.f && c2 > 0.f) {
-      if (alpha > alpha_skip) {
-        const float mstar = 2.f * logf(alpha / alpha_skip);
-        const float sxx = c2 / det, syy = c0 / det;  // Sigma = cinv^-1
-        e1 = sqrtf(mstar * sxx) * 1.01f + 0.05f;
-        e2 = sqrtf(mstar * syy) * 1.01f + 0.05f;
-      } else if (alpha <= alpha_skip * 0.999f) {
-        e1 = -inf; e2 = -inf;  // alpha' <= alpha < skip everywhere: never contributes
-      }
-    }
-    if (!(e1 == e1) || !(e2 == e2)) { e1 = inf; e2 = inf; }  // NaN guard
-  }
-  // skip threshold in the exponent domain
-  float thr;
-  if (alpha_skip > 0.f) thr = (alpha >= alpha_skip) ? log2f(alpha_skip / alpha) : inf;  // alpha < skip never blends
-  else thr = (alpha < 0.f) ? inf : -inf;  // !(alpha' < 0)
-  rec[3 * (size_t)i + 0] = make_float4(ux, uy, EGS_NHL2E * c0, (2.f * EGS_NHL2E) * c1);
-  rec[3 * (size_t)i + 1] = make_float4(EGS_NHL2E * c2, alpha, r, g);
-  rec[3 * (size_t)i + 2] = make_float4(b, e1, e2, thr);
+  make_record(us[2 * (size_t)i], us[2 * (size_t)i + 1], cinv[3 * (size_t)i], cinv[3 * (size_t)i + 1],
+              cinv[3 * (size_t)i + 2], alphas[i], colors[3 * (size_t)i], colors[3 * (size_t)i + 1],
+              colors[3 * (size_t)i + 2], footprint == 1 ? areas[2 * (size_t)i] : 0,
+              footprint == 1 ? areas[2 * (size_t)i + 1] : 0, W, H, footprint, alpha_skip, rec + 3 * (size_t)i);
 }
 
 // ============================================================================
@@ -499,12 +498,25 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
   const int n = r1 - r0;
-  if (n <= 0) return;  // empty tile: outputs stay 0 (final_tau = 0, as the reference leaves it)
   const int lane = threadIdx.x;
   const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
   // pixel k = 2*by + bx of this lane: (tx0 + (lane&7) + 8 bx, ty0 + (lane>>3) + 8 by)
   const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
+  if (n <= 0) {  // empty tile: image = 0, contrib = 0 and final_tau = 0 (NOT 1), exactly what the
+                 // reference's early return leaves in its zero-filled outputs (kernel.cu:182)
+    const size_t HW0 = (size_t)p.W * p.H;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int px = pxb[k & 1], py = pyb[k >> 1];
+      if (px < p.W && py < p.H) {
+        const size_t pix = (size_t)py * p.W + px;
+        image[pix] = 0.f; image[HW0 + pix] = 0.f; image[2 * HW0 + pix] = 0.f;
+        contrib[pix] = 0; final_tau[pix] = 0.f;
+      }
+    }
+    return;
+  }
   const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
   const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
   constexpr int DONE = (int)0x80000000;
@@ -827,12 +839,13 @@ __global__ __launch_bounds__(256) void k_unpack_grads(int n, const float4* __res
 // ============================================================================
 struct BinLayout {
   uint4* rects;
-  uint32_t *counts, *dkeys, *dkeys_alt, *ids, *ids_alt, *offsets, *scan_partials;
+  uint32_t *counts, *dkeys, *dkeys_alt, *ids, *ids_alt, *offsets, *scan_partials, *maxkey;
   SortWs sort;
 };
 static size_t bin_ws_bytes(int n) {
   const size_t N = (size_t)(n > 0 ? n : 1);
-  return align_up(N * 16, 256) + 6 * align_up(N * 4, 256) + scan_ws_bytes(n) + sort_ws_bytes(n) + 4096;
+  return align_up(N * 16, 256) + 6 * align_up(N * 4, 256) + scan_ws_bytes(n) + sort_ws_bytes(n) +
+         align_up((64 + N / 256 + 1) * 4, 256) + 4096;
 }
 static bool bin_carve(void* ws, size_t bytes, int n, BinLayout* L) {
   Carver cv(ws, bytes);
@@ -845,6 +858,7 @@ static bool bin_carve(void* ws, size_t bytes, int n, BinLayout* L) {
   L->ids_alt = cv.take<uint32_t>(N);
   L->offsets = cv.take<uint32_t>(N);
   L->scan_partials = cv.take<uint32_t>(scan_ws_bytes(n) / 4);
+  L->maxkey = cv.take<uint32_t>(64 + div_up(N, 256));  // [0] = max depth key, [1..] per-workgroup partials
   return sort_ws_carve(cv, n, &L->sort) && cv.ok();
 }
 
@@ -957,26 +971,36 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
   p.footprint = pol->footprint; p.far_cull = pol->far_cull; p.depth_key = pol->depth_key;
   p.mutate = (pol->footprint == 0);
   EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rects,
-                     L.counts, L.dkeys, L.ids);
+             L.counts, L.dkeys, L.ids, L.maxkey);
+  EGS_LAUNCH("k_max_reduce", k_max_reduce, dim3(1), dim3(256), s, div_up(n, 256), L.maxkey);
   EGS_LAUNCH_OK();
-  // 4 passes (even): the sorted (dkeys, ids) end up in the primary buffers
-  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, 32, L.sort, s);
+  // 4 passes (even): the sorted (dkeys, ids) end up in the primary buffers; passes over digits
+  // that are zero in every key (mm depth keys rarely need more than 16 bits) are plain copies
+  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, 32, L.sort, s, L.maxkey);
   if (rc) return rc;
   return exclusive_scan(n, L.counts, L.ids, L.offsets, total_patches, L.scan_partials, s);
 }
 
-extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, const float* us,
-                              const float* cinv2ds, const float* alphas, const float* colors,
-                              const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
-                              size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
-                              int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+static int splat_draw_impl(int n, int64_t patches, int width, int height, const float* us,
+                           const float* cinv2ds, const float* alphas, const float* colors,
+                           const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                           size_t ws_draw_bytes, const float4* rec_in, float* image, int32_t* contrib,
+                           float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
+                           void* stream) {
   EGS_CHECK_ARG(n >= 0 && patches >= 0 && patches < (int64_t)0x7FFFFFFF && width > 0 && height > 0 && pol);
   EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
   hipStream_t s = (hipStream_t)stream;
   const DrawParams dp = make_draw_params(width, height, pol);
   EGS_HIP(hipMemsetAsync(patch_range_per_tile, 0, (size_t)dp.T * 8, s));
-  if (n == 0 || patches == 0) return 0;  // nothing to draw: outputs stay zero
-  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && areas && ws_bin && ws_draw && gsid_per_patch);
+  if (n == 0 || patches == 0) {  // nothing to draw: all outputs are zero
+    const size_t hw = (size_t)width * height;
+    EGS_HIP(hipMemsetAsync(image, 0, 12 * hw, s));
+    EGS_HIP(hipMemsetAsync(contrib, 0, 4 * hw, s));
+    EGS_HIP(hipMemsetAsync(final_tau, 0, 4 * hw, s));
+    return 0;
+  }
+  EGS_CHECK_ARG(ws_bin && ws_draw && gsid_per_patch);
+  EGS_CHECK_ARG(rec_in || (us && cinv2ds && alphas && colors && areas));
   BinLayout B;
   if (!bin_carve(const_cast<void*>(ws_bin), bin_ws_bytes(n), n, &B)) return EGS_ERR_WORKSPACE;
   DrawLayout D;
@@ -994,9 +1018,10 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
   EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
                      v0);
-  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
-             pol->alpha_skip, us,
-                     cinv2ds, alphas, colors, areas, D.rec);
+  const float4* rec = rec_in ? rec_in : D.rec;
+  if (!rec_in)
+    EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
+               pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, D.rec);
   EGS_LAUNCH_OK();
   int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s);
   if (rc) return rc;
@@ -1005,7 +1030,7 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                        \
   EGS_LAUNCH("k_draw", (k_draw<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile,     \
-             gsid_per_patch, D.rec, image, contrib, final_tau)
+             gsid_per_patch, rec, image, contrib, final_tau)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {
     case 0: EGS_DRAW(false, false, false); break;
@@ -1022,6 +1047,27 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   return 0;
 }
 
+extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, const float* us,
+                              const float* cinv2ds, const float* alphas, const float* colors,
+                              const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                              size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                              int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+  return splat_draw_impl(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, ws_bin, ws_draw,
+                         ws_draw_bytes, nullptr, image, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
+                         stream);
+}
+
+// as egs_splat_draw, with the packed 2D records already built (egs_fused_forward)
+extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec,
+                                  const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
+                                  float* image, int32_t* contrib, float* final_tau,
+                                  int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+  EGS_CHECK_ARG(rec || n == 0);
+  return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
+                         ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
+                         patch_range_per_tile, gsid_per_patch, stream);
+}
+
 extern "C" size_t egs_splat_bwd_ws_bytes(int n) { return 2 * align_up((size_t)(n > 0 ? n : 1) * 48, 256) + 256; }
 
 namespace egs {
@@ -1029,20 +1075,20 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                     float** gpack_out, void* stream) {
+                     float** gpack_out, void* stream, const void* rec_in) {
   hipStream_t s = (hipStream_t)stream;
-  float4* rec = (float4*)ws;
+  const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
   float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));  // [N][12] packed gradient records
   *gpack_out = gpack;
   (void)ws_bytes;
   EGS_HIP(hipMemsetAsync(gpack, 0, (size_t)n * 48, s));
   if (patches == 0) return 0;
-  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && contrib && final_tau && patch_range_per_tile &&
-                gsid_per_patch && dloss_dgammas);
-  EGS_CHECK_ARG(pol->footprint == 0 || areas);
+  EGS_CHECK_ARG(cinv2ds && contrib && final_tau && patch_range_per_tile && gsid_per_patch && dloss_dgammas);
+  EGS_CHECK_ARG(rec_in || (us && alphas && colors && (pol->footprint == 0 || areas)));
   const DrawParams dp = make_draw_params(width, height, pol);
-  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
-             pol->alpha_skip, us, cinv2ds, alphas, colors, areas, rec);
+  if (!rec_in)
+    EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
+               pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile, \
              gsid_per_patch, rec, cinv2ds, final_tau, contrib, dloss_dgammas, gpack)
@@ -1079,7 +1125,7 @@ extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, cons
   }
   float* gpack = nullptr;
   int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
-                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream);
+                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, nullptr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,

@@ -23,7 +23,7 @@ from .gsplatcu import _alphas, _chk, _lib_on, _pol, _ptr, _stream, _tiles
 
 class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``)."""
-    __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "contrib", "final_tau", "ranges", "gsid",
+    __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
                  "width", "height")
 
 
@@ -55,16 +55,18 @@ def forward(pws, shs, alphas, scales, rots, cam):
     S.cinv2ds = torch.empty((n, 3), dtype=f32, device=dev)
     S.colors = torch.empty((n, 3), dtype=f32, device=dev)
     S.areas = torch.empty((n, 2), dtype=i32, device=dev)
+    S.rec = torch.empty((max(n, 1), 12), dtype=f32, device=dev)   # packed 2D records, reused by backward
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
     total = torch.empty(1, dtype=i32, device=dev)
-    _lib.check(lib.egs_fused_forward(n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(Rcw), _ptr(tcw),
-                                     _ptr(twc), float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), W, H,
-                                     pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds), _ptr(S.colors),
-                                     _ptr(S.areas), _ptr(ws_bin), ws_bin_bytes, _ptr(total), st))
-    image = torch.zeros((3, H, W), dtype=f32, device=dev)       # empty tiles are not written (kernel.cu:182)
-    S.contrib = torch.zeros((H, W), dtype=i32, device=dev)
-    S.final_tau = torch.zeros((H, W), dtype=f32, device=dev)
+    _lib.check(lib.egs_fused_forward(n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(alphas), _ptr(Rcw),
+                                     _ptr(tcw), _ptr(twc), float(cam.fx), float(cam.fy), float(cam.cx),
+                                     float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
+                                     _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(ws_bin), ws_bin_bytes,
+                                     _ptr(total), st))
+    image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
+    S.contrib = torch.empty((H, W), dtype=i32, device=dev)
+    S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
     S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
     patches = int(total.item()) & 0xFFFFFFFF                     # the one 4-byte read-back (gausplat.cu:67)
     if patches >= 2**31:
@@ -72,9 +74,9 @@ def forward(pws, shs, alphas, scales, rots, cam):
     S.gsid = torch.empty(patches, dtype=i32, device=dev)
     ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, W, H)
     ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.egs_splat_draw(n, patches, W, H, _ptr(S.us), _ptr(S.cinv2ds), _ptr(alphas), _ptr(S.colors),
-                                  _ptr(S.areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes, _ptr(image),
-                                  _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), st))
+    _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
+                                      ws_draw_bytes, _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
+                                      _ptr(S.ranges), _ptr(S.gsid), st))
     mask = S.depths > 0.2                                        # gsmodel.py:50
     return image, mask, S
 
@@ -105,7 +107,7 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas):
     _lib.check(lib.egs_fused_backward(n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs),
                                       _ptr(alphas), _ptr(cam.Rcw), _ptr(cam.tcw), _ptr(cam.twc), float(cam.fx),
                                       float(cam.fy), float(cam.cx), float(cam.cy), C.byref(_pol()), _ptr(S.us),
-                                      _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.depths),
+                                      _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(S.depths),
                                       _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), _ptr(dl),
                                       _ptr(ws), ws_bytes, _ptr(dpws), _ptr(dshs), _ptr(dalphas), _ptr(dscales),
                                       _ptr(drots), _ptr(dus), _stream()))

@@ -218,9 +218,9 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     lib = _lib_on(us)
     dev = us.device
     pol = C.byref(_pol())
-    image = torch.zeros((3, height, width), dtype=torch.float32, device=dev)
-    contrib = torch.zeros((height, width), dtype=torch.int32, device=dev)
-    final_tau = torch.zeros((height, width), dtype=torch.float32, device=dev)
+    image = torch.empty((3, height, width), dtype=torch.float32, device=dev)      # fully written by the callee
+    contrib = torch.empty((height, width), dtype=torch.int32, device=dev)
+    final_tau = torch.empty((height, width), dtype=torch.float32, device=dev)
     ranges = torch.empty((_tiles(width, height), 2), dtype=torch.int32, device=dev)
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
@@ -263,10 +263,10 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
         areas = _chk(areas, "areas", torch.int32, (n, 2))
     lib = _lib_on(us)
     dev = us.device
-    d_us = torch.zeros((n, 1, 2), dtype=torch.float32, device=dev)
-    d_cinv = torch.zeros((n, 1, 3), dtype=torch.float32, device=dev)
-    d_alpha = torch.zeros((n, 1, 1), dtype=torch.float32, device=dev)
-    d_color = torch.zeros((n, 1, 3), dtype=torch.float32, device=dev)
+    d_us = torch.empty((n, 1, 2), dtype=torch.float32, device=dev)               # fully written by the callee
+    d_cinv = torch.empty((n, 1, 3), dtype=torch.float32, device=dev)
+    d_alpha = torch.empty((n, 1, 1), dtype=torch.float32, device=dev)
+    d_color = torch.empty((n, 1, 3), dtype=torch.float32, device=dev)
     ws_bytes = lib.egs_splat_bwd_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),

@@ -117,9 +117,10 @@ int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas,
                   const EgsPolicy* pol, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
                   void* stream);
 
-/* patches = the value read back from total_patches.  Outputs: image[3,H,W],
- * contrib[H,W] int32, final_tau[H,W] (zero-filled by the caller),
- * patch_range_per_tile[T,2] int32 (zeroed here), gsid_per_patch[P] int32. */
+/* patches = the value read back from total_patches.  Outputs, all fully written here (no
+ * zero-fill needed): image[3,H,W], contrib[H,W] int32, final_tau[H,W] (empty tiles get
+ * image = 0, contrib = 0, final_tau = 0 like the reference), patch_range_per_tile[T,2] int32,
+ * gsid_per_patch[P] int32. */
 int egs_splat_draw(int n, int64_t patches, int width, int height, const float* us,
                    const float* cinv2ds, const float* alphas, const float* colors, const int32_t* areas,
                    const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
@@ -173,17 +174,25 @@ int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss
  *                         re-derives the Jacobians in registers and applies backward.md
  *                         eq (3)(4)(5)(7) (gsmodel.py:71-85).
  * `depths`/`areas` are the arrays egs_fused_forward produced (incl. the in-place culling). */
+/* rec (nullable): 48 N bytes; receives the packed 2D records of the draw kernels so that
+ * egs_splat_draw_rec / egs_fused_backward skip their own packing pass. */
 int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
-                      const float* shs, const float* Rcw, const float* tcw, const float* twc, float fx,
-                      float fy, float cx, float cy, int width, int height, const EgsPolicy* pol, float* us,
-                      float* depths, float* cinv2ds, float* colors, int32_t* areas, void* ws_bin,
-                      size_t ws_bin_bytes, uint32_t* total_patches, void* stream);
+                      const float* shs, const float* alphas, const float* Rcw, const float* tcw,
+                      const float* twc, float fx, float fy, float cx, float cy, int width, int height,
+                      const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
+                      int32_t* areas, void* rec, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                      void* stream);
+int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
+                       const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
+                       int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
+                       int32_t* gsid_per_patch, void* stream);
 size_t egs_fused_backward_ws_bytes(int n);
 int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
                        const float* rots, const float* scales, const float* shs, const float* alphas,
                        const float* Rcw, const float* tcw, const float* twc, float fx, float fy, float cx,
                        float cy, const EgsPolicy* pol, const float* us, const float* cinv2ds,
-                       const float* colors, const int32_t* areas, const float* depths,
+                       const float* colors, const int32_t* areas, const void* rec /*nullable*/,
+                       const float* depths,
                        const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                        const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
