@@ -530,6 +530,7 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
     if (__any(cont[k] >= 0)) live |= 1 << k;
   }
   const float stop = p.tau_stop;
+  int finany = 0;
   for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     if (base + lane < n) {
@@ -575,7 +576,6 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
           const float pw = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
           bool hit = (cont[k] >= 0) && (pw >= C.w);  // alpha' >= alpha_skip  (kernel.cu:246)
           if (BOX) hit = hit && inx[bx] && iny[by];
-          bool fin = false;
           if (hit) {
             float ap = B.y * __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
             if (CLAMP) ap = min_hi(ap, 0.99f);
@@ -583,15 +583,19 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
             cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
             const float t = tau[k] * (1.f - ap);  // F.5.2
             tau[k] = t;
-            fin = t < stop;
+            const bool fin = t < stop;
             cont[k] = fin ? (idx | DONE) : idx;
-          }
-          if (__any(fin)) {  // some pixel of block k just finished: is the whole block done?
-            if (!__any(cont[k] >= 0)) live &= ~(1 << k);
+            finany |= (int)fin;
           }
         }
       }
-      if (live == 0) break;  // scalar exit: every pixel of the tile is finished
+      if (__any(finany != 0)) {  // some pixel just finished (rare): refresh the live-block mask
+        finany = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (!__any(cont[k] >= 0)) live &= ~(1 << k);
+        if (live == 0) break;  // scalar exit: every pixel of the tile is finished
+      }
     }
   }
   const size_t HW = (size_t)p.W * p.H;
@@ -684,15 +688,16 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
   const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
   const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
   const size_t HW = (size_t)p.W * p.H;
-  float tau[4], lr[4], lg[4], lb[4], qr[4], qg[4], qb[4];  // q = gamma_cur2last
+  // lq = dL/dgamma . gamma_cur2last: the only combination of gamma_cur2last (kernel.cu:854,948)
+  // the gradient needs, so the 3-vector recurrence q += a'(c - q) is carried as one scalar
+  float tau[4], lr[4], lg[4], lb[4], lq[4];
   int cont[4];
   int bmax[4];  // wave-uniform: largest contrib of block k -> entries >= bmax[k] are inert for it
   int maxcont = 0;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int px = pxb[k & 1], py = pyb[k >> 1];
-    tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f;
-    qr[k] = 0.f; qg[k] = 0.f; qb[k] = 0.f;
+    tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f; lq[k] = 0.f;
     if (px < p.W && py < p.H) {
       const size_t pix = (size_t)py * p.W + px;
       tau[k] = final_tau[pix];
@@ -772,8 +777,8 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
             if (CLAMP) ap = min_hi(ap, 0.99f);
             const float tk = tau[k] * __builtin_amdgcn_rcpf(1.f - ap);  // undo F.5.2
             tau[k] = tk;
-            const float dr = B.z - qr[k], dg = B.w - qg[k], db = C.x - qb[k];
-            const float dl_dap = tk * (lr[k] * dr + lg[k] * dg + lb[k] * db);  // B.5a
+            const float dq = (lr[k] * B.z + lg[k] * B.w + lb[k] * C.x) - lq[k];  // dL/dgamma . (color - gamma_cur2last)
+            const float dl_dap = tk * dq;  // B.5a
             acc[e][0] += dl_dap * g;  // dalpha'/dalpha = g, also where the clamp binds (kernel.cu:921)
             const float wgt = ap * tk;
             acc[e][1] += lr[k] * wgt; acc[e][2] += lg[k] * wgt; acc[e][3] += lb[k] * wgt;
@@ -781,7 +786,7 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
             const float wx = w * dx[bx], wy = w * dy[by];
             acc[e][4] += wx; acc[e][5] += wy;
             acc[e][6] += wx * dx[bx]; acc[e][7] += wx * dy[by]; acc[e][8] += wy * dy[by];
-            qr[k] += ap * dr; qg[k] += ap * dg; qb[k] += ap * db;  // gamma_cur2last
+            lq[k] += ap * dq;  // gamma_cur2last <- a' color + (1 - a') gamma_cur2last, dotted with dL/dgamma
             any = true;
           }
         }
