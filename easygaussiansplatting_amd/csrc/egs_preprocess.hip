@@ -204,10 +204,22 @@ __global__ __launch_bounds__(256) void k_chain_rule(
   const f3 gcol = ld3(dL_dcolor + 3 * (size_t)i);
   const float* Bs = J_color_sh + (size_t)NC * i;
   float* osh = dL_dsh + (size_t)(3 * NC) * i;
+  {
+    constexpr int K = 3 * NC;
+    float gsh[K];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    const float bc = Bs[c];
-    osh[3 * c] = gcol.x * bc; osh[3 * c + 1] = gcol.y * bc; osh[3 * c + 2] = gcol.z * bc;
+    for (int c = 0; c < NC; ++c) {
+      const float bc = Bs[c];
+      gsh[3 * c] = gcol.x * bc; gsh[3 * c + 1] = gcol.y * bc; gsh[3 * c + 2] = gcol.z * bc;
+    }
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+      for (int j = 0; j < K / 4; ++j)
+        reinterpret_cast<float4*>(osh)[j] = make_float4(gsh[4 * j], gsh[4 * j + 1], gsh[4 * j + 2], gsh[4 * j + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) osh[k] = gsh[k];
+    }
   }
   // dL/dpc = dL/du @ du_dpc + dL/dcov2d @ dcov2d_dpc ; dL/dpw = dL/dpc @ Rcw + dL/dcolor @ dcolor_dpw
   const float gu0 = dL_du[2 * (size_t)i], gu1 = dL_du[2 * (size_t)i + 1];
@@ -310,8 +322,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
     st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
     st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
+    if constexpr (K % 4 == 0) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) osh[k] = 0.f;
+      for (int j = 0; j < K / 4; ++j) reinterpret_cast<float4*>(osh)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) osh[k] = 0.f;
+    }
     return;
   }
   const f3 pw = ld3(pws + 3 * (size_t)i);
@@ -344,9 +361,20 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   float sh[K];
   load_sh_row<K>(shs + (size_t)K * i, sh);
   const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
+  {  // eq (5): dL/dsh[c, rgb] = dL/dcolor[rgb] * basis[c]; 48- or 192-B rows go out as dwordx4
+    float gsh[K];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {  // eq (5)
-    osh[3 * c] = gcol.x * d.B[c]; osh[3 * c + 1] = gcol.y * d.B[c]; osh[3 * c + 2] = gcol.z * d.B[c];
+    for (int c = 0; c < NC; ++c) {
+      gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
+    }
+    if constexpr (K % 4 == 0) {
+#pragma unroll
+      for (int j = 0; j < K / 4; ++j)
+        reinterpret_cast<float4*>(osh)[j] = make_float4(gsh[4 * j], gsh[4 * j + 1], gsh[4 * j + 2], gsh[4 * j + 3]);
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) osh[k] = gsh[k];
+    }
   }
   float W[9];
   sh_jac_dpw<NC>(d, sh, W);

@@ -72,33 +72,38 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
   if (threadIdx.x == 0) totals[blockIdx.x] = carry;
 }
 
+// Scatter with local reordering: every item's stable rank inside the workgroup's 4096-item tile
+// is found with per-wave ballot multi-split (deterministic, no LDS atomics), the tile is written
+// digit-sorted into LDS, and then streamed out so that consecutive lanes write consecutive
+// addresses inside each digit run (coalesced) instead of 64 scattered dwords per instruction.
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
     int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
     const uint32_t* __restrict__ maxkey) {
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int64_t blockbase = (int64_t)blockIdx.x * RS_TILE;
   if (maxkey && ((*maxkey >> shift) == 0u)) {  // identity pass: plain copy
-    const int64_t b0 = (int64_t)blockIdx.x * RS_TILE;
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
-      const int64_t idx = b0 + r * RS_THREADS + threadIdx.x;
+      const int64_t idx = blockbase + r * RS_THREADS + tid;
       if (idx < n) { keys_out[idx] = keys_in[idx]; vals_out[idx] = vals_in[idx]; }
     }
     return;
   }
   __shared__ uint32_t wcount[4][256];  // per-wave running digit counters -> per-wave offsets
-  __shared__ uint32_t gbase[256];
+  __shared__ uint32_t dstart[256];     // first local slot of each digit inside this tile
+  __shared__ uint32_t gadj[256];       // global position of local slot i with digit d: gadj[d] + i
   __shared__ uint32_t sm[4];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
 #pragma unroll
   for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
   // global base of digit `tid` = (sum of totals of smaller digits) + (same digit in earlier blocks)
   const uint32_t dig_ex = block256_exclusive_scan(totals[tid], sm, nullptr);
-  gbase[tid] = dig_ex + hist[(size_t)tid * nblocks + blockIdx.x];
-  __syncthreads();
+  const uint32_t gbase = dig_ex + hist[(size_t)tid * nblocks + blockIdx.x];
 
-  const int64_t base = (int64_t)blockIdx.x * RS_TILE + (int64_t)wave * RS_WAVE_ITEMS;
-  uint32_t key[RS_IPT], rank[RS_IPT];
+  const int64_t base = blockbase + (int64_t)wave * RS_WAVE_ITEMS;
+  uint32_t key[RS_IPT], val[RS_IPT], rank[RS_IPT];
   volatile uint32_t* wc = wcount[wave];
   const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
 #pragma unroll
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const int64_t idx = base + r * EGS_WAVE + lane;
     const bool valid = idx < n;
     const uint32_t k = valid ? keys_in[idx] : 0u;
+    val[r] = valid ? vals_in[idx] : 0u;
     const uint32_t d = (k >> shift) & dmask;
     // peers = lanes of this wave holding the same digit (multi-split by ballots)
     uint64_t peers = __ballot(valid);
@@ -123,24 +129,40 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     rank[r] = prev + below;
   }
   __syncthreads();
-  {  // digit `tid`: exclusive scan of its per-wave counts
-    uint32_t off = 0;
+  uint32_t cnt = 0;
+  {  // digit `tid`: exclusive scan of its per-wave counts, and its count in the whole tile
 #pragma unroll
     for (int w = 0; w < 4; ++w) {
       const uint32_t c = wcount[w][tid];
-      wcount[w][tid] = off;
-      off += c;
+      wcount[w][tid] = cnt;
+      cnt += c;
     }
   }
+  const uint32_t ds = block256_exclusive_scan(cnt, sm, nullptr);  // (contains barriers)
+  dstart[tid] = ds;
+  gadj[tid] = gbase - ds;
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < RS_IPT; ++r) {
     const int64_t idx = base + r * EGS_WAVE + lane;
     if (idx < n) {
       const uint32_t d = (key[r] >> shift) & dmask;
-      const uint32_t pos = gbase[d] + wcount[wave][d] + rank[r];
-      keys_out[pos] = key[r];
-      vals_out[pos] = vals_in[idx];
+      const uint32_t slot = dstart[d] + wcount[wave][d] + rank[r];
+      skey[slot] = key[r];
+      sval[slot] = val[r];
+    }
+  }
+  __syncthreads();
+  const int64_t rem = n - blockbase;
+  const int nvalid = rem < RS_TILE ? (int)rem : RS_TILE;
+#pragma unroll
+  for (int r = 0; r < RS_IPT; ++r) {
+    const int slot = r * RS_THREADS + tid;
+    if (slot < nvalid) {
+      const uint32_t k = skey[slot];
+      const uint32_t pos = gadj[(k >> shift) & dmask] + (uint32_t)slot;
+      keys_out[pos] = k;
+      vals_out[pos] = sval[slot];
     }
   }
 }
