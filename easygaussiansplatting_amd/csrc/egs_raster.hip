@@ -503,9 +503,10 @@ __device__ __forceinline__ int reach_mask(const float4& A, const float4& C, int 
          ((int)(okx[1] && oky[1]) << 3);
 }
 
-// min(x, hi) as ONE v_med3_f32 (fminf() costs a canonicalising v_max + v_min in IEEE mode)
+// min(x, hi) as ONE v_med3_f32 (fminf() costs a canonicalising v_max + v_min in IEEE mode; the
+// low bound is finite so the compiler cannot fold the median back into a min)
 __device__ __forceinline__ float min_hi(float x, float hi) {
-  return __builtin_amdgcn_fmed3f(x, hi, -__builtin_inff());
+  return __builtin_amdgcn_fmed3f(x, hi, -3.0e38f);
 }
 
 template <bool BOX, bool FLOOR, bool CLAMP>
@@ -513,9 +514,7 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
-  // sC = {col.b, reach mask (int bits), box_y (BOX) , thr}; BOX keeps box_x in sX
   __shared__ float4 sA[64], sB[64], sC[64];
-  __shared__ uint32_t sX[BOX ? 64 : 1];
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -552,27 +551,27 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
     if (__any(cont[k] >= 0)) live |= 1 << k;
   }
   const float stop = p.tau_stop;
-  int finany = 0;
   for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
+    int mymask = 0;   // reach mask of the entry THIS lane staged (lane j <-> entry base + j)
     if (base + lane < n) {
       const int g = gsid[r0 + base + lane];
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+      mymask = reach_mask<BOX>(A, C, tx0, ty0);
       sA[lane] = A;
       sB[lane] = B;
-      sC[lane] = make_float4(C.x, __int_as_float(reach_mask<BOX>(A, C, tx0, ty0)), C.z, C.w);
-      if (BOX) sX[lane] = __float_as_uint(C.y);
+      sC[lane] = C;
     }
     __syncthreads();
     const int m = min(64, n - base);
     for (int j = 0; j < m; ++j) {
-      const float4 C = sC[j];  // wave-uniform address: LDS broadcast
-      const int reach = __builtin_amdgcn_readfirstlane(__float_as_int(C.y)) & live;
+      // the entry's mask comes straight out of lane j's register (v_readlane): no LDS round trip
+      const int reach = __builtin_amdgcn_readlane(mymask, j) & live;
       if (reach == 0) continue;  // scalar branch: no live block within reach of this entry
-      const float4 A = sA[j], B = sB[j];
+      const float4 A = sA[j], B = sB[j], C = sC[j];  // wave-uniform address: LDS broadcast
       bool inx[2] = {true, true}, iny[2] = {true, true};
       if (BOX) {
-        const uint32_t bx = sX[j], by = __float_as_uint(C.z);
+        const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
         const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
@@ -590,6 +589,7 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
         cyy[b] = B.x * dy[b] * dy[b];  // qyy dy dy
       }
       const int idx = base + j + 1;
+      int finacc = 0;  // OR of the counters written by this entry: sign bit <=> some pixel finished
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const int bx = k & 1, by = k >> 1;
@@ -603,16 +603,14 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
             if (CLAMP) ap = min_hi(ap, 0.99f);
             const float w = tau[k] * ap;  // F.5
             cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
-            const float t = tau[k] * (1.f - ap);  // F.5.2
+            const float t = tau[k] - w;  // F.5.2: tau (1 - alpha')
             tau[k] = t;
-            const bool fin = t < stop;
-            cont[k] = fin ? (idx | DONE) : idx;
-            finany |= (int)fin;
+            cont[k] = (t < stop) ? (idx | DONE) : idx;
+            finacc |= cont[k];
           }
         }
       }
-      if (__any(finany != 0)) {  // some pixel just finished (rare): refresh the live-block mask
-        finany = 0;
+      if (__any(finacc < 0)) {  // some pixel just finished (rare): refresh the live-block mask
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (!__any(cont[k] >= 0)) live &= ~(1 << k);
@@ -695,9 +693,7 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
                                                  const int32_t* __restrict__ contrib,
                                                  const float* __restrict__ dLdg,
                                                  float* __restrict__ gpack) {
-  // sC = {col.b, reach mask (int bits), box_y (BOX), thr}; sD = {cinv.x, cinv.y, cinv.z, gsid}
-  __shared__ float4 sA[64], sB[64], sC[64], sD[64];
-  __shared__ uint32_t sX[BOX ? 64 : 1];
+  __shared__ float4 sA[64], sB[64], sC[64], sD[64];  // sD = {cinv.x, cinv.y, cinv.z, gsid}
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -737,13 +733,14 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
   for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
     __syncthreads();
     const int idx = c * 64 + lane;
+    int mymask = 0;  // reach mask of the entry THIS lane staged (lane j <-> entry c*64 + j)
     if (idx < n) {
       const int g = gsid[r0 + idx];
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+      mymask = reach_mask<BOX>(A, C, tx0, ty0);
       sA[lane] = A;
       sB[lane] = B;
-      sC[lane] = make_float4(C.x, __int_as_float(reach_mask<BOX>(A, C, tx0, ty0)), C.z, C.w);
-      if (BOX) sX[lane] = __float_as_uint(C.y);
+      sC[lane] = C;
       sD[lane] = make_float4(cinv[3 * (size_t)g], cinv[3 * (size_t)g + 1], cinv[3 * (size_t)g + 2],
                              __int_as_float(g));
     }
@@ -760,16 +757,15 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         for (int q = 0; q < 9; ++q) acc[e][q] = 0.f;
         const int j = jj - e;
         const int i = c * 64 + j;  // forward index of this entry in the tile list
-        const float4 C = sC[j];
-        int reach = __builtin_amdgcn_readfirstlane(__float_as_int(C.y));
+        int reach = __builtin_amdgcn_readlane(mymask, j);  // lane j's register: no LDS round trip
 #pragma unroll
         for (int k = 0; k < 4; ++k)
           if (i >= bmax[k]) reach &= ~(1 << k);  // no pixel of block k ever got this far (kernel.cu:899)
         if (reach == 0) continue;  // scalar branch (entries past the list end have i >= bmax: inert)
-        const float4 A = sA[j], B = sB[j];
+        const float4 A = sA[j], B = sB[j], C = sC[j];
         bool inx[2] = {true, true}, iny[2] = {true, true};
         if (BOX) {
-          const uint32_t bx = sX[j], by = __float_as_uint(C.z);
+          const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
           const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
