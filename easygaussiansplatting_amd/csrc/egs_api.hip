@@ -26,6 +26,7 @@ static std::mutex g_prof_mu;
 static bool g_prof_enabled = false;
 static std::vector<ProfRec> g_prof_recs;
 static std::vector<hipEvent_t> g_prof_pool;
+static std::string g_prof_filter;  // empty = every kernel
 
 static hipEvent_t prof_event() {
   if (!g_prof_pool.empty()) {
@@ -38,7 +39,10 @@ static hipEvent_t prof_event() {
   return e;
 }
 
-bool prof_on() { return g_prof_enabled; }
+bool prof_on(const char* name) {
+  if (!g_prof_enabled) return false;
+  return g_prof_filter.empty() || g_prof_filter == name;
+}
 
 void prof_begin(const char* name, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_prof_mu);
@@ -58,6 +62,11 @@ extern "C" int egs_prof_enable(int on) {
   const int prev = egs::g_prof_enabled;
   egs::g_prof_enabled = on != 0;
   return prev;
+}
+
+extern "C" void egs_prof_set_filter(const char* kernel_name) {
+  std::lock_guard<std::mutex> lk(egs::g_prof_mu);
+  egs::g_prof_filter = kernel_name ? kernel_name : "";
 }
 
 extern "C" void egs_prof_reset(void) {

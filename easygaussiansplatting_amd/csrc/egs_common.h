@@ -38,13 +38,13 @@ void set_error(int code, const char* what, const char* file, int line);
 #define EGS_LAUNCH_OK() EGS_HIP(hipGetLastError())
 
 // ---- optional per-kernel timing (egs_prof_* in the C ABI) -------------------
-bool prof_on();
+bool prof_on(const char* name);
 void prof_begin(const char* name, hipStream_t s);
 void prof_end(hipStream_t s);
 struct ProfScope {
   hipStream_t s;
   bool on;
-  ProfScope(const char* name, hipStream_t st) : s(st), on(prof_on()) {
+  ProfScope(const char* name, hipStream_t st) : s(st), on(prof_on(name)) {
     if (on) prof_begin(name, s);
   }
   ~ProfScope() {

@@ -203,8 +203,11 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
  * is bracketed by hipEventRecord on the stream it is launched on.
  * egs_prof_report() synchronises the recorded events and writes one line per
  * kernel name: "<name> <launches> <total_ms>\n"; returns the number of bytes
- * needed (excluding the NUL).  Recording costs ~2 us per launch. */
+ * needed (excluding the NUL).  Recording every launch costs ~0.2 ms per 35-launch step on MI355X
+ * (hipEventRecord serialises dispatch), hence the filter: bench.py times only the dominant kernel
+ * inside its timed region. */
 int egs_prof_enable(int on);
+void egs_prof_set_filter(const char* kernel_name); /* NULL or "" = all kernels; else only that kernel */
 void egs_prof_reset(void);
 int egs_prof_report(char* buf, size_t cap);
 
