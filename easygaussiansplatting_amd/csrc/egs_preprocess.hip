@@ -523,8 +523,8 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
                                  const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                                  const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                                  const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                                 int32_t* areas, void* rec, void* ws_bin, size_t ws_bin_bytes,
-                                 uint32_t* total_patches, void* stream) {
+                                 int32_t* areas, void* rec, int key_bits_hint, void* ws_bin,
+                                 size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
   if (n > 0) {
@@ -546,7 +546,8 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
 #undef EGS_PRE
     EGS_LAUNCH_OK();
   }
-  return egs_splat_bin(n, width, height, us, areas, depths, pol, ws_bin, ws_bin_bytes, total_patches, stream);
+  return egs_splat_bin(n, width, height, us, areas, depths, pol, key_bits_hint, ws_bin, ws_bin_bytes,
+                       total_patches, stream);
 }
 
 extern "C" size_t egs_fused_backward_ws_bytes(int n) { return egs_splat_bwd_ws_bytes(n); }

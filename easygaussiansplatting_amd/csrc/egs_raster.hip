@@ -355,7 +355,8 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
   if (threadIdx.x == 0) maxkey[1 + blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
 }
 
-__global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __restrict__ maxkey) {
+__global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __restrict__ maxkey,
+                                                    uint32_t* __restrict__ maxkey_out) {
   __shared__ uint32_t wm[4];
   uint32_t mk = 0u;
   for (int i = threadIdx.x; i < nparts; i += 256) mk = max(mk, maxkey[1 + i]);
@@ -363,7 +364,11 @@ __global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __rest
   for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
   __syncthreads();
-  if (threadIdx.x == 0) maxkey[0] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+  if (threadIdx.x == 0) {
+    const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+    maxkey[0] = m;
+    maxkey_out[0] = m;  // returned to the host next to P: it sizes the next call's sort
+  }
 }
 
 // createKeys (reference kernel.cu:46-80) in depth-sorted Gaussian order; the
@@ -973,13 +978,13 @@ extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int
 }
 
 extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas, float* depths,
-                             const EgsPolicy* pol, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                             void* stream) {
+                             const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                             uint32_t* total_patches, void* stream) {
   EGS_CHECK_ARG(n >= 0 && width > 0 && height > 0 && pol && total_patches);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {  // the reference dereferences patch_offset_per_gs[-1] here (gausplat.cu:67)
-    EGS_HIP(hipMemsetAsync(total_patches, 0, 4, s));
+    EGS_HIP(hipMemsetAsync(total_patches, 0, 8, s));
     return 0;
   }
   EGS_CHECK_ARG(us && areas && depths && ws_bin);
@@ -995,12 +1000,21 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
   p.mutate = (pol->footprint == 0);
   EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rects,
              L.counts, L.dkeys, L.ids, L.maxkey);
-  EGS_LAUNCH("k_max_reduce", k_max_reduce, dim3(1), dim3(256), s, div_up(n, 256), L.maxkey);
+  EGS_LAUNCH("k_max_reduce", k_max_reduce, dim3(1), dim3(256), s, div_up(n, 256), L.maxkey, total_patches + 1);
   EGS_LAUNCH_OK();
   // 4 passes (even): the sorted (dkeys, ids) end up in the primary buffers; passes over digits
   // that are zero in every key (mm depth keys rarely need more than 16 bits) are plain copies
-  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, 32, L.sort, s, L.maxkey);
+  // Only the depth-key bits the caller expects to be significant are sorted (hint from the previous
+  // call's max key, which comes back in total_patches[1]); if the hint turns out too small the
+  // caller re-runs this function with hint = 32.  Within the launched passes, digits that are zero
+  // in every key still degenerate to copies (maxkey check on the device).
+  int end_bit = (key_bits_hint <= 0 || key_bits_hint > 32) ? 32 : ((key_bits_hint + 7) / 8) * 8;
+  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey);
   if (rc) return rc;
+  if (sort_passes(0, end_bit) & 1) {  // odd pass count: bring the result back to the primary buffers
+    EGS_HIP(hipMemcpyAsync(L.dkeys, L.dkeys_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    EGS_HIP(hipMemcpyAsync(L.ids, L.ids_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+  }
   return exclusive_scan(n, L.counts, L.ids, L.offsets, total_patches, L.scan_partials, s);
 }
 

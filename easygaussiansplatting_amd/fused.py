@@ -18,7 +18,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from .gsplatcu import _alphas, _chk, _lib_on, _pol, _ptr, _stream, _tiles
+from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _tiles
 
 
 class FusedState:
@@ -58,19 +58,15 @@ def forward(pws, shs, alphas, scales, rots, cam):
     S.rec = torch.empty((max(n, 1), 12), dtype=f32, device=dev)   # packed 2D records, reused by backward
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
-    total = torch.empty(1, dtype=i32, device=dev)
-    _lib.check(lib.egs_fused_forward(n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(alphas), _ptr(Rcw),
-                                     _ptr(tcw), _ptr(twc), float(cam.fx), float(cam.fy), float(cam.cx),
-                                     float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
-                                     _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(ws_bin), ws_bin_bytes,
-                                     _ptr(total), st))
+    patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward(
+        n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc),
+        float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths),
+        _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), hint, _ptr(ws_bin), ws_bin_bytes,
+        _ptr(total), st)))
     image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
     S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
     S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
-    patches = int(total.item()) & 0xFFFFFFFF                     # the one 4-byte read-back (gausplat.cu:67)
-    if patches >= 2**31:
-        raise RuntimeError("splat: %d tile patches overflow int32 indexing" % patches)
     S.gsid = torch.empty(patches, dtype=i32, device=dev)
     ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, W, H)
     ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)

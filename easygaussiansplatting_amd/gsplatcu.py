@@ -190,6 +190,29 @@ def inverseCov2D(cov2ds, depths, calc_J):
     return [cinv, areas, J] if calc_J else [cinv, areas]
 
 
+_key_bits_hint = 32   # learned from the previous call (depth keys rarely need more than 16 bits)
+
+
+def _bin_stage(enqueue):
+    """Run the binning stage with the depth-key bit-count hint protocol of egs_splat_bin:
+    ``enqueue(hint, total)`` enqueues the stage; returns the patch count P.  The single
+    8-byte read-back (reference: gausplat.cu:67) also brings the largest depth key, which
+    sizes the next call's sort; a too-small hint triggers one full-width re-run."""
+    global _key_bits_hint
+    total = torch.empty(2, dtype=torch.int32, device="cuda")
+    hint = _key_bits_hint
+    enqueue(hint, total)
+    p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
+    need = mk.bit_length()
+    if hint < 32 and need > ((hint + 7) // 8) * 8:
+        enqueue(32, total)
+        p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
+    _key_bits_hint = min(32, need + 1)
+    if p >= 2**31:
+        raise RuntimeError("splat: %d tile patches overflow int32 indexing" % p)
+    return p
+
+
 def _tiles(width, height):
     return ((width + 15) // 16) * ((height + 15) // 16)
 
@@ -224,13 +247,10 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     ranges = torch.empty((_tiles(width, height), 2), dtype=torch.int32, device=dev)
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
-    total = torch.empty(1, dtype=torch.int32, device=dev)
     st = _stream()
-    _lib.check(lib.egs_splat_bin(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, _ptr(ws_bin),
-                                 ws_bin_bytes, _ptr(total), st))
-    patches = int(total.item()) & 0xFFFFFFFF      # the one 4-byte read-back (reference: gausplat.cu:67)
-    if patches >= 2**31:
-        raise RuntimeError("splat: %d tile patches overflow int32 indexing" % patches)
+    patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_splat_bin(
+        n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
+        _ptr(total), st)))
     gsid = torch.empty(patches, dtype=torch.int32, device=dev)
     ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
     ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)

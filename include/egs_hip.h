@@ -112,10 +112,15 @@ size_t egs_splat_bin_ws_bytes(int n);
 size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height);
 
 /* us[N,2], areas[N,2] (IN/OUT), depths[N] (IN/OUT) ; ws_bin must stay alive until
- * egs_splat_draw() has been enqueued.  total_patches: device uint32. */
+ * egs_splat_draw() has been enqueued.
+ * total_patches: device uint32[2] -- [0] = P, [1] = the largest depth key of this call.
+ * key_bits_hint: number of low depth-key bits to sort (0 or 32 = all).  A caller that passes a
+ *   smaller hint (e.g. bit_length of the previous call's max key + 1) MUST check
+ *   total_patches[1] < 2^hint after the read-back and, if not, call egs_splat_bin again with
+ *   hint 32 (the call is idempotent). */
 int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas, float* depths,
-                  const EgsPolicy* pol, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                  void* stream);
+                  const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                  uint32_t* total_patches, void* stream);
 
 /* patches = the value read back from total_patches.  Outputs, all fully written here (no
  * zero-fill needed): image[3,H,W], contrib[H,W] int32, final_tau[H,W] (empty tiles get
@@ -180,8 +185,8 @@ int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, co
                       const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                       const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                       const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                      int32_t* areas, void* rec, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                      void* stream);
+                      int32_t* areas, void* rec, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                      uint32_t* total_patches, void* stream);
 int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,

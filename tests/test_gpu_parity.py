@@ -539,3 +539,20 @@ def test_full_size_forward_cpu_reference_digest(gsc, big):
         assert d.max() < 2e-2
     assert bad <= 64, bad                                             # depth-order swaps / box-edge flips (of 16384 px)
     assert abs(image.mean() - float(g6["image_mean"])) < 1e-6
+
+
+def test_depth_key_bit_hint_protocol(gsc):
+    """A too-small depth-key hint (stale from a previous, shallower call) must be detected from
+    the returned max key and repaired by a full-width re-run: lists stay bit-exact."""
+    from easygaussiansplatting_amd import gsplatcu as mod
+    sc = S.small_scene(6000, 128, 128, 3, seed=21)
+    cam = sc.cam
+    for hint in (1, 8, 32, 11):
+        g = gpu_stages(gsc, sc, False, "gsplatcu")
+        mod._key_bits_hint = hint
+        out = gsc.splat(cam.height, cam.width, g["us"], g["cinv2ds"], g["alphas"], g["depths"], g["colors"],
+                        g["areas"])
+        o_ranges, o_gsid, _, _ = O.bin_tiles(host(g["us"]), host(g["areas"]).copy(), host(g["depths"]).copy(),
+                                             cam.width, cam.height, O.POLICY_G)
+        assert np.array_equal(host(out[3]), o_ranges) and np.array_equal(host(out[4]), o_gsid), hint
+        assert 8 <= mod._key_bits_hint <= 16      # depth 3..7 m -> mm keys of 12-13 bits (+1 margin)
