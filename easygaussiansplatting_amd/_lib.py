@@ -59,6 +59,8 @@ SIGNATURES = {
     "egs_fused_backward_ws_bytes": (_sz, [_i]),
     "egs_fused_backward": (_i, [_i, _i, _i64, _i, _i] + [_P] * 8 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
                            + [_P] * 6 + [_P]),
+    "egs_gau_loss_ws_bytes": (_sz, [_i, _i]),
+    "egs_gau_loss": (_i, [_i, _i, _P, _P, _f, _f, _P, _sz, _P, _P, _P]),
     "egs_prof_enable": (_i, [_i]),
     "egs_prof_set_filter": (None, [C.c_char_p]),
     "egs_prof_reset": (None, []),

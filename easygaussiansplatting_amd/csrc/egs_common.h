@@ -57,6 +57,12 @@ struct ProfScope {
     ::egs::ProfScope ps__(name, stream);                                 \
     hipLaunchKernelGGL(kern, grid, block, 0, stream, __VA_ARGS__);       \
   } while (0)
+// same with `lds` bytes of dynamic LDS (used only to cap residency: see k_draw launch)
+#define EGS_LAUNCH_LDS(name, kern, grid, block, lds, stream, ...)        \
+  do {                                                                   \
+    ::egs::ProfScope ps__(name, stream);                                 \
+    hipLaunchKernelGGL(kern, grid, block, lds, stream, __VA_ARGS__);     \
+  } while (0)
 
 static inline int div_up(int64_t a, int64_t b) { return (int)((a + b - 1) / b); }
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

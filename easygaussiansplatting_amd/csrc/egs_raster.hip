@@ -467,6 +467,15 @@ __device__ __forceinline__ int xcd_tile(int b, const DrawParams& p) {
   const int ty = xcd + 8 * (k / p.gx), tx = k % p.gx;
   return ty < p.gy ? ty * p.gx + tx : -1;
 }
+// Dynamic LDS requested only to CAP the number of resident tile-waves per CU (experiment knobs
+// EGS_DRAW_LDS_PAD / EGS_DRAWB_LDS_PAD, bytes): fewer resident waves let the dispatcher hand the
+// remaining tiles to whichever SIMD drains first (dynamic load balance).
+static size_t draw_lds_pad(int which) {
+  static const size_t pad[2] = {
+      [] { const char* e = getenv("EGS_DRAW_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }(),
+      [] { const char* e = getenv("EGS_DRAWB_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }()};
+  return pad[which];
+}
 static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(p.gy, 8) * p.gx : p.T; }
 
 // Policy is compiled in (BOX: pixel-box footprint; FLOOR: max(0,m); CLAMP: min(0.99,.));
@@ -1066,8 +1075,8 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                      patch_range_per_tile);
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                        \
-  EGS_LAUNCH("k_draw", (k_draw<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile,     \
-             gsid_per_patch, rec, image, contrib, final_tau)
+  EGS_LAUNCH_LDS("k_draw", (k_draw<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), draw_lds_pad(0), s, dp, \
+                 patch_range_per_tile, gsid_per_patch, rec, image, contrib, final_tau)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {
     case 0: EGS_DRAW(false, false, false); break;
@@ -1127,8 +1136,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
-  EGS_LAUNCH("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), s, dp, patch_range_per_tile, \
-             gsid_per_patch, rec, cinv2ds, final_tau, contrib, dloss_dgammas, gpack)
+  EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), draw_lds_pad(1), s, \
+                 dp, patch_range_per_tile, gsid_per_patch, rec, cinv2ds, final_tau, contrib, dloss_dgammas, gpack)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {
     case 0: EGS_DRAWB(false, false, false); break;

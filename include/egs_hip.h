@@ -203,6 +203,17 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
                        float* dloss_drots, float* dloss_dus, void* stream);
 
+/* ---- fused training loss -----------------------------------------
+ * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the
+ * 11x11 Gaussian window (sigma 1.5, zero padding) of reference gsplat/pytorch_ssim.py:10-66.
+ * image, gt_image: [3,H,W].  loss_out: device float[3] = {loss, l1, ssim}.  dloss_dimage
+ * (nullable) [3,H,W] receives grad_scale * dloss/dimage -- exactly the dloss_dgammas that
+ * splatB / egs_fused_backward consume. */
+size_t egs_gau_loss_ws_bytes(int height, int width);
+int egs_gau_loss(int height, int width, const float* image, const float* gt_image, float loss_lambda,
+                 float grad_scale, void* ws, size_t ws_bytes, float* loss_out, float* dloss_dimage,
+                 void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream ---------------
  * bench.py's `roofline` leg: when enabled, every kernel launch of this library
  * is bracketed by hipEventRecord on the stream it is launched on.

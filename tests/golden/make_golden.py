@@ -273,12 +273,35 @@ def g6():
          image_mean=np.array(img.mean()), image_absmax=np.array(np.abs(img).max()))
 
 
+def g7():
+    """gsplat/pytorch_ssim.py gau_loss + torch autograd gradient (CPU) on seeded image pairs."""
+    import torch
+    import gsplat.pytorch_ssim as ref_l
+    out = {}
+    for tag, (H, W) in (("a", (37, 53)), ("b", (16, 64)), ("c", (9, 7))):
+        x = (0.5 + 0.35 * S.normal(31, 1, (3, H, W))).astype(np.float32)
+        y = np.clip(x + 0.15 * S.normal(31, 2, (3, H, W)), 0, 1).astype(np.float32)
+        y[:, : H // 3] = x[:, : H // 3]                     # identical region: sign(0) = 0 branch of |x-y|
+        xt = torch.from_numpy(x).double().requires_grad_(True)
+        yt = torch.from_numpy(y).double()
+        loss = ref_l.gau_loss(xt, yt)
+        loss.backward()
+        out["x_" + tag] = x; out["y_" + tag] = y
+        out["loss_" + tag] = loss.detach().numpy(); out["grad_" + tag] = xt.grad.numpy()
+        out["ssim_" + tag] = ref_l.ssim(xt.detach(), yt).numpy()
+        xf = torch.from_numpy(x).requires_grad_(True)
+        lf = ref_l.gau_loss(xf, torch.from_numpy(y)); lf.backward()
+        out["loss32_" + tag] = lf.detach().numpy(); out["grad32_" + tag] = xf.grad.numpy()
+    save("g7_gau_loss.npz", "reference gsplat/pytorch_ssim.py gau_loss(image, gt) and d loss/d image by torch "
+         "autograd (float64 and float32, CPU) on three seeded [3,H,W] image pairs", **out)
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--g6", action="store_true", help="also run the 1M/1080p reference forward (~1 min)")
     a = ap.parse_args()
-    todo = [g1, g2, g3, g4, g5] + ([g6] if a.g6 else [])
+    todo = [g1, g2, g3, g4, g5, g7] + ([g6] if a.g6 else [])
     for fn in todo:
         if a.only and fn.__name__ not in a.only.split(","):
             continue

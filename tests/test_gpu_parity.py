@@ -556,3 +556,49 @@ def test_depth_key_bit_hint_protocol(gsc):
                                              cam.width, cam.height, O.POLICY_G)
         assert np.array_equal(host(out[3]), o_ranges) and np.array_equal(host(out[4]), o_gsid), hint
         assert 8 <= mod._key_bits_hint <= 16      # depth 3..7 m -> mm keys of 12-13 bits (+1 margin)
+
+
+# --------------------------------------------------------------------------- fused loss
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_gau_loss_vs_reference_fixture(gsc, tag):
+    """HIP gau_loss vs the reference's pytorch_ssim.gau_loss + torch autograd (fixture G7)."""
+    from easygaussiansplatting_amd.loss import gau_loss, gau_loss_with_grad
+    g = load_golden("g7_gau_loss.npz")
+    x = dev(g["x_" + tag]).requires_grad_(True); y = dev(g["y_" + tag])
+    loss = gau_loss(x, y)
+    assert loss.dim() == 0
+    (2.5 * loss).backward()
+    assert abs(float(loss.detach()) - float(g["loss_" + tag])) < 1e-5
+    ref = 2.5 * g["grad_" + tag]
+    assert np.abs(host(x.grad) - ref).max() < 1e-4 * np.abs(ref).max()
+    stats, _ = gau_loss_with_grad(x.detach(), y, 0.2, need_grad=False)
+    assert abs(float(stats[2]) - float(g["ssim_" + tag])) < 1e-5
+
+
+def test_gau_loss_full_hd_vs_oracle_and_torch(gsc):
+    from easygaussiansplatting_amd.loss import gau_loss
+    H, W = 1080, 1920
+    x = (0.5 + 0.3 * S.normal(2, 1, (3, H, W))).astype(np.float32)
+    y = np.clip(x + 0.1 * S.normal(2, 2, (3, H, W)), 0, 1).astype(np.float32)
+    xt = dev(x).requires_grad_(True)
+    loss = gau_loss(xt, dev(y))
+    loss.backward()
+    # plain PyTorch fp32 reference of the same op on the device (five depthwise convs + autograd)
+    import torch.nn.functional as F
+    gw = torch.from_numpy(O.ssim_window().astype(np.float32)).cuda()
+    w2 = (gw[:, None] @ gw[None, :]).expand(3, 1, 11, 11).contiguous()
+    xr = dev(x).requires_grad_(True); yr = dev(y)
+    conv = lambda t: F.conv2d(t, w2, padding=5, groups=3)
+    mu1, mu2 = conv(xr), conv(yr)
+    s11 = conv(xr * xr) - mu1 * mu1; s22 = conv(yr * yr) - mu2 * mu2; s12 = conv(xr * yr) - mu1 * mu2
+    ss = ((2 * mu1 * mu2 + 1e-4) * (2 * s12 + 9e-4)) / ((mu1 * mu1 + mu2 * mu2 + 1e-4) * (s11 + s22 + 9e-4))
+    lr = 0.8 * (xr - yr).abs().mean() + 0.2 * (1 - ss.mean())
+    lr.backward()
+    assert abs(float(loss) - float(lr)) < 2e-6
+    gmax = float(xr.grad.abs().max())
+    assert float((xt.grad - xr.grad).abs().max()) < 2e-4 * gmax
+    # and the float64 oracle on a crop that includes two image borders
+    lo, go, _ = O.gau_loss(x[:, :40, :70], y[:, :40, :70], 0.2, calc_grad=True)
+    xc = dev(x[:, :40, :70]).requires_grad_(True)
+    lc = gau_loss(xc, dev(y[:, :40, :70])); lc.backward()
+    assert abs(float(lc) - lo) < 1e-5 and np.abs(host(xc.grad) - go).max() < 1e-4 * np.abs(go).max()

@@ -231,3 +231,15 @@ def test_g6_digest_sampled_tiles_policy_a():
                            areas, P, tiles=[int(t)])
         tile = img[:, ty * 16:ty * 16 + 16, tx * 16:tx * 16 + 16].transpose(1, 2, 0)
         assert np.abs(tile - ref_tile).max() < 1e-4
+
+
+# ------------------------------------------------------------------ G7: training loss (pytorch_ssim.gau_loss)
+@pytest.mark.parametrize("tag", ["a", "b", "c"])
+def test_g7_gau_loss_and_gradient(tag):
+    g = load_golden("g7_gau_loss.npz")
+    loss, grad, aux = O.gau_loss(g["x_" + tag], g["y_" + tag], 0.2, calc_grad=True)
+    np.testing.assert_allclose(loss, g["loss_" + tag], rtol=1e-7)        # window built in float32 in the reference
+    np.testing.assert_allclose(aux["ssim"], g["ssim_" + tag], rtol=1e-7)
+    scale = np.abs(g["grad_" + tag]).max()
+    assert np.abs(grad - g["grad_" + tag]).max() < 1e-6 * scale
+    assert (grad[:, : g["x_" + tag].shape[1] // 3] != 0).any()          # SSIM part acts where |x-y| = 0
