@@ -1,0 +1,131 @@
+"""Data-parallel training step: the counterpart of the reference's ``train.py:30-83``
+on the MI355X path (SURVEY.md §8a', §8e).
+
+What it keeps from the reference
+* the raw parameterisation and activations (gsplat/utils.py:121-150: sigmoid alphas,
+  exp scales, normalised quaternions, SH = cat(low, high); gsmodel.py:96-129);
+* Adam with the reference's per-group learning rates (gsmodel.py:114-127) and
+  eps = 1e-15 (train.py:32), the exponential position-lr schedule (utils.py:7-44);
+* the loss 0.8 L1 + 0.2 (1 - SSIM) (pytorch_ssim.py:63-66) -- through the fused HIP loss;
+* checkpoints as a structured ``.npy`` of ACTIVATED parameters with the reference's
+  record dtype (gau_io.py:7-12, 141-156).
+
+What is new (the reference renders one view per optimizer step on one GPU)
+* a step renders ``views_per_step`` views: each rank takes its share
+  (dist_views.views_for_rank), accumulates the mean gradient over its local views,
+  then ONE RCCL all-reduce (mean) of the 59 gradient floats per Gaussian and one
+  all-reduce (sum) of the densification statistics.  Densification itself
+  (gsmodel.py:232-331) is out of scope here.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Sequence
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import dist_views as DV
+from .function import Camera, GSFunction
+from .loss import gau_loss
+from .scene import gsdata_type
+
+SH_C0 = 0.28209479177387814
+
+
+def expon_lr(step, lr_init, lr_final, max_steps, delay_steps=0, delay_mult=1.0):
+    """Log-linear learning-rate decay with optional warm-up (restates utils.py:7-44)."""
+    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
+        return 0.0
+    rate = 1.0
+    if delay_steps > 0:
+        rate = delay_mult + (1 - delay_mult) * math.sin(0.5 * math.pi * min(max(step / delay_steps, 0.0), 1.0))
+    t = min(max(step / max_steps, 0.0), 1.0)
+    return rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
+
+
+def raw_params_from_scene(scene, device="cuda") -> Dict[str, torch.Tensor]:
+    """gsmodel.py:96-113: un-activated leaf tensors; SH split into degree 0 (low) and the rest (high)."""
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
+    shs = t(scene.shs)
+    n = shs.shape[0]
+    high = torch.full((n, 45), 0.001, device=device)
+    if shs.shape[1] > 3:
+        high[:, : shs.shape[1] - 3] = shs[:, 3:]
+    alphas = t(scene.alphas).reshape(-1, 1).clamp(1e-4, 1 - 1e-4)
+    p = {"pws": t(scene.pws), "low_shs": shs[:, :3].contiguous(), "high_shs": high,
+         "alphas_raw": torch.log(alphas / (1 - alphas)), "scales_raw": torch.log(t(scene.scales)),
+         "rots_raw": t(scene.rots)}
+    for v in p.values():
+        v.requires_grad_(True)
+    return p
+
+
+def activate(p):
+    """utils.py:129-150 / gsmodel.py:198-207."""
+    return (p["pws"], torch.cat((p["low_shs"], p["high_shs"]), dim=1), torch.sigmoid(p["alphas_raw"]),
+            torch.exp(p["scales_raw"]), torch.nn.functional.normalize(p["rots_raw"]))
+
+
+def make_optimizer(p):
+    groups = [("pws", 0.001), ("low_shs", 0.001), ("high_shs", 0.001 / 20), ("alphas_raw", 0.05),
+              ("scales_raw", 0.005), ("rots_raw", 0.001)]          # gsmodel.py:114-127
+    return torch.optim.Adam([{"params": [p[k]], "lr": lr, "name": k} for k, lr in groups], lr=0.0, eps=1e-15)
+
+
+class Trainer:
+    def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
+                 scene_size: float = 1.0, device="cuda"):
+        self.device = device
+        self.params = raw_params_from_scene(scene, device)
+        self.opt = make_optimizer(self.params)
+        self.cams = [c if isinstance(c, Camera) else Camera.from_scene(c, device) for c in cameras]
+        self.gts = list(gt_images)
+        self.max_steps = max_steps
+        self.scene_size = scene_size
+        self.iteration = 0
+        self.world = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+        n = self.params["pws"].shape[0]
+        self.grad_accum = torch.zeros(n, device=device)             # gsmodel.py:214-230 statistics
+        self.vis_count = torch.zeros(n, dtype=torch.int32, device=device)
+
+    def step(self, view_ids: Sequence[int]) -> float:
+        """One optimizer step on the mean gradient over ``view_ids`` (all ranks pass the same list)."""
+        mine = [view_ids[i] for i in DV.views_for_rank(len(view_ids), self.rank, self.world)]
+        self.opt.zero_grad(set_to_none=True)
+        n = self.params["pws"].shape[0]
+        loss_sum = torch.zeros((), device=self.device)
+        gnorm = torch.zeros(n, device=self.device)
+        count = torch.zeros(n, dtype=torch.int32, device=self.device)
+        for v in mine:
+            us = torch.zeros((n, 2), device=self.device, requires_grad=True)     # gsmodel.py:198-199
+            image, mask = GSFunction.apply(*activate(self.params), us, self.cams[v])
+            loss = gau_loss(image, self.gts[v])
+            (loss / len(view_ids)).backward()           # leaves accumulate the mean over ALL views of the step
+            loss_sum += loss.detach()
+            with torch.no_grad():                       # per-view ||dL/du|| (undo the 1/len scaling)
+                g = torch.norm(us.grad * len(view_ids), dim=-1)
+                gnorm += torch.where(mask, g, torch.zeros_like(g))
+                count += mask.to(torch.int32)
+        if self.world > 1:   # sum over ranks of (sum over local views)/V == mean over all views
+            DV.allreduce_sum_([self.params[k].grad for k in self.params] + [gnorm, count, loss_sum])
+        self.grad_accum += gnorm
+        self.vis_count += count
+        self.opt.step()
+        lr = expon_lr(self.iteration, 1e-4 * self.scene_size, 1e-6 * self.scene_size, self.max_steps,
+                      delay_mult=0.01)                                           # gsmodel.py:180-183, 332-338
+        for gparam in self.opt.param_groups:
+            if gparam["name"] == "pws":
+                gparam["lr"] = lr
+        self.iteration += 1
+        return float(loss_sum) / len(view_ids)
+
+    def save(self, fn: str) -> np.ndarray:
+        """Checkpoint of ACTIVATED parameters, dtype == gau_io.py:7-12 (gau_io.py:141-156)."""
+        with torch.no_grad():
+            pws, shs, alphas, scales, rots = (x.detach().cpu().numpy() for x in activate(self.params))
+        gs = np.rec.fromarrays([pws, rots, scales, alphas.reshape(-1), shs], dtype=gsdata_type(shs.shape[1]))
+        np.save(fn, gs)
+        return gs

@@ -602,3 +602,29 @@ def test_gau_loss_full_hd_vs_oracle_and_torch(gsc):
     xc = dev(x[:, :40, :70]).requires_grad_(True)
     lc = gau_loss(xc, dev(y[:, :40, :70])); lc.backward()
     assert abs(float(lc) - lo) < 1e-5 and np.abs(host(xc.grad) - go).max() < 1e-4 * np.abs(go).max()
+
+
+# --------------------------------------------------------------------------- training-loop counterpart (train.py)
+def test_trainer_loss_decreases_and_checkpoint_format(gsc, tmp_path):
+    """train.py:30-83 counterpart: multi-view steps with the fused raster + fused loss reduce the loss;
+    the checkpoint has the reference's record dtype (gau_io.py:7-12)."""
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer, activate
+    gsc.set_policy("gsplatcu")
+    sc = S.small_scene(3000, 96, 64, 48, seed=17)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 4, radius=5.0)]
+    with torch.no_grad():
+        gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+    start = S.small_scene(3000, 96, 64, 48, seed=17)
+    start.shs[:, :3] += 0.8 * S.normal(5, 3, (3000, 3)).astype(np.float32)      # wrong base colours
+    start.alphas[:] = np.clip(start.alphas * 0.6, 0.05, 0.9)
+    tr = Trainer(start, cams, gts, max_steps=200, scene_size=4.0)
+    losses = [tr.step([0, 1, 2, 3]) for _ in range(40)]
+    assert all(np.isfinite(losses))
+    assert losses[-1] < 0.6 * losses[0], (losses[0], losses[-1])
+    assert int(tr.vis_count.max()) == 4 * 40
+    gs = tr.save(str(tmp_path / "epoch0000.npy"))
+    back = np.load(str(tmp_path / "epoch0000.npy"))
+    assert back.dtype == np.dtype(S.gsdata_type(48)) and back.shape == (3000,)
+    assert np.allclose(np.linalg.norm(back["rot"], axis=1), 1, atol=1e-5)
+    assert (back["alpha"] > 0).all() and (back["alpha"] < 1).all() and (back["scale"] > 0).all()
