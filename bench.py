@@ -237,6 +237,27 @@ def main():
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
 
+    # informative extra (outside the timed region): render + fused L1/SSIM loss + backward, i.e. a
+    # training step without the optimizer (the torch loss of the reference costs 10.9 ms at 1080p)
+    from easygaussiansplatting_amd.loss import gau_loss
+    gt = torch.rand((3, a.height, a.width), device=dev)
+
+    def step_with_loss():
+        for p in params.values():
+            p.grad = None
+        us0.grad = None
+        img, _ = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
+                                  params["rots"], us0, cam)
+        gau_loss(img, gt).backward()
+    for _ in range(2):
+        step_with_loss()
+    torch.cuda.synchronize()
+    tl0 = time.perf_counter()
+    for _ in range(nf):
+        step_with_loss()
+    torch.cuda.synchronize()
+    loss_step_ms = (time.perf_counter() - tl0) / nf * 1e3
+
     roofline = None
     if prof:
         rep = read_report()          # only the dominant kernel, recorded over the timed region
@@ -278,6 +299,8 @@ def main():
                        "views_per_step": world, "policy": "gsplatcu", "mode": a.mode,
                        "patches": P, "tiles": T, "max_list_len": max_len, "pixel_gaussian_pairs": pairs},
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
+            "fwd_loss_bwd": {"ms": round(loss_step_ms, 4),
+                             "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         if cpu:
