@@ -24,8 +24,20 @@ class EgsPolicy(C.Structure):
                 ("alpha_skip", C.c_float), ("tau_stop", C.c_float), ("depth_key", C.c_int32)]
 
 
+class EgsGaussianParams(C.Structure):
+    """Mirror of `struct EgsGaussianParams`: device pointers of the six training tensors (or their moments)."""
+    _fields_ = [(k, C.c_void_p) for k in ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")]
+
+
+class EgsAdamGroup(C.Structure):
+    """Mirror of `struct EgsAdamGroup`."""
+    _fields_ = [("param", C.c_void_p), ("grad", C.c_void_p), ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+                ("count", C.c_int64), ("lr", C.c_float), ("step", C.c_int32)]
+
+
 _P = C.c_void_p
 _PP = C.POINTER(EgsPolicy)
+_PG = C.POINTER(EgsGaussianParams)
 _f = C.c_float
 _i = C.c_int
 _i64 = C.c_int64
@@ -61,6 +73,13 @@ SIGNATURES = {
                            + [_P] * 6 + [_P]),
     "egs_gau_loss_ws_bytes": (_sz, [_i, _i]),
     "egs_gau_loss": (_i, [_i, _i, _P, _P, _f, _f, _P, _sz, _P, _P, _P]),
+    "egs_density_accumulate": (_i, [_i, _P, _P, _i, _P, _P, _P]),
+    "egs_densify_ws_bytes": (_sz, [_i]),
+    "egs_densify_plan": (_i, [_i, _P, _P, _P, _P, _f, _f, _f, _f, _P, _P, _sz, _P, _P]),
+    "egs_densify_apply": (_i, [_i, _i, _i, _i, _i, _P, _P, _PG, _PG, _PG, _PG, _PG, _PG, _P, C.c_uint64,
+                               C.c_uint64, _P]),
+    "egs_reset_alpha": (_i, [_i, _f, _P, _P, _P, _P]),
+    "egs_adam_step": (_i, [_i, C.POINTER(EgsAdamGroup), C.c_double, C.c_double, C.c_double, _P]),
     "egs_prof_enable": (_i, [_i]),
     "egs_prof_set_filter": (None, [C.c_char_p]),
     "egs_prof_reset": (None, []),

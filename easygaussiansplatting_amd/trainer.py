@@ -14,8 +14,11 @@ What is new (the reference renders one view per optimizer step on one GPU)
 * a step renders ``views_per_step`` views: each rank takes its share
   (dist_views.views_for_rank), accumulates the mean gradient over its local views,
   then ONE RCCL all-reduce (mean) of the 59 gradient floats per Gaussian and one
-  all-reduce (sum) of the densification statistics.  Densification itself
-  (gsmodel.py:232-331) is out of scope here.
+  all-reduce (sum) of the densification statistics;
+* the optimizer is ``optim.FusedAdam`` (one HIP launch for all six groups) unless
+  ``fused_adam=False``; densification / alpha reset (gsmodel.py:232-330) run on the device
+  through ``density.DensityControl`` and are replica-consistent: every rank holds the same
+  all-reduced statistics and the split offsets are a pure function of (seed, round, row).
 """
 from __future__ import annotations
 
@@ -27,22 +30,13 @@ import torch
 import torch.distributed as dist
 
 from . import dist_views as DV
+from .density import DensityControl, expon_lr
 from .function import Camera, GSFunction
 from .loss import gau_loss
+from .optim import FusedAdam, adam_groups
 from .scene import gsdata_type
 
 SH_C0 = 0.28209479177387814
-
-
-def expon_lr(step, lr_init, lr_final, max_steps, delay_steps=0, delay_mult=1.0):
-    """Log-linear learning-rate decay with optional warm-up (restates utils.py:7-44)."""
-    if step < 0 or (lr_init == 0.0 and lr_final == 0.0):
-        return 0.0
-    rate = 1.0
-    if delay_steps > 0:
-        rate = delay_mult + (1 - delay_mult) * math.sin(0.5 * math.pi * min(max(step / delay_steps, 0.0), 1.0))
-    t = min(max(step / max_steps, 0.0), 1.0)
-    return rate * math.exp(math.log(lr_init) * (1 - t) + math.log(lr_final) * t)
 
 
 def raw_params_from_scene(scene, device="cuda") -> Dict[str, torch.Tensor]:
@@ -68,18 +62,19 @@ def activate(p):
             torch.exp(p["scales_raw"]), torch.nn.functional.normalize(p["rots_raw"]))
 
 
-def make_optimizer(p):
-    groups = [("pws", 0.001), ("low_shs", 0.001), ("high_shs", 0.001 / 20), ("alphas_raw", 0.05),
-              ("scales_raw", 0.005), ("rots_raw", 0.001)]          # gsmodel.py:114-127
-    return torch.optim.Adam([{"params": [p[k]], "lr": lr, "name": k} for k, lr in groups], lr=0.0, eps=1e-15)
+def make_optimizer(p, fused=True):
+    """train.py:32 over the groups of gsmodel.py:114-127."""
+    cls = FusedAdam if fused else torch.optim.Adam
+    return cls(adam_groups(p), lr=0.0, eps=1e-15)
 
 
 class Trainer:
     def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
-                 scene_size: float = 1.0, device="cuda"):
+                 scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0):
         self.device = device
         self.params = raw_params_from_scene(scene, device)
-        self.opt = make_optimizer(self.params)
+        self.opt = make_optimizer(self.params, fused_adam)
+        self.density = DensityControl(scene_size, max_steps, seed)
         self.cams = [c if isinstance(c, Camera) else Camera.from_scene(c, device) for c in cameras]
         self.gts = list(gt_images)
         self.max_steps = max_steps
@@ -114,13 +109,46 @@ class Trainer:
         self.grad_accum += gnorm
         self.vis_count += count
         self.opt.step()
-        lr = expon_lr(self.iteration, 1e-4 * self.scene_size, 1e-6 * self.scene_size, self.max_steps,
-                      delay_mult=0.01)                                           # gsmodel.py:180-183, 332-338
-        for gparam in self.opt.param_groups:
-            if gparam["name"] == "pws":
-                gparam["lr"] = lr
+        self.density.update_pws_lr(self.opt)                                     # gsmodel.py:180-183, 332-338
         self.iteration += 1
         return float(loss_sum) / len(view_ids)
+
+    def densify(self, verbose: bool = False):
+        """Prune / clone / split on the statistics gathered since the last call (train.py:71-73 ->
+        gsmodel.py:232-317).  Identical on every rank (statistics are already all-reduced)."""
+        self.density.set_density_info(self.grad_accum, self.vis_count)
+        report = self.density.update_gaussian_density(self.params, self.opt, verbose=verbose)
+        n = self.params["pws"].shape[0]
+        self.grad_accum = torch.zeros(n, device=self.device)
+        self.vis_count = torch.zeros(n, dtype=torch.int32, device=self.device)
+        return report
+
+    def reset_alpha(self):
+        """train.py:74-76 -> gsmodel.py:319-330."""
+        self.density.reset_alpha(self.params, self.opt)
+
+    def fit(self, epochs: int, views_per_step: int = None, rng_seed: int = 0, densify_every: int = 5,
+            reset_alpha_every: int = 15, densify_until: int = 50, verbose: bool = False) -> List[float]:
+        """The epoch loop of train.py:44-80: shuffled views, ``views_per_step`` views per optimizer step
+        (1 in the reference), densification every 5th and alpha reset every 15th epoch in (1, 50]."""
+        vps = views_per_step or self.world
+        order_rng = np.random.default_rng(rng_seed)            # same permutation on every rank
+        history = []
+        for epoch in range(epochs):
+            idxs = order_rng.permutation(len(self.cams))
+            total, steps = 0.0, 0
+            for i in range(0, len(idxs) - vps + 1, vps):
+                total += self.step([int(v) for v in idxs[i:i + vps]])
+                steps += 1
+            history.append(total / max(steps, 1))
+            if verbose and self.rank == 0:
+                print("epoch:%d avg_loss:%f" % (epoch, history[-1]))
+            if 1 < epoch <= densify_until:
+                if epoch % densify_every == 0:
+                    self.densify(verbose and self.rank == 0)
+                if epoch % reset_alpha_every == 0:
+                    self.reset_alpha()
+        return history
 
     def save(self, fn: str) -> np.ndarray:
         """Checkpoint of ACTIVATED parameters, dtype == gau_io.py:7-12 (gau_io.py:141-156)."""

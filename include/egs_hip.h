@@ -214,6 +214,66 @@ int egs_gau_loss(int height, int width, const float* image, const float* gt_imag
                  float grad_scale, void* ws, size_t ws_bytes, float* loss_out, float* dloss_dimage,
                  void* stream);
 
+/* ---- adaptive density control + optimizer surgery + Adam -----------
+ * The six training tensors of reference gsplat/gsmodel.py:96-129 (row-major [N, w], w =
+ * 3, 3, high_sh_width (45 in the reference), 1, 3, 4); the same struct describes their Adam
+ * moments (torch.optim.Adam state "exp_avg" / "exp_avg_sq"). */
+typedef struct EgsGaussianParams {
+  float* pws;
+  float* low_shs;
+  float* high_shs;
+  float* alphas_raw;
+  float* scales_raw;
+  float* rots_raw;
+} EgsGaussianParams;
+
+/* GSModel.update_density_info (gsmodel.py:214-230): g = |dloss_dus[i]|; first != 0: grad_accum = g for
+ * every row and count = visible; else rows with visible != 0 get grad_accum += g, count += 1.
+ * visible: one byte per Gaussian (the `depths > 0.2` mask GSFunction returns). */
+int egs_density_accumulate(int n, const float* dloss_dus, const uint8_t* visible, int first, float* grad_accum,
+                           int32_t* count, void* stream);
+
+/* GSModel.update_gaussian_density (gsmodel.py:232-317) in two calls around one 16-byte read-back.
+ * plan: cls[i] = 0 pruned (alpha_raw < alpha_thr_raw or max scale_raw > big_thr_raw), 1 survivor,
+ *   2 survivor + clone, 3 survivor + split (grad_accum/count >= grad_thr with 0/0 = 0; clone iff
+ *   exp(max scale_raw) <= scale_thr); totals (device int32[4]) = {survivors, clones, splits, pruned}.
+ * apply: out* have n_keep + n_clone + n_split rows: [survivors | clones | split children], each group in
+ *   input order (== prune_params 151-166 followed by update_params 132-148).  Appended rows hold
+ *   logit(sigmoid(alpha_raw)), log(exp(scale_raw) [* 0.6 for a split child]), the normalised quaternion,
+ *   copied SH, pws [+ R(q) (exp(scale_raw) * z) for a split child]; their moments are zero.  The parent of
+ *   a split stays unchanged (as in the reference).  z = unit_noise[3 * i + c] (i = INPUT row) when
+ *   unit_noise != NULL, else a counter-based standard normal that is a pure function of
+ *   (seed, round, i, c) -- identical on every replica (easygaussiansplatting_amd/scene.py:normal,
+ *   stream = round, element 3 i + c).  in_exp_avg == NULL (with the other three moment sets) = the
+ *   optimizer has no state yet.  `ws` is the workspace egs_densify_plan filled. */
+size_t egs_densify_ws_bytes(int n);
+int egs_densify_plan(int n, const float* alphas_raw, const float* scales_raw, const float* grad_accum,
+                     const int32_t* count, float alpha_thr_raw, float big_thr_raw, float grad_thr, float scale_thr,
+                     uint8_t* cls, void* ws, size_t ws_bytes, int32_t* totals, void* stream);
+int egs_densify_apply(int n, int n_keep, int n_clone, int n_split, int high_sh_width, const uint8_t* cls,
+                      const void* ws, const EgsGaussianParams* in, const EgsGaussianParams* in_exp_avg,
+                      const EgsGaussianParams* in_exp_avg_sq, const EgsGaussianParams* out,
+                      const EgsGaussianParams* out_exp_avg, const EgsGaussianParams* out_exp_avg_sq,
+                      const float* unit_noise, uint64_t seed, uint64_t round, void* stream);
+
+/* GSModel.reset_alpha (gsmodel.py:319-330): alphas_raw = min(alphas_raw, raw_val); both moments
+ * (nullable) zeroed. */
+int egs_reset_alpha(int n, float raw_val, float* alphas_raw, float* exp_avg, float* exp_avg_sq, void* stream);
+
+/* torch.optim.Adam.step as the reference configures it (train.py:32; no weight decay / amsgrad):
+ * all parameter groups in one launch.  step = the 1-based step count of the group AFTER this update.
+ * betas/eps are doubles because torch derives 1 - beta and the bias corrections in double. */
+typedef struct EgsAdamGroup {
+  float* param;
+  const float* grad;
+  float* exp_avg;
+  float* exp_avg_sq;
+  int64_t count; /* floats */
+  float lr;
+  int32_t step;
+} EgsAdamGroup;
+int egs_adam_step(int n_groups, const EgsAdamGroup* groups, double beta1, double beta2, double eps, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream ---------------
  * bench.py's `roofline` leg: when enabled, every kernel launch of this library
  * is bracketed by hipEventRecord on the stream it is launched on.

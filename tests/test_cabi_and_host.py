@@ -125,3 +125,12 @@ def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.EgsLibraryError):
         _lib.load()
+
+
+def test_host_lr_schedule_matches_reference_samples():
+    """density.expon_lr (host logic of gsmodel.py:180-183 / utils.py:7-44) against fixture G8's samples."""
+    from tests.conftest import load_golden
+    from easygaussiansplatting_amd.density import expon_lr
+    g = load_golden("g8_densify.npz")
+    got = [expon_lr(int(s), 1e-4 * 2.5, 1e-6 * 2.5, 3000, delay_mult=0.01) for s in g["lr_steps"]]
+    np.testing.assert_allclose(got, g["lr_values"], rtol=1e-12)
