@@ -274,6 +274,13 @@ typedef struct EgsAdamGroup {
 } EgsAdamGroup;
 int egs_adam_step(int n_groups, const EgsAdamGroup* groups, double beta1, double beta2, double eps, void* stream);
 
+/* ---- initial scales from a point cloud -----------------------------
+ * out_sqdist[i] = min_{j != i} |points[i] - points[j]|^2 (FLT_MAX when n == 1): the exact squared
+ * distance to the nearest other point, i.e. faiss.IndexFlatL2(3).search(pws, 2)[0][:, 1] of
+ * reference gsplat/read_write_model.py:216-220 (duplicates give 0).  points: [n,3]. */
+size_t egs_nn_sqdist_ws_bytes(int n);
+int egs_nn_sqdist(int n, const float* points, void* ws, size_t ws_bytes, float* out_sqdist, void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream ---------------
  * bench.py's `roofline` leg: when enabled, every kernel launch of this library
  * is bracketed by hipEventRecord on the stream it is launched on.

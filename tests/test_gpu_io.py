@@ -1,0 +1,99 @@
+"""GPU side of the IO / formats row: the nearest-neighbour kernel against the
+float64 oracle and the COLMAP dataset -> trainer path (train.py counterpart)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import io_oracle
+from tests.conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 255, 1024, 1025, 5000, 40000])
+def test_nn_sqdist_matches_oracle(n):
+    from easygaussiansplatting_amd.knn import nn_sqdist
+    rng = np.random.default_rng(n)
+    p = (rng.normal(0, 1, (n, 3)) * rng.uniform(0.1, 10)).astype(np.float32)
+    if n > 10:
+        p[5] = p[9]                                   # duplicate -> 0
+    got = nn_sqdist(p).cpu().numpy()
+    if n == 1:
+        assert got[0] > 1e37                          # no other point
+        return
+    want = io_oracle.nn_sqdist(p)
+    np.testing.assert_allclose(got, want, rtol=2e-5, atol=1e-7)
+    if n > 10:
+        assert got[5] == 0 and got[9] == 0
+
+
+def test_points_to_gaussians_on_device_matches_reference(tmp_path):
+    from easygaussiansplatting_amd import colmap
+    g = load_golden("g9_io.npz")
+    fn = os.path.join(str(tmp_path), "points3D.bin")
+    open(fn, "wb").write(g["colmap_points3D_bytes"].tobytes())
+    gs = colmap.read_points_bin_as_gau(fn)            # HIP neighbour search
+    for f in ("pw", "rot", "alpha", "sh"):
+        np.testing.assert_array_equal(gs[f], g["pts_" + f])
+    np.testing.assert_allclose(gs["scale"], g["pts_scale"], rtol=2e-5)
+
+
+def test_nn_sqdist_large_cloud_sampled():
+    """COLMAP-sized cloud (200 k points): sampled rows against a KD-tree."""
+    from scipy.spatial import cKDTree
+    from easygaussiansplatting_amd.knn import nn_sqdist
+    rng = np.random.default_rng(0)
+    p = rng.normal(0, 3, (200_000, 3)).astype(np.float32)
+    dev = torch.from_numpy(p).cuda()
+    nn_sqdist(dev)
+    torch.cuda.synchronize()
+    t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
+    t0.record(); got = nn_sqdist(dev); t1.record(); torch.cuda.synchronize()
+    print("nn_sqdist 200k points: %.2f ms" % t0.elapsed_time(t1))
+    idx = rng.choice(len(p), 4000, replace=False)
+    d, _ = cKDTree(p.astype(np.float64)).query(p[idx].astype(np.float64), k=2)
+    np.testing.assert_allclose(got.cpu().numpy()[idx], d[:, 1] ** 2, rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize("model", ["PINHOLE", "SIMPLE_PINHOLE"])
+def test_dataset_from_colmap_scene_and_training(tmp_path, model):
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.dataset import GSplatDataset
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer
+    from tests.colmap_fixture import write_scene
+    gsc.set_policy("gsplatcu")
+    sc = S.small_scene(2000, 96, 64, 3, seed=4)
+    cams = S.ring_cameras(sc.cam, 4, radius=5.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    imgs = []
+    with torch.no_grad():
+        for c in cams:
+            im = render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), Camera.from_scene(c))[0]
+            imgs.append((im.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255 + 0.5).astype(np.uint8))
+    rgb = np.clip((sc.shs[:, :3] * 0.28209479177387814 + 0.5) * 255, 0, 255).astype(np.uint8)
+    root = str(tmp_path / "scene")
+    write_scene(root, cams, imgs, sc.pws, rgb, model)
+    ds = GSplatDataset(root)
+    assert len(ds) == 4 and os.path.exists(os.path.join(root, "sparse", "0", "points3D.npy"))
+    cam0, img0 = ds[0]
+    assert (cam0.width, cam0.height) == (96, 64) and img0.shape == (3, 64, 96) and img0.dtype == torch.float32
+    assert abs(cam0.fx - cams[0].fx) < 1e-9 and abs(cam0.cy - cams[0].cy) < 1e-9
+    np.testing.assert_allclose(cam0.Rcw.cpu().numpy(), cams[0].Rcw, atol=1e-6)
+    np.testing.assert_allclose(img0.permute(1, 2, 0).cpu().numpy(), imgs[0] / 255.0, atol=1e-7)
+    twc = np.stack([-np.linalg.inv(c.Rcw) @ c.tcw for c in cams])
+    want_size = 1.1 * np.linalg.norm(twc - twc.mean(0), axis=1).max()
+    assert abs(ds.sence_size - want_size) < 1e-4 * want_size
+    assert ds.gs.shape == (2000,) and np.allclose(ds.gs["alpha"], 0.8)
+    half = GSplatDataset(root, resize_rate=0.5)
+    c_half, i_half = half[1]
+    assert i_half.shape == (3, 32, 48) and abs(c_half.fx - 0.5 * cams[1].fx) < 1e-9
+    # train.py counterpart: initial Gaussians from the point cloud, a few optimizer steps
+    start = S.Scene(ds.gs["pw"].copy(), ds.gs["rot"].copy(), ds.gs["scale"].copy(), ds.gs["alpha"].copy(),
+                    ds.gs["sh"].copy(), cams[0])
+    tr = Trainer(start, ds.cameras, ds.images, max_steps=100, scene_size=ds.sence_size)
+    losses = [tr.step([0, 1, 2, 3]) for _ in range(25)]
+    assert np.isfinite(losses).all() and losses[-1] < losses[0]
