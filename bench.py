@@ -258,6 +258,37 @@ def main():
     torch.cuda.synchronize()
     loss_step_ms = (time.perf_counter() - tl0) / nf * 1e3
 
+    # informative extra: the whole optimizer step of the train.py counterpart (raw parameters ->
+    # activations -> render -> loss -> backward -> Adam) and the two Adam implementations alone
+    train_extra = None
+    if rank == 0 and world == 1:
+        from easygaussiansplatting_amd.optim import FusedAdam, adam_groups
+        from easygaussiansplatting_amd.trainer import activate, raw_params_from_scene
+
+        def timed(fn, n):
+            for _ in range(2):
+                fn()
+            torch.cuda.synchronize()
+            t0_ = time.perf_counter()
+            for _ in range(n):
+                fn()
+            torch.cuda.synchronize()
+            return (time.perf_counter() - t0_) / n * 1e3
+        raw = raw_params_from_scene(sc, dev)
+        opts = {"fused": FusedAdam(adam_groups(raw), eps=1e-15),
+                "torch": torch.optim.Adam(adam_groups(raw), lr=0.0, eps=1e-15)}
+
+        def train_step(opt):
+            opt.zero_grad(set_to_none=True)
+            us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+            img, _ = GSFunction.apply(*activate(raw), us, cam)
+            gau_loss(img, gt).backward()
+            opt.step()
+        train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
+        for name, opt in opts.items():
+            train_extra["train_step_ms_%s_adam" % name] = round(timed(lambda: train_step(opt), nf), 4)
+            train_extra["adam_only_ms_%s" % name] = round(timed(opt.step, nf), 4)
+
     roofline = None
     if prof:
         rep = read_report()          # only the dominant kernel, recorded over the timed region
@@ -301,6 +332,7 @@ def main():
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
             "fwd_loss_bwd": {"ms": round(loss_step_ms, 4),
                              "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
+            "train_step": train_extra,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
         }
         if cpu:
