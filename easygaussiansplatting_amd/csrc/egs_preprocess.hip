@@ -242,7 +242,89 @@ __global__ __launch_bounds__(256) void k_chain_rule(
 struct PreParams {
   float fx, fy, cx, cy, limx, limy, det_eps, alpha_skip;
   int clamp_fov, near_cull, nan_cull, radius_mode, footprint, W, H;
+  int stage_in;   // experiment knob (EGS_PRE_STAGE_IN): k_preprocess_bwd also stages the SH rows it reads
 };
+
+// ---- cooperative row staging through LDS --------------------------------------------------
+// A lane-per-Gaussian kernel that reads its own K-float SH row issues K/4 dwordx4 loads whose 64
+// lanes are 4K bytes apart (64 different cache lines per instruction).  Staged instead: the
+// workgroup's 256 rows are one contiguous span, fetched with fully coalesced dwordx4 loads into LDS,
+// then every lane reads its row from LDS (row stride padded to an odd number of 16-B units:
+// conflict-free ds_read_b128).  Same for the dL/dsh rows on the way out.
+template <int K>
+struct RowStage {
+  static constexpr bool V4 = (K % 4 == 0);
+  static constexpr int Q = K / 4;                                      // float4 per row (V4)
+  static constexpr int STRIDE = V4 ? 4 * ((Q + 1) | 1) : (K | 1);      // floats
+  static constexpr int LDS_FLOATS = 256 * STRIDE;
+};
+
+template <int K>
+__device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int n, int base, float* lds, float* row) {
+  using RS = RowStage<K>;
+  const int rows = min(256, n - base);
+  const int tid = threadIdx.x;
+  if constexpr (RS::V4) {
+    const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + (size_t)K * base);
+#pragma unroll
+    for (int j = 0; j < RS::Q; ++j) {
+      const int f = tid + 256 * j;
+      const int r = f / RS::Q, c = f - r * RS::Q;
+      if (r < rows) *reinterpret_cast<float4*>(lds + r * RS::STRIDE + 4 * c) = s4[f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < RS::Q; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(lds + tid * RS::STRIDE + 4 * j);
+      row[4 * j] = v.x; row[4 * j + 1] = v.y; row[4 * j + 2] = v.z; row[4 * j + 3] = v.w;
+    }
+  } else {
+    const float* __restrict__ s1 = src + (size_t)K * base;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int f = tid + 256 * j;
+      const int r = f / K, c = f - r * K;
+      if (r < rows) lds[r * RS::STRIDE + c] = s1[f];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < K; ++j) row[j] = lds[tid * RS::STRIDE + j];
+  }
+}
+
+// the inverse: every lane deposits its row, the workgroup stores the span coalesced
+template <int K>
+__device__ __forceinline__ void stage_rows_out(const float* row, float* __restrict__ dst, int n, int base, float* lds) {
+  using RS = RowStage<K>;
+  const int rows = min(256, n - base);
+  const int tid = threadIdx.x;
+  __syncthreads();   // everyone is done reading the staged input rows
+  if constexpr (RS::V4) {
+#pragma unroll
+    for (int j = 0; j < RS::Q; ++j)
+      *reinterpret_cast<float4*>(lds + tid * RS::STRIDE + 4 * j) =
+          make_float4(row[4 * j], row[4 * j + 1], row[4 * j + 2], row[4 * j + 3]);
+    __syncthreads();
+    float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + (size_t)K * base);
+#pragma unroll
+    for (int j = 0; j < RS::Q; ++j) {
+      const int f = tid + 256 * j;
+      const int r = f / RS::Q, c = f - r * RS::Q;
+      if (r < rows) d4[f] = *reinterpret_cast<const float4*>(lds + r * RS::STRIDE + 4 * c);
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) lds[tid * RS::STRIDE + j] = row[j];
+    __syncthreads();
+    float* __restrict__ d1 = dst + (size_t)K * base;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      const int f = tid + 256 * j;
+      const int r = f / K, c = f - r * K;
+      if (r < rows) d1[f] = lds[r * RS::STRIDE + c];
+    }
+  }
+}
 
 // forward.md steps 1-5 for one Gaussian in one pass (== gsmodel.py:21-35 minus splat):
 // writes exactly what splat / splatB / the backward pass consume.
@@ -260,41 +342,46 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
                                                         float* __restrict__ colors,
                                                         int32_t* __restrict__ areas,
                                                         float4* __restrict__ rec) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   constexpr int K = 3 * NC;
-  const f3 pw = ld3(pws + 3 * (size_t)i);
-  float col[3];
-  {  // colour has no depth test in the reference (kernel.cu:619-725)
-    float sh[K];
-    load_sh_row<K>(shs + (size_t)K * i, sh);
-    const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
-    sh_color_f<NC>(d, sh, col);
-    st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
-  }
-  const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
-  float u0 = 0.f, u1 = 0.f, depth = EGS_BAD_MARKER, ci[3] = {0.f, 0.f, 0.f};
-  int rx = 0, ry = 0;
-  if (!(pp.near_cull && P.pc.z < EGS_MIN_DEPTH)) {
-    u0 = P.u0; u1 = P.u1; depth = P.pc.z;
-    const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-    const Cov3 c3 = cov3d_f(q, ld3(scales + 3 * (size_t)i));
-    const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
-    const float det_inv = inv_cov2d_f(c2.c, pp.det_eps, ci);
-    if (pp.nan_cull && isnan(det_inv)) {
-      depth = EGS_BAD_MARKER; ci[0] = 0.f; ci[1] = 0.f; ci[2] = 0.f;
-    } else {
-      radius_f(c2.c, pp.radius_mode, rx, ry);
+  __shared__ float stage[RowStage<12>::LDS_FLOATS];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  if (i < n) {
+    const f3 pw = ld3(pws + 3 * (size_t)i);
+    float col[3];
+    {  // colour has no depth test in the reference (kernel.cu:619-725)
+      float sh[K];   // direct dwordx4 row loads: staging them through LDS measured 10 % slower here
+      load_sh_row<K>(shs + (size_t)K * i, sh);
+      const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
+      sh_color_f<NC>(d, sh, col);
+      st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
     }
+    const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
+    float u0 = 0.f, u1 = 0.f, depth = EGS_BAD_MARKER, ci[3] = {0.f, 0.f, 0.f};
+    int rx = 0, ry = 0;
+    if (!(pp.near_cull && P.pc.z < EGS_MIN_DEPTH)) {
+      u0 = P.u0; u1 = P.u1; depth = P.pc.z;
+      const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+      const Cov3 c3 = cov3d_f(q, ld3(scales + 3 * (size_t)i));
+      const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
+      const float det_inv = inv_cov2d_f(c2.c, pp.det_eps, ci);
+      if (pp.nan_cull && isnan(det_inv)) {
+        depth = EGS_BAD_MARKER; ci[0] = 0.f; ci[1] = 0.f; ci[2] = 0.f;
+      } else {
+        radius_f(c2.c, pp.radius_mode, rx, ry);
+      }
+    }
+    us[2 * (size_t)i] = u0; us[2 * (size_t)i + 1] = u1;
+    depths[i] = depth;
+    st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
+    areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry;
+    // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
+    if (rec)
+      make_record(u0, u1, ci[0], ci[1], ci[2], alphas[i], col[0], col[1], col[2], rx, ry, pp.W, pp.H, pp.footprint,
+                  pp.alpha_skip, r);
   }
-  us[2 * (size_t)i] = u0; us[2 * (size_t)i + 1] = u1;
-  depths[i] = depth;
-  st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
-  areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry;
-  // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
-  if (rec)
-    make_record(u0, u1, ci[0], ci[1], ci[2], alphas[i], col[0], col[1], col[2], rx, ry, pp.W, pp.H, pp.footprint,
-                pp.alpha_skip, rec + 3 * (size_t)i);
+  // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
+  if (rec) stage_rows_out<12>(reinterpret_cast<const float*>(r), reinterpret_cast<float*>(rec), n, blockIdx.x * 256, stage);
 }
 
 // backward.md eq (3)(4)(5)(7) == gsmodel.py:71-85 with every Jacobian re-derived in
@@ -308,81 +395,70 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float4* __restrict__ gpack, float* __restrict__ dL_dpw, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dalpha, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
     float* __restrict__ dL_du) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
   constexpr int K = 3 * NC;
-  const float4 ga = gpack[3 * (size_t)i], gb = gpack[3 * (size_t)i + 1], gc = gpack[3 * (size_t)i + 2];
-  const f3 gcol = {ga.y, ga.z, ga.w};
-  const float gu0 = gb.x, gu1 = gb.y;
-  const f3 gci = {gb.z, gb.w, gc.x};
-  dL_dalpha[i] = ga.x;
-  dL_du[2 * (size_t)i] = gu0; dL_du[2 * (size_t)i + 1] = gu1;
-  float* osh = dL_dsh + (size_t)K * i;
-  if (pp.near_cull && depths[i] < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
-    st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
-    st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
-    st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
-    if constexpr (K % 4 == 0) {
+  __shared__ float stage[RowStage<K>::LDS_FLOATS];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float sh[K], gsh[K];
+  if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
+  else if (i < n) load_sh_row<K>(shs + (size_t)K * i, sh);
 #pragma unroll
-      for (int j = 0; j < K / 4; ++j) reinterpret_cast<float4*>(osh)[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int k = 0; k < K; ++k) gsh[k] = 0.f;
+  if (i < n) {
+    const float4 ga = gpack[3 * (size_t)i], gb = gpack[3 * (size_t)i + 1], gc = gpack[3 * (size_t)i + 2];
+    const f3 gcol = {ga.y, ga.z, ga.w};
+    const float gu0 = gb.x, gu1 = gb.y;
+    const f3 gci = {gb.z, gb.w, gc.x};
+    dL_dalpha[i] = ga.x;
+    dL_du[2 * (size_t)i] = gu0; dL_du[2 * (size_t)i + 1] = gu1;
+    if (pp.near_cull && depths[i] < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
+      st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
+      st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
+      st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
     } else {
+      const f3 pw = ld3(pws + 3 * (size_t)i);
+      const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+      const f3 s = ld3(scales + 3 * (size_t)i);
+      const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
+      const Cov3 c3 = cov3d_f(q, s);
+      const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
+      float ci[3];
+      const float det_inv = inv_cov2d_f(c2.c, pp.det_eps, ci);
+      float Ji[9];
+      inv_cov2d_jac(c2.c, det_inv, Ji);
+      // dL/dcov2d = dL/dcinv2d @ J  (row vector times 3x3)
+      const float g2[3] = {gci.x * Ji[0] + gci.y * Ji[3] + gci.z * Ji[6],
+                           gci.x * Ji[1] + gci.y * Ji[4] + gci.z * Ji[7],
+                           gci.x * Ji[2] + gci.y * Ji[5] + gci.z * Ji[8]};
+      float J3[18], Jp[9];
+      cov2d_jac(c2, P.pc.z, Rcw, pp.fx, pp.fy, J3, Jp);
+      float g3[6];
 #pragma unroll
-      for (int k = 0; k < K; ++k) osh[k] = 0.f;
-    }
-    return;
-  }
-  const f3 pw = ld3(pws + 3 * (size_t)i);
-  const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-  const f3 s = ld3(scales + 3 * (size_t)i);
-  const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
-  const Cov3 c3 = cov3d_f(q, s);
-  const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
-  float ci[3];
-  const float det_inv = inv_cov2d_f(c2.c, pp.det_eps, ci);
-  float Ji[9];
-  inv_cov2d_jac(c2.c, det_inv, Ji);
-  // dL/dcov2d = dL/dcinv2d @ J  (row vector times 3x3)
-  const float g2[3] = {gci.x * Ji[0] + gci.y * Ji[3] + gci.z * Ji[6], gci.x * Ji[1] + gci.y * Ji[4] + gci.z * Ji[7],
-                       gci.x * Ji[2] + gci.y * Ji[5] + gci.z * Ji[8]};
-  float J3[18], Jp[9];
-  cov2d_jac(c2, P.pc.z, Rcw, pp.fx, pp.fy, J3, Jp);
-  float g3[6];
+      for (int k = 0; k < 6; ++k) g3[k] = g2[0] * J3[k] + g2[1] * J3[6 + k] + g2[2] * J3[12 + k];
+      q4 gq; f3 gs;
+      cov3d_vjp(c3, q, s, g3, gq, gs);
+      st4(dL_drot + 4 * (size_t)i, gq);      // eq (3)
+      st3(dL_dscale + 3 * (size_t)i, gs);    // eq (4)
+      float j00, j02, j11, j12;
+      project_jac(P, pp.fx, pp.fy, j00, j02, j11, j12);
+      const f3 gpc = {gu0 * j00 + g2[0] * Jp[0] + g2[1] * Jp[3] + g2[2] * Jp[6],
+                      gu1 * j11 + g2[0] * Jp[1] + g2[1] * Jp[4] + g2[2] * Jp[7],
+                      gu0 * j02 + gu1 * j12 + g2[0] * Jp[2] + g2[1] * Jp[5] + g2[2] * Jp[8]};
+      const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
+      // eq (5): dL/dsh[c, rgb] = dL/dcolor[rgb] * basis[c]
 #pragma unroll
-  for (int k = 0; k < 6; ++k) g3[k] = g2[0] * J3[k] + g2[1] * J3[6 + k] + g2[2] * J3[12 + k];
-  q4 gq; f3 gs;
-  cov3d_vjp(c3, q, s, g3, gq, gs);
-  st4(dL_drot + 4 * (size_t)i, gq);      // eq (3)
-  st3(dL_dscale + 3 * (size_t)i, gs);    // eq (4)
-  float j00, j02, j11, j12;
-  project_jac(P, pp.fx, pp.fy, j00, j02, j11, j12);
-  const f3 gpc = {gu0 * j00 + g2[0] * Jp[0] + g2[1] * Jp[3] + g2[2] * Jp[6],
-                  gu1 * j11 + g2[0] * Jp[1] + g2[1] * Jp[4] + g2[2] * Jp[7],
-                  gu0 * j02 + gu1 * j12 + g2[0] * Jp[2] + g2[1] * Jp[5] + g2[2] * Jp[8]};
-  float sh[K];
-  load_sh_row<K>(shs + (size_t)K * i, sh);
-  const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
-  {  // eq (5): dL/dsh[c, rgb] = dL/dcolor[rgb] * basis[c]; 48- or 192-B rows go out as dwordx4
-    float gsh[K];
+      for (int c = 0; c < NC; ++c) {
+        gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
+      }
+      float W[9];
+      sh_jac_dpw<NC>(d, sh, W);
+      float* opw = dL_dpw + 3 * (size_t)i;  // eq (7)
 #pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
-    }
-    if constexpr (K % 4 == 0) {
-#pragma unroll
-      for (int j = 0; j < K / 4; ++j)
-        reinterpret_cast<float4*>(osh)[j] = make_float4(gsh[4 * j], gsh[4 * j + 1], gsh[4 * j + 2], gsh[4 * j + 3]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) osh[k] = gsh[k];
+      for (int k = 0; k < 3; ++k)
+        opw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
+                 gcol.z * W[6 + k];
     }
   }
-  float W[9];
-  sh_jac_dpw<NC>(d, sh, W);
-  float* opw = dL_dpw + 3 * (size_t)i;  // eq (7)
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    opw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
-             gcol.z * W[6 + k];
+  stage_rows_out<K>(gsh, dL_dsh, n, blockIdx.x * 256, stage);
 }
 
 }  // namespace egs
@@ -516,6 +592,8 @@ static PreParams make_pre_params(const EgsPolicy* pol, float fx, float fy, float
   pp.footprint = pol->footprint; pp.W = width; pp.H = height;
   pp.clamp_fov = pol->fov_mode != 2; pp.near_cull = pol->near_cull; pp.nan_cull = pol->nan_cull;
   pp.radius_mode = pol->radius_mode;
+  static const int stage_in = [] { const char* e = getenv("EGS_PRE_STAGE_IN"); return e ? atoi(e) : 0; }();
+  pp.stage_in = stage_in;
   return pp;
 }
 

@@ -445,6 +445,7 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
 struct DrawParams {
   int W, H, gx, gy, T;
   float alpha_skip, tau_stop;
+  float lskip;   // log2(alpha_skip), -inf when there is no skip test
   int maha_floor, alpha_clamp;
   int dbg;       // experiment knob (EGS_DBG), 0 in production
   int map_mode;  // 0: tile = block; 1: contiguous band per XCD; 2: tile rows interleaved over XCDs
@@ -554,17 +555,20 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
   }
   const float fpx[2] = {(float)pxb[0], (float)pxb[1]};
   const float fpy[2] = {(float)pyb[0], (float)pyb[1]};
-  constexpr int DONE = (int)0x80000000;
+  // A pixel is finished when its tau fell below tau_stop (kernel.cu:256-260): `tau >= stop` IS the
+  // "still blending" test, so no separate done flag is kept.  Lanes outside the image start at -1.
   float tau[4], cr[4], cg[4], cb[4];
   int cont[4];
   int live = 0;  // wave-uniform: bit k set while block k still has an unfinished pixel
+  const float stop = p.tau_stop, lskip = p.lskip;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    cont[k] = ((pxb[k & 1] < p.W) && (pyb[k >> 1] < p.H)) ? 0 : DONE;
-    tau[k] = 1.f; cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f;
-    if (__any(cont[k] >= 0)) live |= 1 << k;
+    cont[k] = 0;
+    tau[k] = ((pxb[k & 1] < p.W) && (pyb[k >> 1] < p.H)) ? 1.f : -1.f;
+    cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f;
+    if (__any(tau[k] >= stop)) live |= 1 << k;
   }
-  const float stop = p.tau_stop;
+  constexpr float L99 = -0.014499569695115089f;  // log2(0.99): min(0.99, a) == exp2(min(log2 a, L99))
   for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     int mymask = 0;   // reach mask of the entry THIS lane staged (lane j <-> entry base + j)
@@ -581,53 +585,62 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
     for (int j = 0; j < m; ++j) {
       // the entry's mask comes straight out of lane j's register (v_readlane): no LDS round trip
       const int reach = __builtin_amdgcn_readlane(mymask, j) & live;
-      if (reach == 0) continue;  // scalar branch: no live block within reach of this entry
-      const float4 A = sA[j], B = sB[j], C = sC[j];  // wave-uniform address: LDS broadcast
-      bool inx[2] = {true, true}, iny[2] = {true, true};
-      if (BOX) {
-        const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
-        const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
+      if (reach != 0) {  // scalar branch: some live block is within reach of this entry
+        const float4 A = sA[j], B = sB[j], C = sC[j];  // wave-uniform address: LDS broadcast
+        bool inx[2] = {true, true}, iny[2] = {true, true};
+        if (BOX) {
+          const uint32_t bx = __float_as_uint(C.y), by = __float_as_uint(C.z);
+          const int x0 = bx & 0xFFFF, x1 = bx >> 16, y0 = by & 0xFFFF, y1 = by >> 16;
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            inx[b] = (pxb[b] >= x0) && (pxb[b] < x1);
+            iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
+          }
+        }
+        // alpha' = exp2(e), e = log2(alpha) + log2 exp(-maha/2) (F.5.1, common.cuh:85-88, pre-scaled
+        // conic): no multiply by alpha, the skip test is a compare against the constant log2(skip), and
+        // the floor (maha >= 0) and the 0.99 clamp are ONE min against `cap`.  log2(alpha) comes from the
+        // record's skip threshold thr = log2(skip / alpha) (+inf: never blends).
+        // (no skip test: thr is -inf, or +inf for alpha < 0 which never blends -> compare against thr itself)
+        const bool skips = p.alpha_skip > 0.f;
+        const float la = skips ? lskip - C.w : __builtin_amdgcn_logf(B.y);
+        const float lthr = skips ? lskip : C.w;
+        float cap = 0.f;
+        if (FLOOR) cap = CLAMP ? min_hi(la, L99) : la;
+        else if (CLAMP) cap = L99;
+        float cxx[2], cxy[2], cyy[2], dy[2];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
-          inx[b] = (pxb[b] >= x0) && (pxb[b] < x1);
-          iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
+          const float dx = A.x - fpx[b];
+          cxx[b] = fmaf(A.z * dx, dx, la);  // qxx dx dx + log2 alpha
+          cxy[b] = A.w * dx;                // qxy dx
+          dy[b] = A.y - fpy[b];
+          cyy[b] = B.x * dy[b] * dy[b];     // qyy dy dy
         }
-      }
-      float cxx[2], cxy[2], cyy[2], dy[2];
+        const int idx = base + j + 1;
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float dx = A.x - fpx[b];
-        cxx[b] = A.z * dx * dx;  // qxx dx dx
-        cxy[b] = A.w * dx;       // qxy dx
-        dy[b] = A.y - fpy[b];
-        cyy[b] = B.x * dy[b] * dy[b];  // qyy dy dy
-      }
-      const int idx = base + j + 1;
-      int finacc = 0;  // OR of the counters written by this entry: sign bit <=> some pixel finished
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int bx = k & 1, by = k >> 1;
-        if (reach & (1 << k)) {  // scalar branch: the whole 8x8 block is live and in reach
-          // log2 of exp(-maha/2): F.5.1 (common.cuh:85-88) with the pre-scaled conic
-          const float pw = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
-          bool hit = (cont[k] >= 0) && (pw >= C.w);  // alpha' >= alpha_skip  (kernel.cu:246)
-          if (BOX) hit = hit && inx[bx] && iny[by];
-          if (hit) {
-            float ap = B.y * __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
-            if (CLAMP) ap = min_hi(ap, 0.99f);
-            const float w = tau[k] * ap;  // F.5
-            cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
-            const float t = tau[k] - w;  // F.5.2: tau (1 - alpha')
-            tau[k] = t;
-            cont[k] = (t < stop) ? (idx | DONE) : idx;
-            finacc |= cont[k];
+        for (int k = 0; k < 4; ++k) {
+          const int bx = k & 1, by = k >> 1;
+          if (reach & (1 << k)) {  // scalar branch: the whole 8x8 block is live and in reach
+            const float pwl = cxx[bx] + cyy[by] + cxy[bx] * dy[by];
+            const float e = (FLOOR || CLAMP) ? min_hi(pwl, cap) : pwl;
+            bool hit = (tau[k] >= stop) && (e >= lthr);  // unfinished, alpha' >= alpha_skip (kernel.cu:246)
+            if (BOX) hit = hit && inx[bx] && iny[by];
+            if (hit) {
+              const float w = tau[k] * __builtin_amdgcn_exp2f(e);  // F.5: tau alpha'
+              cr[k] += w * B.z; cg[k] += w * B.w; cb[k] += w * C.x;
+              tau[k] -= w;  // F.5.2: tau (1 - alpha')
+              cont[k] = idx;
+            }
           }
         }
       }
-      if (__any(finacc < 0)) {  // some pixel just finished (rare): refresh the live-block mask
+      // Finished pixels fail `tau >= stop` on their own, so the live-block mask only saves work: it is
+      // refreshed every 8th entry instead of tracking "some pixel just finished" per block.
+      if ((j & 7) == 7) {
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-          if (!__any(cont[k] >= 0)) live &= ~(1 << k);
+          if ((live & (1 << k)) && !__any(tau[k] >= stop)) live &= ~(1 << k);
         if (live == 0) break;  // scalar exit: every pixel of the tile is finished
       }
     }
@@ -641,7 +654,7 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
       image[pix] = cr[k];
       image[HW + pix] = cg[k];
       image[2 * HW + pix] = cb[k];
-      contrib[pix] = cont[k] & 0x7FFFFFFF;
+      contrib[pix] = cont[k];
       final_tau[pix] = tau[k];
     }
   }
@@ -938,6 +951,7 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol) {
   static const int dbg = [] { const char* e = getenv("EGS_DBG"); return e ? atoi(e) : 0; }();
   p.dbg = dbg;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
+  p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
   return p;
 }
