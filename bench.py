@@ -128,8 +128,14 @@ def main():
                              % (a.gpus, a.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # EGS_FORCE_EXCHANGE=1 runs the RCCL gradient exchange even with one rank (a 1-GPU box can then
+    # exercise exactly the code the multi-GPU runs execute)
+    exchange = world > 1 or os.environ.get("EGS_FORCE_EXCHANGE") == "1"
+    if exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     lib = _lib.load()
@@ -165,16 +171,16 @@ def main():
         image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
                                        params["rots"], us0, cam)
         image.backward(dl)
-        if world > 1:  # gradient exchange: 59 floats per Gaussian, SUM then mean
-            hs = [dist.all_reduce(params[k].grad, op=dist.ReduceOp.SUM, async_op=True) for k in order]
+        if exchange:  # gradient exchange: 59 floats per Gaussian, SUM then mean
+            grads = [params[k].grad for k in order]
+            hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
             for h in hs:
                 h.wait()
-            for k in order:
-                params[k].grad.div_(world)
+            torch._foreach_div_(grads, float(world))
         return image
 
     def sync():
-        if world > 1:
+        if exchange:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -216,7 +222,7 @@ def main():
     if prof:
         lib.egs_prof_enable(0)
     dt_t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if exchange:
         dist.all_reduce(dt_t, op=dist.ReduceOp.MAX)
     dt = float(dt_t.item())
     ms = dt / a.steps * 1e3
@@ -337,9 +343,17 @@ def main():
         }
         if cpu:
             line["fwd_speedup_vs_cpu"] = round(line["fwd_only"]["Mpix/s"] / cpu["value"], 1)
-        print(json.dumps(line))
-    if world > 1:
+    if exchange:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL writes a version banner to the C stdout buffer: push it out first so that the JSON
+        # line is the LAST line of output
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

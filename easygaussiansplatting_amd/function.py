@@ -45,6 +45,8 @@ class GSFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pws, shs, alphas, scales, rots, us, cam):
         ctx.mode = GSFunction.mode
+        # the mask output never carries a gradient: do not let autograd zero-fill one per step
+        ctx.set_materialize_grads(False)
         if ctx.mode == "fused":
             image, mask, state = _fused.forward(pws, shs, alphas, scales, rots, cam)
             ctx.cam = cam
@@ -72,6 +74,8 @@ class GSFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dloss_dgammas, _):
         cam = ctx.cam
+        if dloss_dgammas is None:  # the image did not take part in the loss
+            return (None,) * 7
         if ctx.mode == "fused":
             pws, shs, alphas, scales, rots = ctx.saved_tensors
             dpws, dshs, dalphas, dscales, drots, dus = _fused.backward(
