@@ -155,7 +155,7 @@ def main():
     cams = S.ring_cameras(sc.cam, max(8, world))
     cam = Camera.from_scene(cams[rank % len(cams)], dev)   # one view per GPU; view 0 = the BASELINE camera
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
-    params = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1), scales=t(sc.scales),
+    params = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1).clone(), scales=t(sc.scales),
                   rots=t(sc.rots))
     for p in params.values():
         p.requires_grad_(True)

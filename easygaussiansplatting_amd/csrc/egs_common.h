@@ -82,6 +82,22 @@ struct Carver {
   bool ok() const { return off <= cap; }
 };
 
+// ---- binning pieces shared by egs_raster.hip (egs_splat_bin) and egs_preprocess.hip (the fused forward
+// kernel does getRects + the depth key itself) ---------------------------------------------------------
+struct BinParams {
+  int W, H, gx, gy;
+  int footprint, far_cull, depth_key, mutate;
+};
+struct BinCountOut {  // where k_bin_count's results live inside the bin workspace
+  uint4* rects;
+  uint32_t *counts, *dkeys, *ids, *maxkey;  // maxkey[1 + workgroup] = per-workgroup maximum of the depth keys
+};
+BinParams make_bin_params(int width, int height, const EgsPolicy* pol);
+bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out);
+// everything of egs_splat_bin after k_bin_count (max reduce, depth sort, offsets scan)
+int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                          void* stream);
+
 // splatB's draw pass into the packed [N][12] gradient records (egs_raster.hip); *gpack
 // points into `ws`.  Shared by egs_splat_bwd (+unpack) and egs_fused_backward.
 int splat_bwd_packed(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,

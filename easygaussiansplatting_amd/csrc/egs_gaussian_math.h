@@ -344,6 +344,57 @@ __device__ __forceinline__ void pixel_box(float ux, float uy, float rx, float ry
   y0 = f2i(fmaxf(fminf(uy - ry, (float)H), 0.f));
   y1 = f2i(fmaxf(fminf(uy + ry, (float)H), 0.f));
 }
+// getRects (reference kernel.cu:82-122) + the depth key of createKeys (kernel.cu:73) for one Gaussian.
+// Returns the patch count; `cull` = the reference's in-place marking of a Gaussian whose tile rect is
+// empty (depth = -1, areas = 0; kernel.cu:114-119) applies.
+__device__ __forceinline__ uint32_t bin_count_one(const BinParams& p, float ux, float uy, float xs, float ys,
+                                                  float depth, uint4& rect, uint32_t& key, bool& cull) {
+  uint32_t cnt = 0;
+  rect = {0u, 0u, 0u, 0u};
+  key = 0u;  // culled Gaussians emit nothing: any key will do, 0 keeps the maximum small
+  cull = false;
+  if (p.footprint == 0) {
+    if (!(depth < EGS_MIN_DEPTH)) {
+      const float B = (float)EGS_TILE;
+      const int x0 = min(p.gx, max(0, f2i((ux - xs) / B)));
+      const int y0 = min(p.gy, max(0, f2i((uy - ys) / B)));
+      const int x1 = min(p.gx, max(0, f2i((ux + xs + B - 1.f) / B)));  // DIV_ROUND_UP in float (common.cuh:14)
+      const int y1 = min(p.gy, max(0, f2i((uy + ys + B - 1.f) / B)));
+      // (a reversed rect -- only possible with negative radii fed by the caller --
+      //  would wrap in the reference's unsigned product; it is treated as empty)
+      cnt = (x1 > x0 && y1 > y0) ? (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0) : 0u;
+      if (cnt == 0) cull = p.mutate != 0;
+      else rect = {(uint32_t)x0, (uint32_t)y0, (uint32_t)x1, (uint32_t)y1};
+    }
+  } else {
+    bool vis = !(depth < 0.2f || depth > 100.f);                                        // gausplat.py:204
+    vis = vis && !(fabsf(ux / (float)p.W) > 1.3f) && !(fabsf(uy / (float)p.H) > 1.3f);  // gausplat.py:208
+    if (vis) {
+      int x0, x1, y0, y1;
+      pixel_box(ux, uy, xs, ys, p.W, p.H, x0, x1, y0, y1);
+      if ((x1 - x0) * (y1 - y0) != 0 && x1 > x0 && y1 > y0) {
+        rect = {(uint32_t)(x0 / EGS_TILE), (uint32_t)(y0 / EGS_TILE), (uint32_t)((x1 + EGS_TILE - 1) / EGS_TILE),
+                (uint32_t)((y1 + EGS_TILE - 1) / EGS_TILE)};
+        cnt = (rect.w - rect.y) * (rect.z - rect.x);
+      }
+    }
+  }
+  if (cnt != 0) key = (p.depth_key == 0) ? (uint32_t)(depth * 1000.f) : __float_as_uint(depth);
+  return cnt;
+}
+
+// per-workgroup (256 threads) maximum of the depth keys -> maxkey[1 + workgroup]; no atomics (a
+// same-address atomicMax per wave measured +170 us); k_max_reduce folds the <= 4 K partial maxima
+__device__ __forceinline__ void block_max_key(uint32_t key, uint32_t* __restrict__ maxkey) {
+  uint32_t mk = key;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
+  __shared__ uint32_t wm[4];
+  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
+  __syncthreads();
+  if (threadIdx.x == 0) maxkey[1 + blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+}
+
 __device__ __forceinline__ void make_record(float ux, float uy, float c0, float c1, float c2, float alpha,
                                             float r, float g, float b, int area_x, int area_y, int W, int H,
                                             int footprint, float alpha_skip, float4* __restrict__ out) {

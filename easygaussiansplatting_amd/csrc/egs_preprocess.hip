@@ -341,10 +341,12 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
                                                         float* __restrict__ cinv2ds,
                                                         float* __restrict__ colors,
                                                         int32_t* __restrict__ areas,
-                                                        float4* __restrict__ rec) {
+                                                        float4* __restrict__ rec, BinParams bp, BinCountOut bo,
+                                                        uint8_t* __restrict__ visible) {
   constexpr int K = 3 * NC;
   __shared__ float stage[RowStage<12>::LDS_FLOATS];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  uint32_t dkey = 0u;
   float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
@@ -371,8 +373,19 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
         radius_f(c2.c, pp.radius_mode, rx, ry);
       }
     }
+    if (bo.rects) {  // getRects + depth key of the binning stage, straight from registers (no k_bin_count pass)
+      uint4 rect;
+      bool cull;
+      const uint32_t cnt = bin_count_one(bp, u0, u1, (float)rx, (float)ry, depth, rect, dkey, cull);
+      if (cull) { depth = EGS_BAD_MARKER; rx = 0; ry = 0; }  // in-place contract of splat (kernel.cu:114-119)
+      bo.ids[i] = (uint32_t)i;
+      bo.rects[i] = rect;
+      bo.counts[i] = cnt;
+      bo.dkeys[i] = dkey;
+    }
     us[2 * (size_t)i] = u0; us[2 * (size_t)i + 1] = u1;
     depths[i] = depth;
+    if (visible) visible[i] = depth > 0.2f;  // the mask GSFunction returns (gsmodel.py:50)
     st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
     areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry;
     // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
@@ -380,6 +393,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
       make_record(u0, u1, ci[0], ci[1], ci[2], alphas[i], col[0], col[1], col[2], rx, ry, pp.W, pp.H, pp.footprint,
                   pp.alpha_skip, r);
   }
+  if (bo.rects) block_max_key(dkey, bo.maxkey);
   // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
   if (rec) stage_rows_out<12>(reinterpret_cast<const float*>(r), reinterpret_cast<float*>(rec), n, blockIdx.x * 256, stage);
 }
@@ -601,31 +615,41 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
                                  const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                                  const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                                  const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                                 int32_t* areas, void* rec, int key_bits_hint, void* ws_bin,
+                                 int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
                                  size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
+  EGS_CHECK_ARG(width < 32768 && height < 32768);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
-  if (n > 0) {
-    EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && us && depths && cinv2ds && colors && areas);
-    EGS_CHECK_ARG(!rec || alphas);
-    EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0 && (sh_dim % 4 != 0 || ((uintptr_t)shs & 15) == 0));
-    const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
-    dim3 g(div_up(n, 256)), b(256);
-    hipStream_t s = (hipStream_t)stream;
+  hipStream_t s = (hipStream_t)stream;
+  if (n == 0) {
+    EGS_HIP(hipMemsetAsync(total_patches, 0, 8, s));
+    return 0;
+  }
+  EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && us && depths && cinv2ds && colors && areas);
+  EGS_CHECK_ARG(!rec || alphas);
+  EGS_CHECK_ARG(ws_bin);
+  EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0 && (sh_dim % 4 != 0 || ((uintptr_t)shs & 15) == 0));
+  BinCountOut bo;
+  if (!bin_count_outputs(ws_bin, ws_bin_bytes, n, &bo)) {
+    set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  const BinParams bp = make_bin_params(width, height, pol);
+  const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
+  dim3 g(div_up(n, 256)), b(256);
 #define EGS_PRE(NC)                                                                                            \
   EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC>), g, b, s, n, pp, pws, rots, scales, shs, alphas, Rcw,  \
-             tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec)
-    switch (sh_dim) {
-      case 3: EGS_PRE(1); break;
-      case 12: EGS_PRE(4); break;
-      case 27: EGS_PRE(9); break;
-      default: EGS_PRE(16); break;
-    }
-#undef EGS_PRE
-    EGS_LAUNCH_OK();
+             tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo, visible)
+  switch (sh_dim) {
+    case 3: EGS_PRE(1); break;
+    case 12: EGS_PRE(4); break;
+    case 27: EGS_PRE(9); break;
+    default: EGS_PRE(16); break;
   }
-  return egs_splat_bin(n, width, height, us, areas, depths, pol, key_bits_hint, ws_bin, ws_bin_bytes,
-                       total_patches, stream);
+#undef EGS_PRE
+  EGS_LAUNCH_OK();
+  // the kernel above already did getRects + depth keys (k_bin_count of egs_splat_bin)
+  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
 }
 
 extern "C" size_t egs_fused_backward_ws_bytes(int n) { return egs_splat_bwd_ws_bytes(n); }

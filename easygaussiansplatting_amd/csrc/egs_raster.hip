@@ -286,73 +286,31 @@ static int exclusive_scan(int64_t n, const uint32_t* in, const uint32_t* gather,
 // ============================================================================
 // binning
 // ============================================================================
-struct BinParams {
-  int W, H, gx, gy;
-  int footprint, far_cull, depth_key, mutate;
-};
-
-// getRects (reference kernel.cu:82-122) + the depth key of createKeys (kernel.cu:73)
+// getRects (reference kernel.cu:82-122) + the depth key of createKeys (kernel.cu:73); the fused forward
+// kernel (egs_preprocess.hip) does the same through bin_count_one and skips this launch
 __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const float* __restrict__ us,
                                                    int32_t* __restrict__ areas, float* __restrict__ depths,
                                                    uint4* __restrict__ rects, uint32_t* __restrict__ counts,
                                                    uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
                                                    uint32_t* __restrict__ maxkey) {
   const int i = blockIdx.x * 256 + threadIdx.x;
-  uint32_t cnt = 0, key = 0u;  // culled Gaussians emit nothing: any key will do, 0 keeps max small
+  uint32_t key = 0u;
   if (i < n) {
-  ids[i] = (uint32_t)i;
-  uint4 rect = {0u, 0u, 0u, 0u};
-  const float depth = depths[i];
-  const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
-  const float xs = (float)areas[2 * (size_t)i], ys = (float)areas[2 * (size_t)i + 1];
-  if (p.footprint == 0) {
-    if (!(depth < EGS_MIN_DEPTH)) {
-      const float B = (float)EGS_TILE;
-      const int x0 = min(p.gx, max(0, f2i((ux - xs) / B)));
-      const int y0 = min(p.gy, max(0, f2i((uy - ys) / B)));
-      const int x1 = min(p.gx, max(0, f2i((ux + xs + B - 1.f) / B)));  // DIV_ROUND_UP in float (common.cuh:14)
-      const int y1 = min(p.gy, max(0, f2i((uy + ys + B - 1.f) / B)));
-      // (a reversed rect -- only possible with negative radii fed by the caller --
-      //  would wrap in the reference's unsigned product; it is treated as empty)
-      cnt = (x1 > x0 && y1 > y0) ? (uint32_t)(y1 - y0) * (uint32_t)(x1 - x0) : 0u;
-      if (cnt == 0) {
-        if (p.mutate) {  // the in-place contract of the reference (kernel.cu:114-119)
-          depths[i] = EGS_BAD_MARKER;
-          areas[2 * (size_t)i] = 0;
-          areas[2 * (size_t)i + 1] = 0;
-        }
-      } else {
-        rect = {(uint32_t)x0, (uint32_t)y0, (uint32_t)x1, (uint32_t)y1};
-      }
+    uint4 rect;
+    bool cull;
+    const uint32_t cnt = bin_count_one(p, us[2 * (size_t)i], us[2 * (size_t)i + 1], (float)areas[2 * (size_t)i],
+                                       (float)areas[2 * (size_t)i + 1], depths[i], rect, key, cull);
+    if (cull) {  // the in-place contract of the reference (kernel.cu:114-119)
+      depths[i] = EGS_BAD_MARKER;
+      areas[2 * (size_t)i] = 0;
+      areas[2 * (size_t)i + 1] = 0;
     }
-  } else {
-    bool vis = !(depth < 0.2f || depth > 100.f);                                    // gausplat.py:204
-    vis = vis && !(fabsf(ux / (float)p.W) > 1.3f) && !(fabsf(uy / (float)p.H) > 1.3f);  // gausplat.py:208
-    if (vis) {
-      int x0, x1, y0, y1;
-      pixel_box(ux, uy, xs, ys, p.W, p.H, x0, x1, y0, y1);
-      if ((x1 - x0) * (y1 - y0) != 0 && x1 > x0 && y1 > y0) {
-        rect = {(uint32_t)(x0 / EGS_TILE), (uint32_t)(y0 / EGS_TILE), (uint32_t)((x1 + EGS_TILE - 1) / EGS_TILE),
-                (uint32_t)((y1 + EGS_TILE - 1) / EGS_TILE)};
-        cnt = (rect.w - rect.y) * (rect.z - rect.x);
-      }
-    }
+    ids[i] = (uint32_t)i;
+    rects[i] = rect;
+    counts[i] = cnt;
+    dkeys[i] = key;
   }
-  if (cnt != 0) key = (p.depth_key == 0) ? (uint32_t)(depth * 1000.f) : __float_as_uint(depth);
-  rects[i] = rect;
-  counts[i] = cnt;
-  dkeys[i] = key;
-  }
-  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
-  uint32_t mk = key;
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
-  // per-workgroup maximum, no atomics (a same-address atomicMax per wave measured +170 us);
-  // k_max_reduce folds the <= 4 K partial maxima
-  __shared__ uint32_t wm[4];
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
-  __syncthreads();
-  if (threadIdx.x == 0) maxkey[1 + blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
+  block_max_key(key, maxkey);  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
 }
 
 __global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __restrict__ maxkey,
@@ -1016,20 +974,43 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
     set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
+  const BinParams p = make_bin_params(width, height, pol);
+  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rects,
+             L.counts, L.dkeys, L.ids, L.maxkey);
+  EGS_LAUNCH_OK();
+  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
+}
+
+namespace egs {
+BinParams make_bin_params(int width, int height, const EgsPolicy* pol) {
   BinParams p;
   p.W = width; p.H = height;
   p.gx = div_up(width, EGS_TILE); p.gy = div_up(height, EGS_TILE);
   p.footprint = pol->footprint; p.far_cull = pol->far_cull; p.depth_key = pol->depth_key;
   p.mutate = (pol->footprint == 0);
-  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rects,
-             L.counts, L.dkeys, L.ids, L.maxkey);
+  return p;
+}
+
+bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out) {
+  BinLayout L;
+  if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) return false;
+  out->rects = L.rects; out->counts = L.counts; out->dkeys = L.dkeys; out->ids = L.ids; out->maxkey = L.maxkey;
+  return true;
+}
+
+int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                          void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  BinLayout L;
+  if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) {
+    set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
   EGS_LAUNCH("k_max_reduce", k_max_reduce, dim3(1), dim3(256), s, div_up(n, 256), L.maxkey, total_patches + 1);
   EGS_LAUNCH_OK();
-  // 4 passes (even): the sorted (dkeys, ids) end up in the primary buffers; passes over digits
-  // that are zero in every key (mm depth keys rarely need more than 16 bits) are plain copies
   // Only the depth-key bits the caller expects to be significant are sorted (hint from the previous
   // call's max key, which comes back in total_patches[1]); if the hint turns out too small the
-  // caller re-runs this function with hint = 32.  Within the launched passes, digits that are zero
+  // caller re-runs the stage with hint = 32.  Within the launched passes, digits that are zero
   // in every key still degenerate to copies (maxkey check on the device).
   int end_bit = (key_bits_hint <= 0 || key_bits_hint > 32) ? 32 : ((key_bits_hint + 7) / 8) * 8;
   int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey);
@@ -1040,6 +1021,7 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
   }
   return exclusive_scan(n, L.counts, L.ids, L.offsets, total_patches, L.scan_partials, s);
 }
+}  // namespace egs
 
 static int splat_draw_impl(int n, int64_t patches, int width, int height, const float* us,
                            const float* cinv2ds, const float* alphas, const float* colors,

@@ -56,12 +56,13 @@ def forward(pws, shs, alphas, scales, rots, cam):
     S.colors = torch.empty((n, 3), dtype=f32, device=dev)
     S.areas = torch.empty((n, 2), dtype=i32, device=dev)
     S.rec = torch.empty((max(n, 1), 12), dtype=f32, device=dev)   # packed 2D records, reused by backward
+    mask = torch.empty((n,), dtype=torch.bool, device=dev)        # depths > 0.2, written by the kernel
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
     patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward(
         n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc),
         float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths),
-        _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), hint, _ptr(ws_bin), ws_bin_bytes,
+        _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin), ws_bin_bytes,
         _ptr(total), st)))
     image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
@@ -73,7 +74,6 @@ def forward(pws, shs, alphas, scales, rots, cam):
     _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                       ws_draw_bytes, _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                       _ptr(S.ranges), _ptr(S.gsid), st))
-    mask = S.depths > 0.2                                        # gsmodel.py:50
     return image, mask, S
 
 

@@ -180,13 +180,15 @@ int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss
  *                         eq (3)(4)(5)(7) (gsmodel.py:71-85).
  * `depths`/`areas` are the arrays egs_fused_forward produced (incl. the in-place culling). */
 /* rec (nullable): 48 N bytes; receives the packed 2D records of the draw kernels so that
- * egs_splat_draw_rec / egs_fused_backward skip their own packing pass. */
+ * egs_splat_draw_rec / egs_fused_backward skip their own packing pass.
+ * visible (nullable): N bytes; receives depths[i] > 0.2 AFTER the in-place culling of splat, i.e. the
+ * mask GSFunction.forward returns (gsmodel.py:50). */
 int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
                       const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                       const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                       const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                      int32_t* areas, void* rec, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
-                      uint32_t* total_patches, void* stream);
+                      int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
+                      size_t ws_bin_bytes, uint32_t* total_patches, void* stream);
 int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,

@@ -11,7 +11,7 @@ dev = torch.device("cuda", 0)
 sc = S.big_scene(1_000_000, 1920, 1080, 48)
 cam = Camera.from_scene(sc.cam, dev)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
-P = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1), scales=t(sc.scales), rots=t(sc.rots))
+P = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1).clone(), scales=t(sc.scales), rots=t(sc.rots))
 for p in P.values():
     p.requires_grad_(True)
 us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
