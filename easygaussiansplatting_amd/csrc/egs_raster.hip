@@ -26,17 +26,20 @@ namespace egs {
 // stable LSD radix sort, 8-bit digits, (u32 key, u32 value)
 // ============================================================================
 constexpr int RS_THREADS = 256;
-constexpr int RS_IPT = 16;                         // items per thread
-constexpr int RS_TILE = RS_THREADS * RS_IPT;       // 4096 items per workgroup
-constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // 1024 contiguous items per wave
+// items per thread: 16 (4096-item tiles) for long arrays; 8 for short ones, where 4096-item tiles would
+// leave fewer workgroups than there are CUs (1 M depth keys = 245 tiles)
+constexpr int64_t RS_SHORT = 5 << 19;              // <= 2.6 M items: 2048-item tiles (measured: 4 M patches prefer 4096)
+static int rs_ipt(int64_t n) { return n <= RS_SHORT ? 8 : 16; }
 
 // `maxkey` (nullable, device): upper bound of all keys.  A pass whose digit is 0 for every key
 // ((*maxkey >> shift) == 0) is the identity permutation: hist/rowscan return at once and
 // scatter degenerates to a coalesced copy.
+template <int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
                                                            int shift, uint32_t dmask, int nblocks,
                                                            uint32_t* __restrict__ hist,
                                                            const uint32_t* __restrict__ maxkey) {
+  constexpr int RS_TILE = RS_THREADS * RS_IPT;
   __shared__ uint32_t h[256];
   const int tid = threadIdx.x;
   if (maxkey && ((*maxkey >> shift) == 0u)) return;
@@ -76,11 +79,14 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
 // is found with per-wave ballot multi-split (deterministic, no LDS atomics), the tile is written
 // digit-sorted into LDS, and then streamed out so that consecutive lanes write consecutive
 // addresses inside each digit run (coalesced) instead of 64 scattered dwords per instruction.
+template <int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
     int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
     const uint32_t* __restrict__ maxkey) {
+  constexpr int RS_TILE = RS_THREADS * RS_IPT;       // items per workgroup
+  constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // contiguous items per wave
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int64_t blockbase = (int64_t)blockIdx.x * RS_TILE;
   if (maxkey && ((*maxkey >> shift) == 0u)) {  // identity pass: plain copy
@@ -173,11 +179,11 @@ struct SortWs {
   int nblocks;
 };
 static size_t sort_ws_bytes(int64_t n) {
-  const int nb = n > 0 ? div_up(n, RS_TILE) : 1;
+  const int nb = n > 0 ? div_up(n, RS_THREADS * 8) : 1;   // sized for the smaller tile
   return align_up((size_t)256 * nb * 4, 256) + 256 * 4 + 512;
 }
 static bool sort_ws_carve(Carver& cv, int64_t n, SortWs* w) {
-  w->nblocks = n > 0 ? div_up(n, RS_TILE) : 1;
+  w->nblocks = n > 0 ? div_up(n, RS_THREADS * rs_ipt(n)) : 1;
   w->hist = cv.take<uint32_t>((size_t)256 * w->nblocks);
   w->totals = cv.take<uint32_t>(256);
   return cv.ok();
@@ -193,12 +199,20 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
   for (int shift = begin_bit; shift < end_bit; shift += 8) {
     const int nb = end_bit - shift < 8 ? end_bit - shift : 8;  // the last digit may be narrower
     const uint32_t dmask = (1u << nb) - 1u;
-    EGS_LAUNCH("k_radix_hist", k_radix_hist, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask, w.nblocks,
-               w.hist, maxkey);
+    if (rs_ipt(n) == 8)
+      EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
+                 w.nblocks, w.hist, maxkey);
+    else
+      EGS_LAUNCH("k_radix_hist", k_radix_hist<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
+                 w.nblocks, w.hist, maxkey);
     EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals, shift,
                maxkey);
-    EGS_LAUNCH("k_radix_scatter", k_radix_scatter, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
-               dmask, w.nblocks, w.hist, w.totals, maxkey);
+    if (rs_ipt(n) == 8)
+      EGS_LAUNCH("k_radix_scatter", k_radix_scatter<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
+                 dmask, w.nblocks, w.hist, w.totals, maxkey);
+    else
+      EGS_LAUNCH("k_radix_scatter", k_radix_scatter<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n,
+                 shift, dmask, w.nblocks, w.hist, w.totals, maxkey);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
