@@ -293,15 +293,23 @@ def main():
         opts = {"fused": FusedAdam(adam_groups(raw), eps=1e-15),
                 "torch": torch.optim.Adam(adam_groups(raw), lr=0.0, eps=1e-15)}
 
-        def train_step(opt):
+        from easygaussiansplatting_amd.function import GSRawFunction
+
+        def train_step(opt, fused_act=False):
             opt.zero_grad(set_to_none=True)
             us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-            img, _ = GSFunction.apply(*activate(raw), us, cam)
+            if fused_act:   # activations inside the HIP kernels
+                img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                             raw["scales_raw"], raw["rots_raw"], us, cam)
+            else:           # the reference's structure: torch activations around GSFunction
+                img, _ = GSFunction.apply(*activate(raw), us, cam)
             gau_loss(img, gt).backward()
             opt.step()
         train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
+        train_extra["train_step_ms_fused_activations_fused_adam"] = round(
+            timed(lambda: train_step(opts["fused"], True), nf), 4)
         for name, opt in opts.items():
-            train_extra["train_step_ms_%s_adam" % name] = round(timed(lambda: train_step(opt), nf), 4)
+            train_extra["train_step_ms_torch_activations_%s_adam" % name] = round(timed(lambda: train_step(opt), nf), 4)
             train_extra["adam_only_ms_%s" % name] = round(timed(opt.step, nf), 4)
 
     roofline = None

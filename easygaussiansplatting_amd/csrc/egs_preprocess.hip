@@ -245,6 +245,18 @@ struct PreParams {
   int stage_in;   // experiment knob (EGS_PRE_STAGE_IN): k_preprocess_bwd also stages the SH rows it reads
 };
 
+// ---- activations of the raw training parameters (reference gsplat/utils.py:121-150) -------------
+// The RAW variants of the fused kernels read the optimizer's own tensors -- alphas_raw, scales_raw,
+// rots_raw, low_shs [N,3] and high_shs [N,K-3] -- and return gradients with respect to THEM, so the
+// torch ops around GSFunction (sigmoid, exp, normalize, cat and their autograd twins: ~0.4 ms per
+// step at 1 M Gaussians, 12 launches, 0.9 GB of HBM traffic) disappear.
+__device__ __forceinline__ float act_alpha(float a) { return 1.f / (1.f + expf(-a)); }   // get_alphas
+__device__ __forceinline__ f3 act_scale(const f3& s) { return {expf(s.x), expf(s.y), expf(s.z)}; }  // get_scales
+__device__ __forceinline__ float4 act_rot(const float4& r, float& norm) {                // get_rots
+  norm = fmaxf(sqrtf(r.x * r.x + r.y * r.y + r.z * r.z + r.w * r.w), 1e-12f);            // F.normalize eps
+  return make_float4(r.x / norm, r.y / norm, r.z / norm, r.w / norm);
+}
+
 // ---- cooperative row staging through LDS --------------------------------------------------
 // A lane-per-Gaussian kernel that reads its own K-float SH row issues K/4 dwordx4 loads whose 64
 // lanes are 4K bytes apart (64 different cache lines per instruction).  Staged instead: the
@@ -326,13 +338,46 @@ __device__ __forceinline__ void stage_rows_out(const float* row, float* __restri
   }
 }
 
+// Rows whose width is not a multiple of 4 floats (the 45-float high_shs rows): the workgroup's 256 rows
+// are still ONE contiguous, 16-B aligned span (256 * K * 4 bytes), so the span moves as dwordx4 and lands
+// in LDS unpadded; lane t then owns lds[t*K .. t*K+K) -- an odd K makes the dword reads conflict-free.
+template <int K>
+__device__ __forceinline__ void stage_span_in(const float* __restrict__ src, int n, int base, float* lds, float* row) {
+  static_assert(K % 2 == 1, "odd row width expected (conflict-free LDS rows)");
+  const int rows = min(256, n - base);
+  const int tid = threadIdx.x;
+  const int total = rows * K, nq = total >> 2;
+  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + (size_t)K * base);
+  for (int f = tid; f < nq; f += 256) reinterpret_cast<float4*>(lds)[f] = s4[f];
+  for (int f = 4 * nq + tid; f < total; f += 256) lds[f] = src[(size_t)K * base + f];   // <= 3 tail floats
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < K; ++j) row[j] = lds[tid * K + j];
+}
+
+template <int K>
+__device__ __forceinline__ void stage_span_out(const float* row, float* __restrict__ dst, int n, int base, float* lds) {
+  const int rows = min(256, n - base);
+  const int tid = threadIdx.x;
+  __syncthreads();   // everyone is done reading the staged input rows
+#pragma unroll
+  for (int j = 0; j < K; ++j) lds[tid * K + j] = row[j];
+  __syncthreads();
+  const int total = rows * K, nq = total >> 2;
+  float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + (size_t)K * base);
+  for (int f = tid; f < nq; f += 256) d4[f] = reinterpret_cast<const float4*>(lds)[f];
+  for (int f = 4 * nq + tid; f < total; f += 256) dst[(size_t)K * base + f] = lds[f];
+}
+
 // forward.md steps 1-5 for one Gaussian in one pass (== gsmodel.py:21-35 minus splat):
 // writes exactly what splat / splatB / the backward pass consume.
-template <int NC>
+// RAW: rots/scales/alphas are the un-activated tensors, shs = low_shs [N,3], shs_high = high_shs [N,K-3]
+template <int NC, bool RAW>
 __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
                                                         const float* __restrict__ rots,
                                                         const float* __restrict__ scales,
                                                         const float* __restrict__ shs,
+                                                        const float* __restrict__ shs_high,
                                                         const float* __restrict__ alphas,
                                                         const float* __restrict__ Rcw,
                                                         const float* __restrict__ tcw,
@@ -344,16 +389,29 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
                                                         float4* __restrict__ rec, BinParams bp, BinCountOut bo,
                                                         uint8_t* __restrict__ visible) {
   constexpr int K = 3 * NC;
-  __shared__ float stage[RowStage<12>::LDS_FLOATS];
+  constexpr int KH = K - 3;   // width of high_shs
+  constexpr int STAGE_FLOATS = (RAW && KH > 0 && RowStage<KH>::LDS_FLOATS > RowStage<12>::LDS_FLOATS)
+                                   ? RowStage<KH>::LDS_FLOATS : RowStage<12>::LDS_FLOATS;
+  __shared__ float stage[STAGE_FLOATS];
   const int i = blockIdx.x * 256 + threadIdx.x;
   uint32_t dkey = 0u;
+  float sh[K];
+  if constexpr (RAW) {   // 180-B high_shs rows cannot be dwordx4-loaded per lane: the workgroup's span through LDS
+    if constexpr (KH > 0) {
+      if constexpr (KH % 2 == 1) stage_span_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+      else stage_rows_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+    }
+  }
   float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
     float col[3];
     {  // colour has no depth test in the reference (kernel.cu:619-725)
-      float sh[K];   // direct dwordx4 row loads: staging them through LDS measured 10 % slower here
-      load_sh_row<K>(shs + (size_t)K * i, sh);
+      if constexpr (RAW) {
+        sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
+      } else {  // direct dwordx4 row loads: staging them through LDS measured 10 % slower here
+        load_sh_row<K>(shs + (size_t)K * i, sh);
+      }
       const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
       sh_color_f<NC>(d, sh, col);
       st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
@@ -363,8 +421,10 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
     int rx = 0, ry = 0;
     if (!(pp.near_cull && P.pc.z < EGS_MIN_DEPTH)) {
       u0 = P.u0; u1 = P.u1; depth = P.pc.z;
-      const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-      const Cov3 c3 = cov3d_f(q, ld3(scales + 3 * (size_t)i));
+      float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+      f3 sc = ld3(scales + 3 * (size_t)i);
+      if constexpr (RAW) { float nrm; q = act_rot(q, nrm); sc = act_scale(sc); }
+      const Cov3 c3 = cov3d_f(q, sc);
       const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
       const float det_inv = inv_cov2d_f(c2.c, pp.det_eps, ci);
       if (pp.nan_cull && isnan(det_inv)) {
@@ -390,8 +450,8 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
     areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry;
     // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
     if (rec)
-      make_record(u0, u1, ci[0], ci[1], ci[2], alphas[i], col[0], col[1], col[2], rx, ry, pp.W, pp.H, pp.footprint,
-                  pp.alpha_skip, r);
+      make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alphas[i]) : alphas[i], col[0], col[1], col[2], rx, ry,
+                  pp.W, pp.H, pp.footprint, pp.alpha_skip, r);
   }
   if (bo.rects) block_max_key(dkey, bo.maxkey);
   // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
@@ -401,20 +461,33 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
 // backward.md eq (3)(4)(5)(7) == gsmodel.py:71-85 with every Jacobian re-derived in
 // registers from the parameters.  gpack = the packed per-Gaussian gradient records
 // written by k_draw_bwd: {dalpha, dcolor[3], du[2], dcinv[3], pad[3]}.
-template <int NC>
+// RAW: parameters as in k_preprocess_fwd<.., true>; gradients come out with respect to the raw tensors
+// (dL_dsh = low_shs [N,3], dL_dsh_high = high_shs [N,K-3]); alphas = alphas_raw (only read when RAW)
+template <int NC, bool RAW>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int n, PreParams pp, const float* __restrict__ pws, const float* __restrict__ rots,
-    const float* __restrict__ scales, const float* __restrict__ shs, const float* __restrict__ Rcw,
+    const float* __restrict__ scales, const float* __restrict__ shs, const float* __restrict__ shs_high,
+    const float* __restrict__ alphas, const float* __restrict__ Rcw,
     const float* __restrict__ tcw, const float* __restrict__ twc, const float* __restrict__ depths,
     const float4* __restrict__ gpack, float* __restrict__ dL_dpw, float* __restrict__ dL_dsh,
-    float* __restrict__ dL_dalpha, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
+    float* __restrict__ dL_dsh_high, float* __restrict__ dL_dalpha, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
     float* __restrict__ dL_du) {
   constexpr int K = 3 * NC;
-  __shared__ float stage[RowStage<K>::LDS_FLOATS];
+  constexpr int KH = K - 3;
+  constexpr int KS = RAW ? (KH > 0 ? KH : 1) : K;   // width of the rows that go through LDS
+  __shared__ float stage[RowStage<KS>::LDS_FLOATS];
   const int i = blockIdx.x * 256 + threadIdx.x;
   float sh[K], gsh[K];
-  if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
-  else if (i < n) load_sh_row<K>(shs + (size_t)K * i, sh);
+  if constexpr (RAW) {
+    if constexpr (KH > 0) {
+      if constexpr (KH % 2 == 1) stage_span_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+      else stage_rows_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+    }
+    if (i < n) { sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2]; }
+  } else {
+    if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
+    else if (i < n) load_sh_row<K>(shs + (size_t)K * i, sh);
+  }
 #pragma unroll
   for (int k = 0; k < K; ++k) gsh[k] = 0.f;
   if (i < n) {
@@ -422,7 +495,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const f3 gcol = {ga.y, ga.z, ga.w};
     const float gu0 = gb.x, gu1 = gb.y;
     const f3 gci = {gb.z, gb.w, gc.x};
-    dL_dalpha[i] = ga.x;
+    if constexpr (RAW) {
+      const float al = act_alpha(alphas[i]);
+      dL_dalpha[i] = ga.x * al * (1.f - al);   // sigmoid'
+    } else {
+      dL_dalpha[i] = ga.x;
+    }
     dL_du[2 * (size_t)i] = gu0; dL_du[2 * (size_t)i + 1] = gu1;
     if (pp.near_cull && depths[i] < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
       st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
@@ -430,8 +508,10 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
     } else {
       const f3 pw = ld3(pws + 3 * (size_t)i);
-      const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-      const f3 s = ld3(scales + 3 * (size_t)i);
+      float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+      f3 s = ld3(scales + 3 * (size_t)i);
+      float qnorm = 1.f;
+      if constexpr (RAW) { q = act_rot(q, qnorm); s = act_scale(s); }
       const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
       const Cov3 c3 = cov3d_f(q, s);
       const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
@@ -450,6 +530,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       for (int k = 0; k < 6; ++k) g3[k] = g2[0] * J3[k] + g2[1] * J3[6 + k] + g2[2] * J3[12 + k];
       q4 gq; f3 gs;
       cov3d_vjp(c3, q, s, g3, gq, gs);
+      if constexpr (RAW) {   // through normalize: (g - q (q.g)) / |r|; through exp: g * scale
+        const float qg = q.x * gq.w + q.y * gq.x + q.z * gq.y + q.w * gq.z;
+        gq = {(gq.w - q.x * qg) / qnorm, (gq.x - q.y * qg) / qnorm, (gq.y - q.z * qg) / qnorm,
+              (gq.z - q.w * qg) / qnorm};
+        gs = {gs.x * s.x, gs.y * s.y, gs.z * s.z};
+      }
       st4(dL_drot + 4 * (size_t)i, gq);      // eq (3)
       st3(dL_dscale + 3 * (size_t)i, gs);    // eq (4)
       float j00, j02, j11, j12;
@@ -472,7 +558,15 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
                  gcol.z * W[6 + k];
     }
   }
-  stage_rows_out<K>(gsh, dL_dsh, n, blockIdx.x * 256, stage);
+  if constexpr (RAW) {
+    if (i < n) { dL_dsh[3 * (size_t)i] = gsh[0]; dL_dsh[3 * (size_t)i + 1] = gsh[1]; dL_dsh[3 * (size_t)i + 2] = gsh[2]; }
+    if constexpr (KH > 0) {
+      if constexpr (KH % 2 == 1) stage_span_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage);
+      else stage_rows_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage);
+    }
+  } else {
+    stage_rows_out<K>(gsh, dL_dsh, n, blockIdx.x * 256, stage);
+  }
 }
 
 }  // namespace egs
@@ -611,12 +705,12 @@ static PreParams make_pre_params(const EgsPolicy* pol, float fx, float fy, float
   return pp;
 }
 
-extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
-                                 const float* shs, const float* alphas, const float* Rcw, const float* tcw,
-                                 const float* twc, float fx, float fy, float cx, float cy, int width, int height,
-                                 const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                                 int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                                 size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, const float* rots, const float* scales,
+                              const float* shs, const float* shs_high, const float* alphas, const float* Rcw,
+                              const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
+                              int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds,
+                              float* colors, int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint,
+                              void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
@@ -628,7 +722,9 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
   EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && us && depths && cinv2ds && colors && areas);
   EGS_CHECK_ARG(!rec || alphas);
   EGS_CHECK_ARG(ws_bin);
-  EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0 && (sh_dim % 4 != 0 || ((uintptr_t)shs & 15) == 0));
+  EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0);
+  if (raw) EGS_CHECK_ARG(sh_dim == 3 || (shs_high && ((uintptr_t)shs_high & 15) == 0));
+  else EGS_CHECK_ARG(sh_dim % 4 != 0 || ((uintptr_t)shs & 15) == 0);
   BinCountOut bo;
   if (!bin_count_outputs(ws_bin, ws_bin_bytes, n, &bo)) {
     set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
@@ -637,14 +733,18 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
   const BinParams bp = make_bin_params(width, height, pol);
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
   dim3 g(div_up(n, 256)), b(256);
-#define EGS_PRE(NC)                                                                                            \
-  EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC>), g, b, s, n, pp, pws, rots, scales, shs, alphas, Rcw,  \
-             tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo, visible)
-  switch (sh_dim) {
-    case 3: EGS_PRE(1); break;
-    case 12: EGS_PRE(4); break;
-    case 27: EGS_PRE(9); break;
-    default: EGS_PRE(16); break;
+#define EGS_PRE(NC, RAW)                                                                                        \
+  EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW>), g, b, s, n, pp, pws, rots, scales, shs, shs_high, \
+             alphas, Rcw, tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo, visible)
+  switch (sh_dim * 2 + (raw ? 1 : 0)) {
+    case 6: EGS_PRE(1, false); break;
+    case 7: EGS_PRE(1, true); break;
+    case 24: EGS_PRE(4, false); break;
+    case 25: EGS_PRE(4, true); break;
+    case 54: EGS_PRE(9, false); break;
+    case 55: EGS_PRE(9, true); break;
+    case 96: EGS_PRE(16, false); break;
+    default: EGS_PRE(16, true); break;
   }
 #undef EGS_PRE
   EGS_LAUNCH_OK();
@@ -652,23 +752,48 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
   return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
 }
 
+extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
+                                 const float* shs, const float* alphas, const float* Rcw, const float* tcw,
+                                 const float* twc, float fx, float fy, float cx, float cy, int width, int height,
+                                 const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
+                                 int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
+                                 size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+  return fused_forward_impl(false, n, sh_dim, pws, rots, scales, shs, nullptr, alphas, Rcw, tcw, twc, fx, fy, cx, cy,
+                            width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible, key_bits_hint,
+                            ws_bin, ws_bin_bytes, total_patches, stream);
+}
+
+extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots_raw,
+                                     const float* scales_raw, const float* low_shs, const float* high_shs,
+                                     const float* alphas_raw, const float* Rcw, const float* tcw, const float* twc,
+                                     float fx, float fy, float cx, float cy, int width, int height,
+                                     const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
+                                     int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
+                                     size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+  EGS_CHECK_ARG(n == 0 || (rec && alphas_raw));  // the activated alpha only exists inside the records
+  return fused_forward_impl(true, n, sh_dim, pws, rots_raw, scales_raw, low_shs, high_shs, alphas_raw, Rcw, tcw, twc,
+                            fx, fy, cx, cy, width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible,
+                            key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
+}
+
 extern "C" size_t egs_fused_backward_ws_bytes(int n) { return egs_splat_bwd_ws_bytes(n); }
 
-extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
-                                  const float* rots, const float* scales, const float* shs, const float* alphas,
-                                  const float* Rcw, const float* tcw, const float* twc, float fx, float fy, float cx,
-                                  float cy, const EgsPolicy* pol, const float* us, const float* cinv2ds,
-                                  const float* colors, const int32_t* areas, const void* rec, const float* depths,
-                                  const int32_t* contrib, const float* final_tau,
-                                  const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
-                                  const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
-                                  float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                                  float* dloss_drots, float* dloss_dus, void* stream) {
+static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
+                               const float* rots, const float* scales, const float* shs, const float* shs_high,
+                               const float* alphas, const float* Rcw, const float* tcw, const float* twc, float fx,
+                               float fy, float cx, float cy, const EgsPolicy* pol, const float* us,
+                               const float* cinv2ds, const float* colors, const int32_t* areas, const void* rec,
+                               const float* depths, const int32_t* contrib, const float* final_tau,
+                               const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
+                               const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
+                               float* dloss_dshs, float* dloss_dshs_high, float* dloss_dalphas, float* dloss_dscales,
+                               float* dloss_drots, float* dloss_dus, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && patches >= 0);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
   if (n == 0) return 0;
   EGS_CHECK_ARG(pws && rots && scales && shs && alphas && Rcw && tcw && twc && depths && ws && dloss_dpws &&
                 dloss_dshs && dloss_dalphas && dloss_dscales && dloss_drots && dloss_dus);
+  if (raw) EGS_CHECK_ARG(rec && (sh_dim == 3 || (shs_high && dloss_dshs_high)));
   if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
     set_error(EGS_ERR_WORKSPACE, "fused_backward workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
@@ -680,17 +805,56 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
   dim3 g(div_up(n, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
-#define EGS_PREB(NC)                                                                                           \
-  EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC>), g, b, s, n, pp, pws, rots, scales, shs, Rcw, tcw, twc, \
-             depths, (const float4*)gpack, dloss_dpws, dloss_dshs, dloss_dalphas, dloss_dscales, dloss_drots,    \
-             dloss_dus)
-  switch (sh_dim) {
-    case 3: EGS_PREB(1); break;
-    case 12: EGS_PREB(4); break;
-    case 27: EGS_PREB(9); break;
-    default: EGS_PREB(16); break;
+#define EGS_PREB(NC, RAW)                                                                                       \
+  EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW>), g, b, s, n, pp, pws, rots, scales, shs, shs_high, \
+             alphas, Rcw, tcw, twc, depths, (const float4*)gpack, dloss_dpws, dloss_dshs, dloss_dshs_high,       \
+             dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus)
+  switch (sh_dim * 2 + (raw ? 1 : 0)) {
+    case 6: EGS_PREB(1, false); break;
+    case 7: EGS_PREB(1, true); break;
+    case 24: EGS_PREB(4, false); break;
+    case 25: EGS_PREB(4, true); break;
+    case 54: EGS_PREB(9, false); break;
+    case 55: EGS_PREB(9, true); break;
+    case 96: EGS_PREB(16, false); break;
+    default: EGS_PREB(16, true); break;
   }
 #undef EGS_PREB
   EGS_LAUNCH_OK();
   return 0;
+}
+
+extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
+                                  const float* rots, const float* scales, const float* shs, const float* alphas,
+                                  const float* Rcw, const float* tcw, const float* twc, float fx, float fy, float cx,
+                                  float cy, const EgsPolicy* pol, const float* us, const float* cinv2ds,
+                                  const float* colors, const int32_t* areas, const void* rec, const float* depths,
+                                  const int32_t* contrib, const float* final_tau,
+                                  const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
+                                  const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
+                                  float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
+                                  float* dloss_drots, float* dloss_dus, void* stream) {
+  return fused_backward_impl(false, n, sh_dim, patches, width, height, pws, rots, scales, shs, nullptr, alphas, Rcw,
+                             tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths, contrib,
+                             final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, dloss_dpws,
+                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, stream);
+}
+
+extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
+                                      const float* rots_raw, const float* scales_raw, const float* low_shs,
+                                      const float* high_shs, const float* alphas_raw, const float* Rcw,
+                                      const float* tcw, const float* twc, float fx, float fy, float cx, float cy,
+                                      const EgsPolicy* pol, const float* us, const float* cinv2ds,
+                                      const float* colors, const int32_t* areas, const void* rec,
+                                      const float* depths, const int32_t* contrib, const float* final_tau,
+                                      const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
+                                      const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
+                                      float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
+                                      float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
+                                      void* stream) {
+  return fused_backward_impl(true, n, sh_dim, patches, width, height, pws, rots_raw, scales_raw, low_shs, high_shs,
+                             alphas_raw, Rcw, tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths,
+                             contrib, final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes,
+                             dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
+                             dloss_drots_raw, dloss_dus, stream);
 }

@@ -105,6 +105,34 @@ class GSFunction(torch.autograd.Function):
                 dloss_dus.reshape(n, 2), None)
 
 
+class GSRawFunction(torch.autograd.Function):
+    """``GSModel.forward`` (gsmodel.py:185-212) as ONE autograd node on the optimizer's tensors:
+    inputs ``(pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw, us, cam)`` -- the argument order
+    of ``GSModel.forward`` -- outputs ``(image, depths > 0.2)``.  The activations (sigmoid, exp,
+    normalize, cat; gsplat/utils.py:121-150) and their derivatives run inside the fused kernels."""
+
+    @staticmethod
+    def forward(ctx, pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw, us, cam):
+        ctx.set_materialize_grads(False)
+        image, mask, state = _fused.forward(pws, low_shs, alphas_raw, scales_raw, rots_raw, cam, high_shs=high_shs)
+        ctx.cam = cam
+        ctx.state = state
+        ctx.save_for_backward(pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw)
+        ctx.mark_non_differentiable(mask)
+        return image, mask
+
+    @staticmethod
+    def backward(ctx, dloss_dgammas, _):
+        if dloss_dgammas is None:
+            return (None,) * 8
+        pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw = ctx.saved_tensors
+        dpws, dlow, dhigh, dalphas, dscales, drots, dus = _fused.backward(
+            pws, low_shs, alphas_raw, scales_raw, rots_raw, ctx.cam, ctx.state, dloss_dgammas.contiguous(),
+            high_shs=high_shs)
+        ctx.state = None
+        return dpws, dlow, dhigh, dalphas, dscales, drots, dus, None
+
+
 def render(pws, shs, alphas, scales, rots, cam, calc_J=False):
     """Inference path of the reference's forward_gpu.py:47-60 (six op calls)."""
     us, pcs, depths = gsc.project(pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, False)

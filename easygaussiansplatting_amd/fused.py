@@ -27,15 +27,31 @@ class FusedState:
                  "width", "height")
 
 
-def forward(pws, shs, alphas, scales, rots, cam):
+def _split_sh(low_shs, high_shs, n):
+    low = _chk(low_shs, "low_shs", torch.float32, (n, 3))
+    high = _chk(high_shs, "high_shs", torch.float32, (n, None))
+    K = 3 + high.shape[1]
+    if K not in (3, 12, 27, 48):
+        raise ValueError("low_shs + high_shs must have 3, 12, 27 or 48 columns, got %d" % K)
+    return low, high, K
+
+
+def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
     """-> (image[3,H,W], mask[N] bool, state).  ``cam`` carries Rcw/tcw/twc device
-    tensors and fx, fy, cx, cy, width, height (reference gausplat_dataset.py:14-26)."""
+    tensors and fx, fy, cx, cy, width, height (reference gausplat_dataset.py:14-26).
+    With ``high_shs`` the inputs are the RAW training tensors (``shs`` = low_shs, ``alphas`` =
+    alphas_raw, ``scales`` = scales_raw, ``rots`` = rots_raw) and the activations of
+    gsplat/utils.py:121-150 run inside the kernel (egs_fused_forward_raw)."""
+    raw = high_shs is not None
     pws = _chk(pws, "pws", torch.float32, (None, 3))
     n = pws.shape[0]
-    shs = _chk(shs, "shs", torch.float32, (n, None))
-    K = shs.shape[1]
-    if K not in (3, 12, 27, 48):
-        raise ValueError("shs must have 3, 12, 27 or 48 columns, got %d" % K)
+    if raw:
+        shs, high_shs, K = _split_sh(shs, high_shs, n)
+    else:
+        shs = _chk(shs, "shs", torch.float32, (n, None))
+        K = shs.shape[1]
+        if K not in (3, 12, 27, 48):
+            raise ValueError("shs must have 3, 12, 27 or 48 columns, got %d" % K)
     alphas = _alphas(alphas, n)
     scales = _chk(scales, "scales", torch.float32, (n, 3))
     rots = _chk(rots, "rots", torch.float32, (n, 4))
@@ -59,11 +75,16 @@ def forward(pws, shs, alphas, scales, rots, cam):
     mask = torch.empty((n,), dtype=torch.bool, device=dev)        # depths > 0.2, written by the kernel
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
-    patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward(
-        n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc),
-        float(cam.fx), float(cam.fy), float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths),
-        _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin), ws_bin_bytes,
-        _ptr(total), st)))
+    tail = lambda hint, total: (_ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc), float(cam.fx), float(cam.fy),
+                                float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
+                                _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin),
+                                ws_bin_bytes, _ptr(total), st)
+    if raw:
+        patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
+            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *tail(hint, total))))
+    else:
+        patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward(
+            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *tail(hint, total))))
     image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
     S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
@@ -77,13 +98,19 @@ def forward(pws, shs, alphas, scales, rots, cam):
     return image, mask, S
 
 
-def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas):
+def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, high_shs=None):
     """-> (dloss_dpws[N,3], dloss_dshs[N,K], dloss_dalphas[N,1], dloss_dscales[N,3],
-           dloss_drots[N,4], dloss_dus[N,2])  -- the gradient tuple of gsmodel.py:87-93."""
+           dloss_drots[N,4], dloss_dus[N,2])  -- the gradient tuple of gsmodel.py:87-93.
+    With ``high_shs`` (raw tensors, see ``forward``): -> (dpws, dlow_shs[N,3], dhigh_shs[N,K-3],
+    dalphas_raw[N,1], dscales_raw, drots_raw, dus)."""
+    raw = high_shs is not None
     pws = _chk(pws, "pws", torch.float32, (None, 3))
     n = pws.shape[0]
-    shs = _chk(shs, "shs", torch.float32, (n, None))
-    K = shs.shape[1]
+    if raw:
+        shs, high_shs, K = _split_sh(shs, high_shs, n)
+    else:
+        shs = _chk(shs, "shs", torch.float32, (n, None))
+        K = shs.shape[1]
     alphas = _alphas(alphas, n)
     scales = _chk(scales, "scales", torch.float32, (n, 3))
     rots = _chk(rots, "rots", torch.float32, (n, 4))
@@ -93,18 +120,23 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas):
     dev = pws.device
     f32 = torch.float32
     dpws = torch.empty((n, 3), dtype=f32, device=dev)
-    dshs = torch.empty((n, K), dtype=f32, device=dev)
+    dshs = torch.empty((n, 3 if raw else K), dtype=f32, device=dev)
+    dhigh = torch.empty((n, K - 3), dtype=f32, device=dev) if raw else None
     dalphas = torch.empty((n, 1), dtype=f32, device=dev)
     dscales = torch.empty((n, 3), dtype=f32, device=dev)
     drots = torch.empty((n, 4), dtype=f32, device=dev)
     dus = torch.empty((n, 2), dtype=f32, device=dev)
     ws_bytes = lib.egs_fused_backward_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    mid = (_ptr(alphas), _ptr(cam.Rcw), _ptr(cam.tcw), _ptr(cam.twc), float(cam.fx), float(cam.fy), float(cam.cx),
+           float(cam.cy), C.byref(_pol()), _ptr(S.us), _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec),
+           _ptr(S.depths), _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), _ptr(dl), _ptr(ws),
+           ws_bytes, _ptr(dpws), _ptr(dshs))
+    if raw:
+        _lib.check(lib.egs_fused_backward_raw(n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales),
+                                              _ptr(shs), _ptr(high_shs), *mid, _ptr(dhigh), _ptr(dalphas),
+                                              _ptr(dscales), _ptr(drots), _ptr(dus), _stream()))
+        return dpws, dshs, dhigh, dalphas, dscales, drots, dus
     _lib.check(lib.egs_fused_backward(n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs),
-                                      _ptr(alphas), _ptr(cam.Rcw), _ptr(cam.tcw), _ptr(cam.twc), float(cam.fx),
-                                      float(cam.fy), float(cam.cx), float(cam.cy), C.byref(_pol()), _ptr(S.us),
-                                      _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(S.depths),
-                                      _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), _ptr(dl),
-                                      _ptr(ws), ws_bytes, _ptr(dpws), _ptr(dshs), _ptr(dalphas), _ptr(dscales),
-                                      _ptr(drots), _ptr(dus), _stream()))
+                                      *mid, _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _stream()))
     return dpws, dshs, dalphas, dscales, drots, dus

@@ -31,7 +31,7 @@ import torch.distributed as dist
 
 from . import dist_views as DV
 from .density import DensityControl, expon_lr
-from .function import Camera, GSFunction
+from .function import Camera, GSFunction, GSRawFunction
 from .loss import gau_loss
 from .optim import FusedAdam, adam_groups
 from .scene import gsdata_type
@@ -70,8 +70,12 @@ def make_optimizer(p, fused=True):
 
 class Trainer:
     def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
-                 scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0):
+                 scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0,
+                 fused_activations: bool = True):
         self.device = device
+        # True: GSRawFunction (activations inside the HIP kernels); False: torch activations + GSFunction,
+        # the reference's structure (gsmodel.py:198-210)
+        self.fused_activations = fused_activations
         self.params = raw_params_from_scene(scene, device)
         self.opt = make_optimizer(self.params, fused_adam)
         self.density = DensityControl(scene_size, max_steps, seed)
@@ -96,7 +100,12 @@ class Trainer:
         count = torch.zeros(n, dtype=torch.int32, device=self.device)
         for v in mine:
             us = torch.zeros((n, 2), device=self.device, requires_grad=True)     # gsmodel.py:198-199
-            image, mask = GSFunction.apply(*activate(self.params), us, self.cams[v])
+            if self.fused_activations:
+                p = self.params
+                image, mask = GSRawFunction.apply(p["pws"], p["low_shs"], p["high_shs"], p["alphas_raw"],
+                                                  p["scales_raw"], p["rots_raw"], us, self.cams[v])
+            else:
+                image, mask = GSFunction.apply(*activate(self.params), us, self.cams[v])
             loss = gau_loss(image, self.gts[v])
             (loss / len(view_ids)).backward()           # leaves accumulate the mean over ALL views of the step
             loss_sum += loss.detach()

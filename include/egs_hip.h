@@ -205,6 +205,28 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
                        float* dloss_drots, float* dloss_dus, void* stream);
 
+/* The same pair on the OPTIMIZER's tensors (gsplat/gsmodel.py:96-129: alphas_raw, scales_raw, rots_raw,
+ * low_shs [N,3], high_shs [N,sh_dim-3]): the activations of gsplat/utils.py:121-150 (sigmoid, exp,
+ * normalize, cat) are applied inside the kernels and the gradients come back with respect to the raw
+ * tensors, i.e. GSModel.forward (gsmodel.py:185-212) + GSFunction in two calls.  `rec` is required (the
+ * activated alpha only exists inside the records). */
+int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots_raw, const float* scales_raw,
+                          const float* low_shs, const float* high_shs, const float* alphas_raw, const float* Rcw,
+                          const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
+                          int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
+                          int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
+                          size_t ws_bin_bytes, uint32_t* total_patches, void* stream);
+int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
+                           const float* rots_raw, const float* scales_raw, const float* low_shs,
+                           const float* high_shs, const float* alphas_raw, const float* Rcw, const float* tcw,
+                           const float* twc, float fx, float fy, float cx, float cy, const EgsPolicy* pol,
+                           const float* us, const float* cinv2ds, const float* colors, const int32_t* areas,
+                           const void* rec, const float* depths, const int32_t* contrib, const float* final_tau,
+                           const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
+                           const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
+                           float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
+                           float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus, void* stream);
+
 /* ---- fused training loss -----------------------------------------
  * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the
  * 11x11 Gaussian window (sigma 1.5, zero padding) of reference gsplat/pytorch_ssim.py:10-66.

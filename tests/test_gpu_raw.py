@@ -1,0 +1,88 @@
+"""GSRawFunction (activations of gsplat/utils.py:121-150 inside the fused kernels) against the
+reference's structure: torch activations + GSFunction (gsmodel.py:198-210)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _raw_params(n, K, seed, w=160, h=96):
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera
+    sc = S.small_scene(n, w, h, K, seed=seed)
+    g = torch.Generator().manual_seed(seed)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32))
+    alphas = t(sc.alphas).clamp(1e-3, 1 - 1e-3)
+    p = {"pws": t(sc.pws), "low_shs": t(sc.shs[:, :3]).contiguous(), "high_shs": t(sc.shs[:, 3:]).contiguous(),
+         "alphas_raw": torch.log(alphas / (1 - alphas)).reshape(-1, 1),
+         "scales_raw": torch.log(t(sc.scales)),
+         "rots_raw": t(sc.rots) * (0.2 + 3 * torch.rand(n, 1, generator=g))}      # un-normalised on purpose
+    p["pws"][: n // 50, 2] = -50.0                                                # some behind the camera
+    return {k: v.cuda().contiguous() for k, v in p.items()}, Camera.from_scene(sc.cam)
+
+
+@pytest.mark.parametrize("K", [48, 12, 3])
+def test_raw_function_matches_torch_activations(K):
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    from easygaussiansplatting_amd.function import GSFunction, GSRawFunction
+    gsc.set_policy("gsplatcu")
+    n = 5000
+    base, cam = _raw_params(n, K, 11)
+    dl = torch.randn(3, cam.height, cam.width, device="cuda") / (3 * cam.height * cam.width)
+    names = ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")
+
+    def run(raw):
+        p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+        us = torch.zeros(n, 2, device="cuda", requires_grad=True)
+        if raw:
+            img, mask = GSRawFunction.apply(*[p[k] for k in names], us, cam)
+        else:
+            img, mask = GSFunction.apply(p["pws"], torch.cat((p["low_shs"], p["high_shs"]), dim=1),
+                                         torch.sigmoid(p["alphas_raw"]), torch.exp(p["scales_raw"]),
+                                         torch.nn.functional.normalize(p["rots_raw"]), us, cam)
+        img.backward(dl)
+        grads = {k: (p[k].grad if p[k].grad is not None else torch.zeros_like(p[k])) for k in names}
+        grads["us"] = us.grad
+        return img.detach(), mask, grads
+
+    img_a, mask_a, ga = run(False)
+    img_b, mask_b, gb = run(True)
+    assert torch.equal(mask_a, mask_b) and int(mask_a.sum()) < n
+    assert float((img_a - img_b).abs().max()) < 2e-5
+    for k in ga:
+        a, b = ga[k].cpu().numpy(), gb[k].cpu().numpy()
+        assert a.shape == b.shape, k
+        if a.size == 0:          # K == 3: high_shs has no columns
+            continue
+        scale = max(1.0, float(np.abs(a).max()))
+        assert np.abs(a - b).max() <= 2e-4 * scale, (k, np.abs(a - b).max(), scale)
+        # relative check on the bulk, so that a wrong factor cannot hide behind the absolute bound
+        big = np.abs(a) > 1e-3 * np.abs(a).max() if np.abs(a).max() > 0 else np.zeros_like(a, bool)
+        if big.any():
+            assert np.median(np.abs(a[big] - b[big]) / np.abs(a[big])) < 1e-4, k
+
+
+def test_raw_function_full_size_step_and_trainer_equivalence():
+    """1 M Gaussians: same image as the torch-activation path; and one Trainer step with either path moves the
+    parameters identically (Adam normalises the gradient, so this is a strict check of its direction)."""
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer
+    sc = S.small_scene(20000, 256, 144, 48, seed=2)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 2, radius=5.0)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    with torch.no_grad():
+        gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+    outs = []
+    for fused_act in (False, True):
+        start = S.small_scene(20000, 256, 144, 48, seed=2)
+        start.shs[:, :3] += 0.5
+        tr = Trainer(start, cams, gts, max_steps=100, scene_size=4.0, fused_activations=fused_act)
+        losses = [tr.step([0, 1]) for _ in range(3)]
+        outs.append((losses, {k: v.detach().cpu().numpy() for k, v in tr.params.items()}))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-4)
+    for k in outs[0][1]:
+        a, b = outs[0][1][k], outs[1][1][k]
+        # three Adam steps of size lr: parameters agree to a small fraction of the distance moved
+        assert np.abs(a - b).max() < 2e-3 * max(1e-3, np.abs(a).max()), k

@@ -16,6 +16,7 @@ ap.add_argument("--gaussians", type=int, default=1_000_000)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--train", action="store_true", help="whole optimizer step: GSRawFunction + HIP loss + FusedAdam")
 a = ap.parse_args()
 
 import torch
@@ -31,8 +32,23 @@ for p in P.values():
     p.requires_grad_(True)
 us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
 dl = torch.from_numpy(S.normal(1, 77, (3, a.height, a.width)).astype(np.float32)).to(dev) / (3 * a.width * a.height)
+if a.train:
+    from easygaussiansplatting_amd.function import GSRawFunction
+    from easygaussiansplatting_amd.loss import gau_loss
+    from easygaussiansplatting_amd.optim import FusedAdam, adam_groups
+    from easygaussiansplatting_amd.trainer import raw_params_from_scene
+    raw = raw_params_from_scene(sc, dev)
+    opt = FusedAdam(adam_groups(raw), eps=1e-15)
+    gt = torch.rand((3, a.height, a.width), device=dev)
 for _ in range(a.steps):
-    if a.fwd_only:
+    if a.train:
+        opt.zero_grad(set_to_none=True)
+        us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+        img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                     raw["scales_raw"], raw["rots_raw"], us, cam)
+        gau_loss(img, gt).backward()
+        opt.step()
+    elif a.fwd_only:
         with torch.no_grad():
             render(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam)
     else:
