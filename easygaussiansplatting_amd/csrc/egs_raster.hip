@@ -243,26 +243,22 @@ __global__ __launch_bounds__(256) void k_scan_partials(const uint32_t* __restric
   if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void k_scan_spine(uint32_t* __restrict__ partials, int nparts,
-                                                    uint32_t* __restrict__ total) {
-  __shared__ uint32_t sm[4];
-  uint32_t carry = 0;
-  for (int base = 0; base < nparts; base += 256) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = (i < nparts) ? partials[i] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block256_exclusive_scan(v, sm, &tot);
-    if (i < nparts) partials[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0 && total) *total = carry;
-}
-
+// second pass: every workgroup sums the partials of its predecessors itself (a few hundred values out
+// of L2 -- cheaper than a separate single-workgroup spine launch), then scans its tile
 __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__ in,
                                                     const uint32_t* __restrict__ gather, int64_t n,
                                                     const uint32_t* __restrict__ partials,
-                                                    uint32_t* __restrict__ out) {
+                                                    uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
   __shared__ uint32_t sm[4];
+  __shared__ uint32_t s_prefix;
+  uint32_t pre = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) pre += partials[i];
+  pre = wave_inclusive_scan(pre);
+  if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = pre;
+  __syncthreads();
+  if (threadIdx.x == 0) s_prefix = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  const uint32_t prefix = s_prefix;
   const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
   uint32_t v[SC_IPT];
   uint32_t s = 0;
@@ -272,7 +268,9 @@ __global__ __launch_bounds__(256) void k_scan_apply(const uint32_t* __restrict__
     v[k] = (i < n) ? in[gather ? gather[i] : i] : 0u;
     s += v[k];
   }
-  uint32_t ex = block256_exclusive_scan(s, sm, nullptr) + partials[blockIdx.x];
+  uint32_t blocksum;
+  uint32_t ex = block256_exclusive_scan(s, sm, &blocksum) + prefix;
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prefix + blocksum;
 #pragma unroll
   for (int k = 0; k < SC_IPT; ++k) {
     const int64_t i = base + k;
@@ -291,8 +289,7 @@ static int exclusive_scan(int64_t n, const uint32_t* in, const uint32_t* gather,
   }
   const int nb = div_up(n, SC_TILE);
   EGS_LAUNCH("k_scan_partials", k_scan_partials, dim3(nb), dim3(256), s, in, gather, n, partials);
-  EGS_LAUNCH("k_scan_spine", k_scan_spine, dim3(1), dim3(256), s, partials, nb, total);
-  EGS_LAUNCH("k_scan_apply", k_scan_apply, dim3(nb), dim3(256), s, in, gather, n, partials, out);
+  EGS_LAUNCH("k_scan_apply", k_scan_apply, dim3(nb), dim3(256), s, in, gather, n, partials, out, total);
   EGS_LAUNCH_OK();
   return 0;
 }
@@ -343,24 +340,53 @@ __global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __rest
   }
 }
 
-// createKeys (reference kernel.cu:46-80) in depth-sorted Gaussian order; the
-// depth half of the key is implicit in the emission order.
+// createKeys (reference kernel.cu:46-80) in depth-sorted Gaussian order; the depth half of the key is
+// implicit in the emission order.  The reference (and the first version here) lets every thread loop over
+// its own rect: lanes idle while the largest rect of the wave finishes and every store instruction is 64
+// scattered dwords (measured HBM traffic 149 MB for 33 MB of output).  Here the workgroup's 256 Gaussians
+// own ONE contiguous output span (offsets are a prefix sum): output slot s finds its owner by binary
+// search over the 256 offsets in LDS, so all lanes work and consecutive lanes write consecutive addresses.
 __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t* __restrict__ ids,
                                                   const uint32_t* __restrict__ offsets,
                                                   const uint4* __restrict__ rects,
                                                   uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid) {
-  const int j = blockIdx.x * 256 + threadIdx.x;
-  if (j >= n) return;
-  const uint32_t g = ids[j];
-  const uint4 r = rects[g];
-  if (r.z <= r.x || r.w <= r.y) return;
-  uint32_t off = offsets[j];
-  for (uint32_t y = r.y; y < r.w; ++y)
-    for (uint32_t x = r.x; x < r.z; ++x) {
-      tkeys[off] = y * (uint32_t)gx + x;
-      gsid[off] = g;
-      ++off;
-    }
+  __shared__ uint32_t s_off[257];   // offsets relative to the workgroup's first one; [256] = span length
+  __shared__ uint32_t s_g[256], s_xy[256], s_w[256];
+  const int tid = threadIdx.x;
+  const int j = blockIdx.x * 256 + tid;
+  uint32_t off = 0, cnt = 0, g = 0, x0 = 0, y0 = 0, w = 1;
+  if (j < n) {
+    g = ids[j];
+    const uint4 r = rects[g];
+    off = offsets[j];
+    if (r.z > r.x && r.w > r.y) { x0 = r.x; y0 = r.y; w = r.z - r.x; cnt = w * (r.w - r.y); }
+  }
+  // first offset of the workgroup (thread 0 always has a valid j) and the span length
+  __shared__ uint32_t s_first, s_last;
+  if (tid == 0) s_first = off;
+  const int last = min(255, n - 1 - blockIdx.x * 256);
+  if (tid == last) s_last = off + cnt;
+  __syncthreads();
+  const uint32_t first = s_first;
+  s_off[tid] = (j < n) ? off - first : 0xFFFFFFFFu;   // lanes past the end never own a slot
+  s_g[tid] = g;
+  s_xy[tid] = x0 | (y0 << 16);
+  s_w[tid] = w;
+  const uint32_t span = s_last - first;
+  __syncthreads();
+  for (uint32_t s0 = tid; s0 < span; s0 += 256) {
+    // owner = last t with s_off[t] <= s0 (Gaussians without patches share their successor's offset and
+    // are skipped by taking the LAST such t: it is the only one with cnt > 0 covering s0)
+    int lo = 0;
+#pragma unroll
+    for (int step = 128; step >= 1; step >>= 1)
+      if (s_off[lo + step] <= s0) lo += step;     // s_off[lo + step] with lo + step <= 255
+    const uint32_t r = s0 - s_off[lo];
+    const uint32_t ww = s_w[lo], xy = s_xy[lo];
+    const uint32_t ry = r / ww, rx = r - ry * ww;
+    tkeys[first + s0] = ((xy >> 16) + ry) * (uint32_t)gx + (xy & 0xFFFFu) + rx;
+    gsid[first + s0] = s_g[lo];
+  }
 }
 
 // getRanges (reference kernel.cu:125-150; its P==1 hole is closed here)
@@ -419,7 +445,6 @@ struct DrawParams {
   float alpha_skip, tau_stop;
   float lskip;   // log2(alpha_skip), -inf when there is no skip test
   int maha_floor, alpha_clamp;
-  int dbg;       // experiment knob (EGS_DBG), 0 in production
   int map_mode;  // 0: tile = block; 1: contiguous band per XCD; 2: tile rows interleaved over XCDs
 };
 
@@ -808,7 +833,7 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
           }
         }
       }
-      if (__any(any) && !(p.dbg & 2)) {  // wave-uniform
+      if (__any(any)) {  // wave-uniform
         float tot[9];
 #pragma unroll
         for (int q = 0; q < 9; ++q) tot[q] = reduce4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
@@ -818,14 +843,16 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         const int j = jj - e;
         // entries past the end of the list (top group of the last chunk) have stale LDS slots:
         // they are inert (all partials exactly 0) and must not touch memory
-        const bool rowact = (c * 64 + j < n) &&
-                            (tot[0] != 0.f || tot[1] != 0.f || tot[2] != 0.f || tot[3] != 0.f || tot[4] != 0.f ||
-                             tot[5] != 0.f || tot[6] != 0.f || tot[7] != 0.f || tot[8] != 0.f);
+        const bool rowact = c * 64 + j < n;
         const float4 D = sD[j];
         // B.5.2b / B.5.2c from the moments, then lane q (0..8) of each row takes quantity q so
         // that the 9 atomics of an entry are ONE instruction on ONE 48-byte gradient record
         // (packed order: dalpha, dcolor[3], du[2], dcinv[3]; 36 lanes active per group).
-        const float gux = -(D.x * tot[4] + D.y * tot[5]), guy = -(D.y * tot[4] + D.z * tot[5]);
+        // (du is the only quantity scaled by per-Gaussian data: an entry without contribution must stay
+        //  exactly 0 even if its cinv is not finite, so that the `v != 0` test below skips it)
+        const bool moved = tot[4] != 0.f || tot[5] != 0.f;
+        const float gux = moved ? -(D.x * tot[4] + D.y * tot[5]) : 0.f;
+        const float guy = moved ? -(D.y * tot[4] + D.z * tot[5]) : 0.f;
         const int q = lane & 15;
         float v = tot[0];
         v = (q == 1) ? tot[1] : v;
@@ -836,7 +863,7 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         v = (q == 6) ? -0.5f * tot[6] : v;
         v = (q == 7) ? -tot[7] : v;
         v = (q == 8) ? -0.5f * tot[8] : v;
-        if (!(p.dbg & 1) && rowact && q < 9 && v != 0.f)
+        if (rowact && q < 9 && v != 0.f)
           unsafeAtomicAdd(gpack + 12 * (size_t)__float_as_int(D.w) + q, v);
       }
     }
@@ -920,8 +947,6 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol) {
     return e ? atoi(e) : 2;
   }();
   p.map_mode = mode;
-  static const int dbg = [] { const char* e = getenv("EGS_DBG"); return e ? atoi(e) : 0; }();
-  p.dbg = dbg;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
