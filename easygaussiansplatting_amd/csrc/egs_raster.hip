@@ -196,8 +196,12 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
                       const uint32_t* maxkey = nullptr) {
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
-  for (int shift = begin_bit; shift < end_bit; shift += 8) {
-    const int nb = end_bit - shift < 8 ? end_bit - shift : 8;  // the last digit may be narrower
+  // the bits are spread evenly over the passes (13 tile bits = 7 + 6, not 8 + 5): fewer buckets per pass
+  // mean longer coalesced runs out of every tile
+  const int passes = sort_passes(begin_bit, end_bit);
+  const int width = (end_bit - begin_bit + passes - 1) / passes;
+  for (int shift = begin_bit; shift < end_bit; shift += width) {
+    const int nb = end_bit - shift < width ? end_bit - shift : width;  // the last digit may be narrower
     const uint32_t dmask = (1u << nb) - 1u;
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
@@ -1051,7 +1055,7 @@ int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_
   // call's max key, which comes back in total_patches[1]); if the hint turns out too small the
   // caller re-runs the stage with hint = 32.  Within the launched passes, digits that are zero
   // in every key still degenerate to copies (maxkey check on the device).
-  int end_bit = (key_bits_hint <= 0 || key_bits_hint > 32) ? 32 : ((key_bits_hint + 7) / 8) * 8;
+  const int end_bit = (key_bits_hint <= 0 || key_bits_hint > 32) ? 32 : key_bits_hint;
   int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey);
   if (rc) return rc;
   if (sort_passes(0, end_bit) & 1) {  // odd pass count: bring the result back to the primary buffers

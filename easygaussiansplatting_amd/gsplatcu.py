@@ -204,7 +204,7 @@ def _bin_stage(enqueue):
     enqueue(hint, total)
     p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
     need = mk.bit_length()
-    if hint < 32 and need > ((hint + 7) // 8) * 8:
+    if hint < 32 and need > hint:
         enqueue(32, total)
         p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
     _key_bits_hint = min(32, need + 1)
