@@ -175,11 +175,16 @@ def main():
                                        params["rots"], us0, cam)
         image.backward(dl)
         if exchange:  # gradient exchange: 59 floats per Gaussian, SUM then mean
-            grads = [params[k].grad for k in order]
-            hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
-            for h in hs:
-                h.wait()
-            torch._foreach_div_(grads, float(world))
+            flat = fused_path.flat_grad_buffer([params[k] for k in order])
+            if flat is not None:      # the fused backward hands out slices of one buffer: ONE all-reduce
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(float(world))
+            else:
+                grads = [params[k].grad for k in order]
+                hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
+                for h in hs:
+                    h.wait()
+                torch._foreach_div_(grads, float(world))
         return image
 
     def sync():

@@ -18,6 +18,7 @@ import ctypes as C
 import torch
 
 from . import _lib
+from .dist_views import flat_grad_buffer  # noqa: F401  (re-exported: the buffer is allocated here)
 from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _tiles
 
 
@@ -119,12 +120,22 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     lib = _lib_on(pws)
     dev = pws.device
     f32 = torch.float32
-    dpws = torch.empty((n, 3), dtype=f32, device=dev)
-    dshs = torch.empty((n, 3 if raw else K), dtype=f32, device=dev)
-    dhigh = torch.empty((n, K - 3), dtype=f32, device=dev) if raw else None
-    dalphas = torch.empty((n, 1), dtype=f32, device=dev)
-    dscales = torch.empty((n, 3), dtype=f32, device=dev)
-    drots = torch.empty((n, 4), dtype=f32, device=dev)
+    # The parameter gradients are slices of ONE allocation (order: pws, shs | low, high, alphas, scales,
+    # rots): a data-parallel caller exchanges all 59 floats per Gaussian with a single all-reduce of
+    # ``flat_grad_buffer(params)`` instead of five or six latency-bound ones (autograd adopts the slices as
+    # ``.grad`` without copying).
+    widths = [3, 3, K - 3, 1, 3, 4] if raw else [3, K, 1, 3, 4]
+    starts, at = [], 0
+    for w in widths:                      # every slice starts 16-B aligned (the kernels store dwordx4)
+        starts.append(at)
+        at += (n * w + 3) // 4 * 4
+    flat = torch.empty(at, dtype=f32, device=dev)
+    parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]
+    if raw:
+        dpws, dshs, dhigh, dalphas, dscales, drots = parts
+    else:
+        dpws, dshs, dalphas, dscales, drots = parts
+        dhigh = None
     dus = torch.empty((n, 2), dtype=f32, device=dev)
     ws_bytes = lib.egs_fused_backward_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

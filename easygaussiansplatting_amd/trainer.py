@@ -114,7 +114,7 @@ class Trainer:
                 gnorm += torch.where(mask, g, torch.zeros_like(g))
                 count += mask.to(torch.int32)
         if self.world > 1:   # sum over ranks of (sum over local views)/V == mean over all views
-            DV.allreduce_sum_([self.params[k].grad for k in self.params] + [gnorm, count, loss_sum])
+            DV.allreduce_sum_(DV.coalesce_grads(list(self.params.values())) + [gnorm, count, loss_sum])
         self.grad_accum += gnorm
         self.vis_count += count
         self.opt.step()

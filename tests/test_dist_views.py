@@ -101,3 +101,54 @@ def test_single_process_is_a_noop():
     assert torch.equal(t, torch.ones(4))
     assert DV.grad_exchange_bytes(1_000_000) == 236_000_000
     assert DV.views_for_rank(8, 3, 8) == [3] and DV.views_for_rank(8, 1, 2) == [1, 3, 5, 7]
+
+
+def _worker_flat(rank, world, port, q):
+    """Gradients laid out the way the fused backward allocates them: 16-B aligned slices of one buffer."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        n, widths = 37, (3, 48, 1, 3, 4)
+        starts, at = [], 0
+        for w in widths:
+            starts.append(at)
+            at += (n * w + 3) // 4 * 4
+        flat = torch.full((at,), float("nan"), dtype=torch.float32)      # padding stays garbage
+        params = {}
+        for k, a, w in zip(DV.PARAM_ORDER, starts, widths):
+            p = torch.zeros(n, w, requires_grad=True)
+            g = flat[a:a + n * w].view(n, w)
+            g.copy_(torch.arange(n * w, dtype=torch.float32).view(n, w) * (rank + 1) + a)
+            p.grad = g
+            params[k] = p
+        calls = []
+        real = dist.all_reduce
+        dist.all_reduce = lambda t, *a, **k: (calls.append(t.numel()), real(t, *a, **k))[1]
+        try:
+            DV.exchange_gradients(params)
+        finally:
+            dist.all_reduce = real
+        q.put((rank, calls, {k: params[k].grad.numpy().copy() for k in DV.PARAM_ORDER}, starts))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_exchange_of_a_flat_gradient_buffer_is_one_collective():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_flat, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    n, widths = 37, (3, 48, 1, 3, 4)
+    for rank, calls, grads, starts in res:
+        assert len(calls) == 1 and calls[0] >= 59 * n          # ONE all-reduce over the whole buffer
+        for k, a, w in zip(DV.PARAM_ORDER, starts, widths):
+            want = np.arange(n * w, dtype=np.float32).reshape(n, w) * 1.5 + a      # mean of x1 and x2
+            np.testing.assert_allclose(grads[k], want, rtol=1e-6)

@@ -86,3 +86,34 @@ def test_raw_function_full_size_step_and_trainer_equivalence():
         a, b = outs[0][1][k], outs[1][1][k]
         # three Adam steps of size lr: parameters agree to a small fraction of the distance moved
         assert np.abs(a - b).max() < 2e-3 * max(1e-3, np.abs(a).max()), k
+
+
+@pytest.mark.parametrize("n", [4001, 5000])
+def test_parameter_gradients_share_one_buffer(n):
+    """The fused backward hands out the parameter gradients as 16-B aligned slices of one allocation, and
+    autograd adopts them as .grad without copying: a data-parallel caller all-reduces ONE tensor."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import GSFunction, GSRawFunction
+    base, cam = _raw_params(n, 48, 5)
+    dl = torch.randn(3, cam.height, cam.width, device="cuda") / (3 * cam.height * cam.width)
+    p = {k: v.clone().requires_grad_(True) for k, v in base.items()}
+    us = torch.zeros(n, 2, device="cuda", requires_grad=True)
+    names = ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")
+    img, _ = GSRawFunction.apply(*[p[k] for k in names], us, cam)
+    img.backward(dl)
+    flat = fused.flat_grad_buffer([p[k] for k in names])
+    assert flat is not None and flat.numel() >= 59 * n and flat.numel() < 59 * n + 24
+    for k in names:
+        assert p[k].grad.data_ptr() % 16 == 0
+        assert p[k].grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr()
+    before = p["high_shs"].grad.clone()
+    flat.mul_(2.0)                                       # what an all-reduce + scale does: in place, all at once
+    assert torch.equal(p["high_shs"].grad, before * 2)
+    # the activated-parameter function too
+    q = [base["pws"].clone(), torch.cat((base["low_shs"], base["high_shs"]), 1), torch.sigmoid(base["alphas_raw"]),
+         torch.exp(base["scales_raw"]), torch.nn.functional.normalize(base["rots_raw"])]
+    q = [t.contiguous().requires_grad_(True) for t in q]
+    img, _ = GSFunction.apply(*q, torch.zeros(n, 2, device="cuda", requires_grad=True), cam)
+    img.backward(dl)
+    assert fused.flat_grad_buffer(q) is not None
+    assert fused.flat_grad_buffer(q[:3]) is None         # does not tile the buffer
