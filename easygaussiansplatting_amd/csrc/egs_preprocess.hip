@@ -414,7 +414,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
       }
       const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
       sh_color_f<NC>(d, sh, col);
-      st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
+      if (colors) st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
     }
     const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
     float u0 = 0.f, u1 = 0.f, depth = EGS_BAD_MARKER, ci[3] = {0.f, 0.f, 0.f};
@@ -443,11 +443,13 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
       bo.counts[i] = cnt;
       bo.dkeys[i] = dkey;
     }
-    us[2 * (size_t)i] = u0; us[2 * (size_t)i + 1] = u1;
+    // us / cinv2ds / colors / areas are only needed by callers that go on with the seven-op surface; the
+    // fused path draws from the packed records alone and passes NULL (40 B/Gaussian less to write)
+    if (us) { us[2 * (size_t)i] = u0; us[2 * (size_t)i + 1] = u1; }
     depths[i] = depth;
     if (visible) visible[i] = depth > 0.2f;  // the mask GSFunction returns (gsmodel.py:50)
-    st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
-    areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry;
+    if (cinv2ds) st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
+    if (areas) { areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry; }
     // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
     if (rec)
       make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alphas[i]) : alphas[i], col[0], col[1], col[2], rx, ry,
@@ -719,7 +721,8 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
     EGS_HIP(hipMemsetAsync(total_patches, 0, 8, s));
     return 0;
   }
-  EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && us && depths && cinv2ds && colors && areas);
+  EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && depths);
+  EGS_CHECK_ARG(rec || (us && cinv2ds && colors && areas));   // something must carry the 2D Gaussians on
   EGS_CHECK_ARG(!rec || alphas);
   EGS_CHECK_ARG(ws_bin);
   EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0);

@@ -716,7 +716,6 @@ template <bool BOX, bool FLOOR, bool CLAMP>
 __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __restrict__ ranges,
                                                  const int32_t* __restrict__ gsid,
                                                  const float4* __restrict__ rec,
-                                                 const float* __restrict__ cinv,
                                                  const float* __restrict__ final_tau,
                                                  const int32_t* __restrict__ contrib,
                                                  const float* __restrict__ dLdg,
@@ -769,8 +768,10 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
       sA[lane] = A;
       sB[lane] = B;
       sC[lane] = C;
-      sD[lane] = make_float4(cinv[3 * (size_t)g], cinv[3 * (size_t)g + 1], cinv[3 * (size_t)g + 2],
-                             __int_as_float(g));
+      // cinv back out of the pre-scaled conic of the record (q = -0.5 log2(e) (cinv.x, 2 cinv.y, cinv.z)):
+      // no second 12-B gather per patch (131 MB of sector traffic at P = 4.1 M)
+      constexpr float INVQ = 1.f / EGS_NHL2E;
+      sD[lane] = make_float4(A.z * INVQ, A.w * (0.5f * INVQ), B.x * INVQ, __int_as_float(g));
     }
     __syncthreads();
     // Groups of four entries aligned to 4 (jj = 4m+3): every j = jj-e is >= 0.  Entries above
@@ -1168,7 +1169,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   (void)ws_bytes;
   EGS_HIP(hipMemsetAsync(gpack, 0, (size_t)n * 48, s));
   if (patches == 0) return 0;
-  EGS_CHECK_ARG(cinv2ds && contrib && final_tau && patch_range_per_tile && gsid_per_patch && dloss_dgammas);
+  EGS_CHECK_ARG(contrib && final_tau && patch_range_per_tile && gsid_per_patch && dloss_dgammas);
+  EGS_CHECK_ARG(rec_in || (us && cinv2ds && alphas && colors && (areas || pol->footprint != 1)));
   EGS_CHECK_ARG(rec_in || (us && alphas && colors && (pol->footprint == 0 || areas)));
   const DrawParams dp = make_draw_params(width, height, pol);
   if (!rec_in)
@@ -1176,7 +1178,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), draw_lds_pad(1), s, \
-                 dp, patch_range_per_tile, gsid_per_patch, rec, cinv2ds, final_tau, contrib, dloss_dgammas, gpack)
+                 dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, gpack)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {
     case 0: EGS_DRAWB(false, false, false); break;

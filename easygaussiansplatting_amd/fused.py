@@ -67,11 +67,10 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
     f32, i32 = torch.float32, torch.int32
     S = FusedState()
     S.width, S.height = W, H
-    S.us = torch.empty((n, 2), dtype=f32, device=dev)
+    # the draw kernels (forward and backward) work from the packed records alone: us / cinv2ds / colors /
+    # areas are not materialised
+    S.us = S.cinv2ds = S.colors = S.areas = None
     S.depths = torch.empty((n,), dtype=f32, device=dev)
-    S.cinv2ds = torch.empty((n, 3), dtype=f32, device=dev)
-    S.colors = torch.empty((n, 3), dtype=f32, device=dev)
-    S.areas = torch.empty((n, 2), dtype=i32, device=dev)
     S.rec = torch.empty((max(n, 1), 12), dtype=f32, device=dev)   # packed 2D records, reused by backward
     mask = torch.empty((n,), dtype=torch.bool, device=dev)        # depths > 0.2, written by the kernel
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)

@@ -180,7 +180,9 @@ int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss
  *                         eq (3)(4)(5)(7) (gsmodel.py:71-85).
  * `depths`/`areas` are the arrays egs_fused_forward produced (incl. the in-place culling). */
 /* rec (nullable): 48 N bytes; receives the packed 2D records of the draw kernels so that
- * egs_splat_draw_rec / egs_fused_backward skip their own packing pass.
+ * egs_splat_draw_rec / egs_fused_backward skip their own packing pass.  With rec given, each of
+ * us / cinv2ds / colors / areas may be NULL (they are only needed to continue on the seven-op surface)
+ * and egs_fused_backward accepts NULL for them too.
  * visible (nullable): N bytes; receives depths[i] > 0.2 AFTER the in-place culling of splat, i.e. the
  * mask GSFunction.forward returns (gsmodel.py:50). */
 int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
