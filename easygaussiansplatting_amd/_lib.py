@@ -85,6 +85,7 @@ SIGNATURES = {
     "egs_adam_step": (_i, [_i, C.POINTER(EgsAdamGroup), C.c_double, C.c_double, C.c_double, _P]),
     "egs_nn_sqdist_ws_bytes": (_sz, [_i]),
     "egs_nn_sqdist": (_i, [_i, _P, _P, _sz, _P, _P]),
+    "egs_viewer_prep": (_i, [_i, _i, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _f, _f, _P, _P, _P]),
     "egs_prof_enable": (_i, [_i]),
     "egs_prof_set_filter": (None, [C.c_char_p]),
     "egs_prof_reset": (None, []),

@@ -26,7 +26,7 @@ class Camera(RenderCamera):
 
 
 def _to_tensor(img, device):
-    a = np.asarray(img.convert("RGB"), dtype=np.uint8)
+    a = np.array(img.convert("RGB"), dtype=np.uint8)   # (a writable copy: torch.from_numpy warns otherwise)
     return torch.from_numpy(a).to(device).permute(2, 0, 1).to(torch.float32).div_(255.0).contiguous()
 
 

@@ -307,6 +307,16 @@ int egs_adam_step(int n_groups, const EgsAdamGroup* groups, double beta1, double
 size_t egs_nn_sqdist_ws_bytes(int n);
 int egs_nn_sqdist(int n, const float* points, void* ws, size_t ws_bytes, float* out_sqdist, void* stream);
 
+/* ---- the viewer's per-frame preprocess (last item) -------------------
+ * reference viewer/shaders/gau_prep.glsl (dispatched by viewer/custom_items/gaussian_item.py:264-272):
+ * gs_data [n, 11 + sh_dim] = {pos 3, rot 4, scale 3, alpha, sh} -> gs_prep [n,12] = {u 3 (NDC), covinv 3,
+ * color 3, area 2, alpha} and depth [n] (view-space z, the viewer's sort key).  Culled rows (|u.xy| > 1.3,
+ * |u.z| > 1, det == 0) only get u = -100; the rest of the row is left untouched, as the shader does.
+ * view_matrix / projection_matrix: HOST float[16], row-major, mathematical convention (pc = V pw). */
+int egs_viewer_prep(int n, int sh_dim, const float* gs_data, const float* view_matrix,
+                    const float* projection_matrix, float focal_x, float focal_y, float* gs_prep, float* depth,
+                    void* stream);
+
 /* ---- per-kernel timing with HIP events on the launch stream ---------------
  * bench.py's `roofline` leg: when enabled, every kernel launch of this library
  * is bracketed by hipEventRecord on the stream it is launched on.

@@ -97,3 +97,44 @@ def test_dataset_from_colmap_scene_and_training(tmp_path, model):
     tr = Trainer(start, ds.cameras, ds.images, max_steps=100, scene_size=ds.sence_size)
     losses = [tr.step([0, 1, 2, 3]) for _ in range(25)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+
+
+def _gl_matrices(width, height, fov_deg=60.0, near=0.1, far=100.0):
+    """A view matrix looking down -z from (0.5, -0.3, 6) and an OpenGL perspective matrix, mathematical
+    (row-major) convention as gaussian_item.py holds them."""
+    t = np.tan(np.radians(fov_deg) / 2)
+    P = np.array([[1 / (t * width / height), 0, 0, 0], [0, 1 / t, 0, 0],
+                  [0, 0, -(far + near) / (far - near), -2 * far * near / (far - near)], [0, 0, -1, 0]], np.float64)
+    a = 0.3
+    R = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    V = np.eye(4)
+    V[:3, :3] = R
+    V[:3, 3] = -R @ np.array([0.5, -0.3, 6.0])
+    focal = (P[0, 0] * width / 2, P[1, 1] * height / 2)            # gaussian_item.py:143-144
+    return V, P, focal
+
+
+@pytest.mark.parametrize("K", [48, 12, 3])
+def test_viewer_prep_matches_shader_restatement(K):
+    """egs_viewer_prep against the float64 restatement of viewer/shaders/gau_prep.glsl."""
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.viewer import gau_prep, pack_gs_data
+    sc = S.small_scene(4000, 320, 200, K, seed=8)
+    gs = np.rec.fromarrays([sc.pws, sc.rots, sc.scales, sc.alphas, sc.shs], dtype=S.gsdata_type(K))
+    data = pack_gs_data(gs)
+    data[:40, 2] += 30.0                                           # behind the GL camera / out of the frustum
+    data[40:80, 0] += 20.0
+    V, P, focal = _gl_matrices(320, 200)
+    prep, depth = gau_prep(data, V, P, focal)
+    want, wdepth, culled = io_oracle.viewer_prep(data, V, P, focal)
+    assert 50 < culled.sum() < 3000
+    prep, depth = prep.cpu().numpy(), depth.cpu().numpy()
+    np.testing.assert_allclose(depth, wdepth, rtol=1e-5, atol=1e-5)
+    np.testing.assert_array_equal(prep[:, 0] == -100, culled)
+    np.testing.assert_array_equal(prep[culled], want[culled])
+    ok = ~culled
+    scale = np.maximum(1.0, np.abs(want[ok]))
+    assert (np.abs(prep[ok] - want[ok]) / scale).max() < 2e-4
+    # a record array is accepted as well
+    prep2, _ = gau_prep(gs, V, P, focal)
+    assert prep2.shape == (4000, 12)
