@@ -97,6 +97,17 @@ def test_dataset_from_colmap_scene_and_training(tmp_path, model):
     tr = Trainer(start, ds.cameras, ds.images, max_steps=100, scene_size=ds.sence_size)
     losses = [tr.step([0, 1, 2, 3]) for _ in range(25)]
     assert np.isfinite(losses).all() and losses[-1] < losses[0]
+    if model == "PINHOLE":      # the train.py counterpart script end to end
+        import subprocess
+        import sys
+        from tests.conftest import REPO
+        out = str(tmp_path / "ckpt")
+        r = subprocess.run([sys.executable, os.path.join(REPO, "examples", "train.py"), "--path", root, "--epochs", "4",
+                            "--out", out], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        assert "Training is finished." in r.stdout and "epoch:3 avg_loss:" in r.stdout
+        final = np.load(os.path.join(out, "final.npy"))
+        assert final.dtype == np.dtype(S.gsdata_type(48)) and np.isfinite(final["pw"]).all()
 
 
 def _gl_matrices(width, height, fov_deg=60.0, near=0.1, far=100.0):
