@@ -149,3 +149,27 @@ def test_viewer_prep_matches_shader_restatement(K):
     # a record array is accepted as well
     prep2, _ = gau_prep(gs, V, P, focal)
     assert prep2.shape == (4000, 12)
+
+
+def test_forward_gpu_script_counterpart(tmp_path):
+    """examples/forward_gpu.py (the reference's forward_gpu.py on the drop-in module): example scene and a
+    .ply written by gau_io."""
+    import subprocess
+    import sys
+    from PIL import Image
+    from easygaussiansplatting_amd import gau_io
+    from tests.conftest import REPO
+    script = os.path.join(REPO, "examples", "forward_gpu.py")
+    out = str(tmp_path / "a.png")
+    r = subprocess.run([sys.executable, script, "--out", out], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    img = np.asarray(Image.open(out))
+    assert img.shape == (546, 979, 3) and img.max() > 100            # the four blobs are there
+    ply = str(tmp_path / "ex.ply")
+    gau_io.save_ply(ply, gau_io.get_example_gs())
+    out2 = str(tmp_path / "b.png")
+    r = subprocess.run([sys.executable, script, "--gs", ply, "--out", out2, "--policy", "forward_cpu"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    img2 = np.asarray(Image.open(out2)).astype(int)
+    assert np.abs(img2 - img.astype(int)).mean() < 2.0                # same picture under the CPU-path semantics
