@@ -664,19 +664,6 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
 // ============================================================================
 // draw backward: per-tile back-to-front gradients        (reference kernel.cu:809-950)
 // ============================================================================
-template <int CTRL>
-__device__ __forceinline__ float dpp_add(float v) {
-  const int t = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false);
-  return v + __int_as_float(t);
-}
-// sum over each row of 16 lanes; every lane of a row ends up with its row's total
-__device__ __forceinline__ float row_sum16(float v) {
-  v = dpp_add<0xB1>(v);   // quad_perm [1,0,3,2]
-  v = dpp_add<0x4E>(v);   // quad_perm [2,3,0,1]
-  v = dpp_add<0x141>(v);  // row_half_mirror
-  v = dpp_add<0x140>(v);  // row_mirror
-  return v;
-}
 // gfx950 cross-half / cross-row swaps (v_permlane32_swap_b32, v_permlane16_swap_b32)
 __device__ __forceinline__ void swap32(float& a, float& b) {  // a[32..63] <-> b[0..31]
   auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
@@ -688,17 +675,45 @@ __device__ __forceinline__ void swap16(float& a, float& b) {  // odd rows of a <
   a = __uint_as_float(r[0]);
   b = __uint_as_float(r[1]);
 }
-// Four per-lane partials (one per list entry e0..e3) -> one register whose rows of 16
-// lanes hold the four wave totals in the order [e0, e2, e1, e3]: 3 swaps + 3 adds + 4 DPP
-// adds instead of 4 x 6 DPP adds.
-__device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3) {
+// ---- transposing wave reduction ------------------------------------------------------------------
+// 4 entries x 9 quantities = 36 per-lane partials have to become 36 wave totals.  Every step pairs two
+// registers, sends half of each to the partner lanes and adds: one output register per input pair, so the
+// register count halves with the lane span (36 -> 18 -> 9 across the 16-lane rows with
+// v_permlane32_swap / v_permlane16_swap, then 9 -> 5 -> 3 -> 2 -> 1 inside the rows with DPP mirrors).
+// 54 + 27 instructions instead of 36 x 6 DPP adds, and the nine totals of an entry land in nine
+// different lanes of its row -- exactly where the one-instruction atomic wants them.
+__device__ __forceinline__ float rows_of4(float e0, float e1, float e2, float e3) {
   swap32(e0, e1);
   const float s01 = e0 + e1;  // lanes 0-31: e0 halves, lanes 32-63: e1 halves
   swap32(e2, e3);
   const float s23 = e2 + e3;
   float a = s01, b = s23;
   swap16(a, b);               // rows of a: [e0, e2, e1, e3]; rows of b: the other halves
-  return row_sum16(a + b);
+  return a + b;               // row r: 16 partial sums of entry {0,2,1,3}[r]
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_get(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, false));
+}
+// `hi` lanes reduce b, the others reduce a; partner lane through the mirror CTRL (a bijection between
+// the two lane classes)
+template <int CTRL>
+__device__ __forceinline__ float merge2(float a, float b, bool hi) {
+  const float own = hi ? b : a, other = hi ? a : b;
+  return own + dpp_get<CTRL>(other);
+}
+// the nine row-wise totals of (q0..q8) in lanes {0, 8, 4, 12, 2, 10, 6, 14, odd} of every row
+__device__ __forceinline__ float rows_to_lanes9(const float (&q)[9], int c16) {
+  const bool h8 = (c16 & 8) != 0, h4 = (c16 & 4) != 0, h2 = (c16 & 2) != 0, h1 = (c16 & 1) != 0;
+  constexpr int M8 = 0x140, M4 = 0x141, M2 = 0x4E, M1 = 0xB1;  // row_mirror, row_half_mirror, quad [2,3,0,1], [1,0,3,2]
+  const float p01 = merge2<M8>(q[0], q[1], h8), p23 = merge2<M8>(q[2], q[3], h8);
+  const float p45 = merge2<M8>(q[4], q[5], h8), p67 = merge2<M8>(q[6], q[7], h8);
+  float s8 = q[8] + dpp_get<M8>(q[8]);
+  const float a = merge2<M4>(p01, p23, h4), b = merge2<M4>(p45, p67, h4);
+  s8 += dpp_get<M4>(s8);
+  const float r = merge2<M2>(a, b, h2);
+  s8 += dpp_get<M2>(s8);
+  return merge2<M1>(r, s8, h1);
 }
 
 // Per-tile back-to-front gradient pass.  One wave64 per 16x16 tile walked as four 8x8
@@ -710,8 +725,8 @@ __device__ __forceinline__ float reduce4(float e0, float e1, float e2, float e3)
 //   with w = dL/dalpha' alpha':  M1x = sum w dx, M1y = sum w dy,
 //   M2xx = sum w dx dx, M2xy = sum w dx dy, M2yy = sum w dy dy    (B.5.2b / B.5.2c as moments:
 //   du = -cinv (M1x, M1y), dcinv = -(M2xx/2, M2xy, M2yy/2), applied once per entry)
-// The 9 partials are reduced across the wave 4 entries at a time (reduce4) and one lane
-// per entry issues the 9 atomics: one atomic set per (tile, Gaussian).
+// The 9 partials are reduced across the wave 4 entries at a time (transposing reduction below) and nine
+// lanes per entry issue the 9 atomics as one instruction: one atomic set per (tile, Gaussian).
 template <bool BOX, bool FLOOR, bool CLAMP>
 __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __restrict__ ranges,
                                                  const int32_t* __restrict__ gsid,
@@ -756,6 +771,20 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
     maxcont = max(maxcont, bmax[k]);
   }
   if (maxcont <= 0) return;
+  // where the transposing reduction leaves the nine totals inside a row of 16 lanes, and what each of
+  // those lanes adds to the packed gradient record {dalpha, dcolor[3], du[2], dcinv[3]}
+  const int c16 = lane & 15;
+  int qoff = -1, kind = 0;
+  float kscale = 1.f;
+  if (c16 & 1) { if (c16 == 1) { qoff = 8; kscale = -0.5f; } }          // M2yy -> dcinv.z
+  else if (c16 == 0) { qoff = 4; kind = 1; }                            // M1x  -> du.x
+  else if (c16 == 2) { qoff = 5; kind = 2; }                            // M1y  -> du.y
+  else if (c16 == 4) qoff = 0;                                          // dalpha
+  else if (c16 == 6) qoff = 1;                                          // dcolor.r
+  else if (c16 == 8) qoff = 2;                                          // dcolor.g
+  else if (c16 == 10) qoff = 3;                                         // dcolor.b
+  else if (c16 == 12) { qoff = 6; kscale = -0.5f; }                     // M2xx -> dcinv.x
+  else { qoff = 7; kscale = -1.f; }                                     // M2xy -> dcinv.y  (lane 14)
 
   for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
     __syncthreads();
@@ -839,10 +868,15 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         }
       }
       if (__any(any)) {  // wave-uniform
-        float tot[9];
+        // quantity order chosen so that the two first moments meet in one quad (lanes 0 and 2):
+        //   lane 0: M1x  2: M1y  4: dalpha  6,8,10: dcolor  12: M2xx  14: M2xy  odd: M2yy
+        float rows[9];
+        constexpr int ORDER[9] = {4, 2, 0, 6, 5, 3, 1, 7, 8};   // acc index feeding leaf q0..q8
 #pragma unroll
-        for (int q = 0; q < 9; ++q) tot[q] = reduce4(acc[0][q], acc[1][q], acc[2][q], acc[3][q]);
-        // row r of the wave now holds the totals of entry e = {0,2,1,3}[r]
+        for (int q = 0; q < 9; ++q)
+          rows[q] = rows_of4(acc[0][ORDER[q]], acc[1][ORDER[q]], acc[2][ORDER[q]], acc[3][ORDER[q]]);
+        const float v = rows_to_lanes9(rows, c16);
+        // row r of the wave holds the totals of entry e = {0,2,1,3}[r]
         const int row = lane >> 4;
         const int e = ((row & 1) << 1) | (row >> 1);
         const int j = jj - e;
@@ -850,26 +884,15 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         // they are inert (all partials exactly 0) and must not touch memory
         const bool rowact = c * 64 + j < n;
         const float4 D = sD[j];
-        // B.5.2b / B.5.2c from the moments, then lane q (0..8) of each row takes quantity q so
-        // that the 9 atomics of an entry are ONE instruction on ONE 48-byte gradient record
-        // (packed order: dalpha, dcolor[3], du[2], dcinv[3]; 36 lanes active per group).
-        // (du is the only quantity scaled by per-Gaussian data: an entry without contribution must stay
-        //  exactly 0 even if its cinv is not finite, so that the `v != 0` test below skips it)
-        const bool moved = tot[4] != 0.f || tot[5] != 0.f;
-        const float gux = moved ? -(D.x * tot[4] + D.y * tot[5]) : 0.f;
-        const float guy = moved ? -(D.y * tot[4] + D.z * tot[5]) : 0.f;
-        const int q = lane & 15;
-        float v = tot[0];
-        v = (q == 1) ? tot[1] : v;
-        v = (q == 2) ? tot[2] : v;
-        v = (q == 3) ? tot[3] : v;
-        v = (q == 4) ? gux : v;
-        v = (q == 5) ? guy : v;
-        v = (q == 6) ? -0.5f * tot[6] : v;
-        v = (q == 7) ? -tot[7] : v;
-        v = (q == 8) ? -0.5f * tot[8] : v;
-        if (rowact && q < 9 && v != 0.f)
-          unsafeAtomicAdd(gpack + 12 * (size_t)__float_as_int(D.w) + q, v);
+        // B.5.2b / B.5.2c from the moments: du = -cinv (M1x, M1y) needs both first moments -> the partner
+        // comes from the other lane of the pair (quad_perm [2,3,0,1]); dcinv = -(M2xx/2, M2xy, M2yy/2).
+        // The 9 atomics of an entry are ONE instruction on ONE 48-byte gradient record.
+        const float nb = dpp_get<0x4E>(v);
+        const float c_own = (kind == 1) ? -D.x : ((kind == 2) ? -D.z : kscale);
+        float val = v * c_own;
+        if (kind != 0) val = fmaf(nb, -D.y, val);
+        if (rowact && qoff >= 0 && val != 0.f)
+          unsafeAtomicAdd(gpack + 12 * (size_t)__float_as_int(D.w) + qoff, val);
       }
     }
   }
