@@ -22,6 +22,9 @@ from .dist_views import flat_grad_buffer  # noqa: F401  (re-exported: the buffer
 from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _tiles
 
 
+_patch_capacity = {}     # (N, W, H) -> patch-list allocation size learnt from earlier calls
+
+
 class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
@@ -79,21 +82,34 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
                                 float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
                                 _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin),
                                 ws_bin_bytes, _ptr(total), st)
+    out = {}
+
+    def allocate_outputs():     # everything that does not depend on the exact patch count: done while the GPU bins
+        out["image"] = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
+        S.contrib = torch.empty((H, W), dtype=i32, device=dev)
+        S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
+        S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
+        cap = _patch_capacity.get((n, W, H), 0)
+        if cap:                 # sized by the largest patch count seen for this problem size (+12.5 %)
+            out["gsid"] = torch.empty(cap, dtype=i32, device=dev)
+            out["ws_draw"] = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
+
     if raw:
         patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
-            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *tail(hint, total))))
+            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *tail(hint, total))),
+            allocate_outputs)
     else:
         patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward(
-            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *tail(hint, total))))
-    image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
-    S.contrib = torch.empty((H, W), dtype=i32, device=dev)
-    S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
-    S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
-    S.gsid = torch.empty(patches, dtype=i32, device=dev)
-    ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, W, H)
-    ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
+            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *tail(hint, total))), allocate_outputs)
+    image = out["image"]
+    if "gsid" in out and patches <= out["gsid"].shape[0]:
+        S.gsid, ws_draw = out["gsid"][:patches], out["ws_draw"]
+    else:                       # first call for this size, or more patches than ever before
+        S.gsid = torch.empty(patches, dtype=i32, device=dev)
+        ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
+    _patch_capacity[(n, W, H)] = max(_patch_capacity.get((n, W, H), 0), patches + patches // 8 + 1024)
     _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
-                                      ws_draw_bytes, _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
+                                      ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                       _ptr(S.ranges), _ptr(S.gsid), st))
     return image, mask, S
 

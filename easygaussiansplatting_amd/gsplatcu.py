@@ -193,15 +193,19 @@ def inverseCov2D(cov2ds, depths, calc_J):
 _key_bits_hint = 32   # learned from the previous call (depth keys rarely need more than 16 bits)
 
 
-def _bin_stage(enqueue):
+def _bin_stage(enqueue, while_waiting=None):
     """Run the binning stage with the depth-key bit-count hint protocol of egs_splat_bin:
     ``enqueue(hint, total)`` enqueues the stage; returns the patch count P.  The single
     8-byte read-back (reference: gausplat.cu:67) also brings the largest depth key, which
-    sizes the next call's sort; a too-small hint triggers one full-width re-run."""
+    sizes the next call's sort; a too-small hint triggers one full-width re-run.
+    ``while_waiting()`` runs between the enqueue and the blocking read: host work that does not need
+    P (output allocations) belongs there, so that the GPU idles as briefly as possible afterwards."""
     global _key_bits_hint
     total = torch.empty(2, dtype=torch.int32, device="cuda")
     hint = _key_bits_hint
     enqueue(hint, total)
+    if while_waiting is not None:
+        while_waiting()
     p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
     need = mk.bit_length()
     if hint < 32 and need > hint:
