@@ -1,0 +1,44 @@
+"""Reference module name gsplat/utils.py: activations of the raw training parameters and the learning-rate
+schedule.  (The torch covariance helper and the viewer colour map of the reference are not needed by the
+training path and are not provided.)"""
+import numpy as np
+import torch
+
+from easygaussiansplatting_amd.density import expon_lr
+
+
+def get_expon_lr_func(lr_init, lr_final, lr_delay_steps=0, lr_delay_mult=1.0, max_steps=1000000):
+    """utils.py:7-44."""
+    return lambda step: expon_lr(step, lr_init, lr_final, max_steps, lr_delay_steps, lr_delay_mult)
+
+
+def rotate_vector_by_quaternion(q, v):
+    """utils.py:46-54 (q = (w, x, y, z), normalised inside)."""
+    q = torch.nn.functional.normalize(q)
+    u, s = q[:, 1:], q[:, :1]
+    return 2.0 * u * (u * v).sum(1, keepdim=True) + v * (s * s - (u * u).sum(1, keepdim=True)) + \
+        2.0 * s * torch.linalg.cross(u, v, dim=1)
+
+
+def get_alphas_raw(x):
+    return float(np.log(x / (1 - x))) if isinstance(x, float) else torch.log(x / (1 - x))
+
+
+def get_alphas(x):
+    return torch.sigmoid(x)
+
+
+def get_scales_raw(x):
+    return float(np.log(x)) if isinstance(x, float) else torch.log(x)
+
+
+def get_scales(x):
+    return torch.exp(x)
+
+
+def get_rots(x):
+    return torch.nn.functional.normalize(x)
+
+
+def get_shs(low_shs, high_shs):
+    return torch.cat((low_shs, high_shs), dim=1)

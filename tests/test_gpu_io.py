@@ -173,3 +173,66 @@ def test_forward_gpu_script_counterpart(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     img2 = np.asarray(Image.open(out2)).astype(int)
     assert np.abs(img2 - img.astype(int)).mean() < 2.0                # same picture under the CPU-path semantics
+
+
+def test_reference_module_names_carry_a_train_py_style_loop(tmp_path):
+    """The loop of the reference's train.py:30-83 written against the reference's OWN module names
+    (gsplat.gsmodel / gsplat.pytorch_ssim / gsplat.gau_io / gsplat.gausplat_dataset, torch.optim.Adam):
+    with this repository on the path those names resolve to the MI355X implementations."""
+    import torch.optim as optim
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera, render
+    from tests.colmap_fixture import write_scene
+    from gsplat.pytorch_ssim import gau_loss, ssim
+    from gsplat.gau_io import save_training_params, load_gs
+    from gsplat.gausplat_dataset import GSplatDataset
+    from gsplat.gsmodel import GSModel, get_training_params
+    gsc.set_policy("gsplatcu")
+    sc = S.small_scene(2000, 96, 64, 3, seed=4)
+    cams = S.ring_cameras(sc.cam, 4, radius=5.0)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    imgs = []
+    with torch.no_grad():
+        for c in cams:
+            im = render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), Camera.from_scene(c))[0]
+            imgs.append((im.clamp(0, 1).permute(1, 2, 0).cpu().numpy() * 255 + 0.5).astype(np.uint8))
+    rgb = np.clip((sc.shs[:, :3] * 0.28209479177387814 + 0.5) * 255, 0, 255).astype(np.uint8)
+    root = str(tmp_path / "scene")
+    write_scene(root, cams, imgs, sc.pws, rgb)
+
+    gs_set = GSplatDataset(root)
+    training_params, adam_params = get_training_params(gs_set.gs)
+    optimizer = optim.Adam(adam_params, lr=0.000, eps=1e-15)
+    epochs, n = 8, len(gs_set)
+    model = GSModel(gs_set.sence_size, len(gs_set) * epochs)
+    model.grad_threshold = 1e-7                       # tiny images: let the densification fire
+    history = []
+    for epoch in range(epochs):
+        idxs = np.arange(n)
+        np.random.default_rng(epoch).shuffle(idxs)
+        avg_loss = 0
+        for i in idxs:
+            cam, image_gt = gs_set[i]
+            image = model(*training_params.values(), cam)
+            loss = gau_loss(image, image_gt)
+            loss.backward()
+            model.update_density_info()
+            optimizer.step()
+            optimizer.zero_grad(set_to_none=True)
+            model.update_pws_lr(optimizer)
+            avg_loss += loss.item()
+        history.append(avg_loss / n)
+        with torch.no_grad():
+            if epoch == 3:
+                model.update_gaussian_density(training_params, optimizer)
+            if epoch == 5:
+                model.reset_alpha(training_params, optimizer)
+    assert np.isfinite(history).all() and history[2] < history[0]
+    assert training_params["pws"].shape[0] != 2000 and model.iteration == epochs * n
+    fn = str(tmp_path / "final.npy")
+    save_training_params(fn, training_params)
+    back = load_gs(fn)
+    assert back.shape[0] == training_params["pws"].shape[0] and back["sh"].shape[1] == 48
+    s = float(ssim(image.detach(), image_gt))
+    assert 0.0 < s <= 1.0
