@@ -289,6 +289,23 @@ def test_splat_dense_long_lists(gsc):
 def test_splat_policy_a_tile_lists_and_blend(gsc):
     _splat_and_check(gsc, S.small_scene(5000, 256, 256, 3, seed=2), "forward_cpu", O.POLICY_A)
 
+@pytest.mark.parametrize("case", ["giants", "ties", "one_tile"])
+def test_splat_adversarial_binning(gsc, case):
+    """Patch-list shapes the cooperative emit / scan / sort must survive bit-exactly: a few Gaussians that
+    cover every tile among thousands of tiny ones; identical depths (ties resolve in index order: the stable
+    sorts); everything inside one tile."""
+    sc = S.small_scene(4000, 320, 208, 3, seed=21)
+    if case == "giants":
+        sc.scales[:5] = 3.0                                  # each covers the whole 20x13 tile grid
+        sc.scales[5:] *= 0.2
+    elif case == "ties":
+        sc.pws[:, 2] = np.round(sc.pws[:, 2] * 2) / 2        # a handful of distinct depths, thousands of ties
+    else:
+        sc.pws[:, :2] = sc.pws[:, :2] * 0.001                # all in front of the principal point
+        sc.scales[:] = 0.002
+    _splat_and_check(gsc, sc)
+
+
 
 def test_g5_fixture_raster(gsc):
     """Reference backward_cpu.py calc_gamma per pixel (fixture G5) vs splat/splatB."""
