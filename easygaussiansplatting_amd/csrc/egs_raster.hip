@@ -582,8 +582,10 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
       sC[lane] = C;
     }
     __syncthreads();
-    const int m = min(64, n - base);
-    for (int j = 0; j < m; ++j) {
+    const int m = __builtin_amdgcn_readfirstlane(min(64, n - base));
+    for (int j0 = 0; j0 < m && live != 0; j0 += 8) {  // eight entries, then the live-mask refresh
+    const int jend = min(j0 + 8, m);
+    for (int j = j0; j < jend; ++j) {
       // the entry's mask comes straight out of lane j's register (v_readlane): no LDS round trip
       const int reach = __builtin_amdgcn_readlane(mymask, j) & live;
       if (reach != 0) {  // scalar branch: some live block is within reach of this entry
@@ -636,14 +638,13 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
           }
         }
       }
-      // Finished pixels fail `tau >= stop` on their own, so the live-block mask only saves work: it is
-      // refreshed every 8th entry instead of tracking "some pixel just finished" per block.
-      if ((j & 7) == 7) {
+    }
+    // Finished pixels fail `tau >= stop` on their own, so the live-block mask only saves work: it is
+    // refreshed every 8 entries instead of tracking "some pixel just finished" per block; when it
+    // empties, every pixel of the tile is finished and both loops end (scalar exit).
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if ((live & (1 << k)) && !__any(tau[k] >= stop)) live &= ~(1 << k);
-        if (live == 0) break;  // scalar exit: every pixel of the tile is finished
-      }
+    for (int k = 0; k < 4; ++k)
+      if ((live & (1 << k)) && !__any(tau[k] >= stop)) live &= ~(1 << k);
     }
   }
   const size_t HW = (size_t)p.W * p.H;
