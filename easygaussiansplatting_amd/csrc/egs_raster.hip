@@ -525,7 +525,7 @@ __device__ __forceinline__ float min_hi(float x, float hi) {
   return __builtin_amdgcn_fmed3f(x, hi, -3.0e38f);
 }
 
-template <bool BOX, bool FLOOR, bool CLAMP>
+template <bool BOX, bool FLOOR, bool CLAMP, bool SKIP>
 __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
@@ -605,9 +605,9 @@ __global__ __launch_bounds__(64) void k_draw(DrawParams p, const int32_t* __rest
         // the floor (maha >= 0) and the 0.99 clamp are ONE min against `cap`.  log2(alpha) comes from the
         // record's skip threshold thr = log2(skip / alpha) (+inf: never blends).
         // (no skip test: thr is -inf, or +inf for alpha < 0 which never blends -> compare against thr itself)
-        const bool skips = p.alpha_skip > 0.f;
-        const float la = skips ? lskip - C.w : __builtin_amdgcn_logf(B.y);
-        const float lthr = skips ? lskip : C.w;
+        // (SKIP = the policy has a skip threshold, compiled in: a per-entry scalar branch otherwise)
+        const float la = SKIP ? lskip - C.w : __builtin_amdgcn_logf(B.y);
+        const float lthr = SKIP ? lskip : C.w;
         float cap = 0.f;
         if (FLOOR) cap = CLAMP ? min_hi(la, L99) : la;
         else if (CLAMP) cap = L99;
@@ -1138,9 +1138,17 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile);
   // policy -> template instance (compile-time footprint / floor / clamp)
-#define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                        \
-  EGS_LAUNCH_LDS("k_draw", (k_draw<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), draw_lds_pad(0), s, dp, \
-                 patch_range_per_tile, gsid_per_patch, rec, image, contrib, final_tau)
+#define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                         \
+  do {                                                                                                      \
+    if (pol->alpha_skip > 0.f)                                                                              \
+      EGS_LAUNCH_LDS("k_draw", (k_draw<BOX, FLOOR, CLAMP, true>), dim3(draw_grid(dp)), dim3(64),            \
+                     draw_lds_pad(0), s, dp, patch_range_per_tile, gsid_per_patch, rec, image, contrib,    \
+                     final_tau);                                                                            \
+    else                                                                                                    \
+      EGS_LAUNCH_LDS("k_draw", (k_draw<BOX, FLOOR, CLAMP, false>), dim3(draw_grid(dp)), dim3(64),           \
+                     draw_lds_pad(0), s, dp, patch_range_per_tile, gsid_per_patch, rec, image, contrib,    \
+                     final_tau);                                                                            \
+  } while (0)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {
     case 0: EGS_DRAW(false, false, false); break;
