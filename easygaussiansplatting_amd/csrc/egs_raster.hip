@@ -812,8 +812,17 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
       bool any = false;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
+        {  // nine zeros from five 64-bit moves (v_mov_b64 on gfx940+): the zeroing runs at full exec once per
+           // entry and this kernel is VALU-issue bound
 #pragma unroll
-        for (int q = 0; q < 9; ++q) acc[e][q] = 0.f;
+          for (int q = 0; q < 8; q += 2) {
+            unsigned long long z = 0ull;
+            asm volatile("" : "+v"(z));   // materialise the pair in VGPRs, keep it from being split into two constants
+            acc[e][q] = __uint_as_float((unsigned)z);
+            acc[e][q + 1] = __uint_as_float((unsigned)(z >> 32));
+          }
+          acc[e][8] = 0.f;
+        }
         const int j = jj - e;
         const int i = c * 64 + j;  // forward index of this entry in the tile list
         int reach = __builtin_amdgcn_readlane(mymask, j);  // lane j's register: no LDS round trip
