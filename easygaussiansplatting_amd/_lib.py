@@ -71,6 +71,7 @@ SIGNATURES = {
     "egs_fused_backward_raw": (_i, [_i, _i, _i64, _i, _i] + [_P] * 9 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
                                + [_P] * 7 + [_P]),
     "egs_splat_draw_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P]),
+    "egs_splat_draw_rec_dev": (_i, [_i, _i64, _P, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P]),
     "egs_fused_backward_ws_bytes": (_sz, [_i]),
     "egs_fused_backward": (_i, [_i, _i, _i64, _i, _i] + [_P] * 8 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
                            + [_P] * 6 + [_P]),

@@ -38,11 +38,13 @@ template <int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
                                                            int shift, uint32_t dmask, int nblocks,
                                                            uint32_t* __restrict__ hist,
-                                                           const uint32_t* __restrict__ maxkey) {
+                                                           const uint32_t* __restrict__ maxkey,
+                                                           const uint32_t* __restrict__ n_dev) {
   constexpr int RS_TILE = RS_THREADS * RS_IPT;
   __shared__ uint32_t h[256];
   const int tid = threadIdx.x;
   if (maxkey && ((*maxkey >> shift) == 0u)) return;
+  if (n_dev) n = min(n, (int64_t)*n_dev);   // `n` is a capacity: the real count is on the device
   h[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blockIdx.x * RS_TILE;
@@ -84,7 +86,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
     int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
-    const uint32_t* __restrict__ maxkey) {
+    const uint32_t* __restrict__ maxkey, const uint32_t* __restrict__ n_dev) {
+  if (n_dev) n = min(n, (int64_t)*n_dev);
   constexpr int RS_TILE = RS_THREADS * RS_IPT;       // items per workgroup
   constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // contiguous items per wave
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -193,7 +196,7 @@ static int sort_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit
 // enqueue all passes; result ends in (keys,vals) if the pass count is even
 static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
                       int begin_bit, int end_bit, const SortWs& w, hipStream_t s,
-                      const uint32_t* maxkey = nullptr) {
+                      const uint32_t* maxkey = nullptr, const uint32_t* n_dev = nullptr) {
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
   // the bits are spread evenly over the passes (13 tile bits = 7 + 6, not 8 + 5): fewer buckets per pass
@@ -205,18 +208,18 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
     const uint32_t dmask = (1u << nb) - 1u;
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
-                 w.nblocks, w.hist, maxkey);
+                 w.nblocks, w.hist, maxkey, n_dev);
     else
       EGS_LAUNCH("k_radix_hist", k_radix_hist<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
-                 w.nblocks, w.hist, maxkey);
+                 w.nblocks, w.hist, maxkey, n_dev);
     EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals, shift,
                maxkey);
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
-                 dmask, w.nblocks, w.hist, w.totals, maxkey);
+                 dmask, w.nblocks, w.hist, w.totals, maxkey, n_dev);
     else
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n,
-                 shift, dmask, w.nblocks, w.hist, w.totals, maxkey);
+                 shift, dmask, w.nblocks, w.hist, w.totals, maxkey, n_dev);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
@@ -353,7 +356,8 @@ __global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __rest
 __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t* __restrict__ ids,
                                                   const uint32_t* __restrict__ offsets,
                                                   const uint4* __restrict__ rects,
-                                                  uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid) {
+                                                  uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid,
+                                                  uint32_t cap) {
   __shared__ uint32_t s_off[257];   // offsets relative to the workgroup's first one; [256] = span length
   __shared__ uint32_t s_g[256], s_xy[256], s_w[256];
   const int tid = threadIdx.x;
@@ -388,6 +392,7 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
     const uint32_t r = s0 - s_off[lo];
     const uint32_t ww = s_w[lo], xy = s_xy[lo];
     const uint32_t ry = r / ww, rx = r - ry * ww;
+    if (first + s0 >= cap) break;   // (only when the buffers were sized from an earlier call: see egs_splat_draw_rec_dev)
     tkeys[first + s0] = ((xy >> 16) + ry) * (uint32_t)gx + (xy & 0xFFFFu) + rx;
     gsid[first + s0] = s_g[lo];
   }
@@ -395,7 +400,9 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
 
 // getRanges (reference kernel.cu:125-150; its P==1 hole is closed here)
 __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* __restrict__ tkeys,
-                                                     int32_t* __restrict__ ranges) {
+                                                     int32_t* __restrict__ ranges,
+                                                     const uint32_t* __restrict__ n_dev) {
+  if (n_dev) P = min(P, (int64_t)*n_dev);
   const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (p >= P) return;
   const uint32_t cur = tkeys[p];
@@ -1105,7 +1112,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
                            size_t ws_draw_bytes, const float4* rec_in, float* image, int32_t* contrib,
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
-                           void* stream) {
+                           void* stream, const uint32_t* patches_dev = nullptr) {
+  // patches_dev != NULL: `patches` is only the capacity of gsid_per_patch / ws_draw, the real count is read on
+  // the device (the host has not seen it yet)
   EGS_CHECK_ARG(n >= 0 && patches >= 0 && patches < (int64_t)0x7FFFFFFF && width > 0 && height > 0 && pol);
   EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
   hipStream_t s = (hipStream_t)stream;
@@ -1136,16 +1145,16 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
   EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
-                     v0);
+                     v0, (uint32_t)patches);
   const float4* rec = rec_in ? rec_in : D.rec;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, D.rec);
   EGS_LAUNCH_OK();
-  int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s);
+  int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s, nullptr, patches_dev);
   if (rc) return rc;
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
-                     patch_range_per_tile);
+                     patch_range_per_tile, patches_dev);
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                         \
   do {                                                                                                      \
@@ -1193,6 +1202,22 @@ extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height,
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
                          patch_range_per_tile, gsid_per_patch, stream);
+}
+
+// as egs_splat_draw_rec, enqueued BEFORE the host has read total_patches: patch_capacity sizes
+// gsid_per_patch / ws_draw, the real count comes from total_patches[0] on the device.  When
+// host_totals != NULL (page-locked host memory), total_patches[0..1] is copied there first, in stream order.
+extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_patches,
+                                      uint32_t* host_totals, int width, int height, const void* rec,
+                                      const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
+                                      float* image, int32_t* contrib, float* final_tau,
+                                      int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+  EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
+  if (host_totals)
+    EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
+                         ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
+                         patch_range_per_tile, gsid_per_patch, stream, total_patches);
 }
 
 extern "C" size_t egs_splat_bwd_ws_bytes(int n) { return 2 * align_up((size_t)(n > 0 ? n : 1) * 48, 256) + 256; }

@@ -14,15 +14,19 @@ Results equal the seven-op path (same device functions, csrc/egs_gaussian_math.h
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
 from . import _lib
+from . import gsplatcu as _gsc
 from .dist_views import flat_grad_buffer  # noqa: F401  (re-exported: the buffer is allocated here)
 from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _tiles
 
 
+ENQUEUE_AHEAD = os.environ.get("EGS_ENQUEUE_AHEAD", "1") != "0"   # knob for A/B measurements and tests
 _patch_capacity = {}     # (N, W, H) -> patch-list allocation size learnt from earlier calls
+_mailbox = {}            # device index -> page-locked int32[2]: landing zone of {P, max depth key}
 
 
 class FusedState:
@@ -82,35 +86,71 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
                                 float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
                                 _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin),
                                 ws_bin_bytes, _ptr(total), st)
-    out = {}
+    image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
+    S.contrib = torch.empty((H, W), dtype=i32, device=dev)
+    S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
+    S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
 
-    def allocate_outputs():     # everything that does not depend on the exact patch count: done while the GPU bins
-        out["image"] = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
-        S.contrib = torch.empty((H, W), dtype=i32, device=dev)
-        S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
-        S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
-        cap = _patch_capacity.get((n, W, H), 0)
-        if cap:                 # sized by the largest patch count seen for this problem size (+12.5 %)
-            out["gsid"] = torch.empty(cap, dtype=i32, device=dev)
-            out["ws_draw"] = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
-
-    if raw:
-        patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
-            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *tail(hint, total))),
-            allocate_outputs)
-    else:
-        patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_fused_forward(
-            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *tail(hint, total))), allocate_outputs)
-    image = out["image"]
-    if "gsid" in out and patches <= out["gsid"].shape[0]:
-        S.gsid, ws_draw = out["gsid"][:patches], out["ws_draw"]
-    else:                       # first call for this size, or more patches than ever before
+    def draw_exact(patches):
         S.gsid = torch.empty(patches, dtype=i32, device=dev)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
-    _patch_capacity[(n, W, H)] = max(_patch_capacity.get((n, W, H), 0), patches + patches // 8 + 1024)
-    _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
-                                      ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
-                                      _ptr(S.ranges), _ptr(S.gsid), st))
+        _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
+                                          ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
+                                          _ptr(S.ranges), _ptr(S.gsid), st))
+
+    if raw:
+        enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
+            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *tail(hint, total)))
+    else:
+        enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward(
+            n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *tail(hint, total)))
+
+    cap = _patch_capacity.get((n, W, H), 0) if ENQUEUE_AHEAD else 0
+    if cap == 0 or n == 0:
+        patches = _bin_stage(enqueue_bin)            # first call for this size: synchronous read-back of P
+        draw_exact(patches)
+    else:
+        # The draw stage is enqueued AHEAD of the read-back: buffers sized by the largest patch count seen so
+        # far, the kernels take the real count from device memory, and {P, max depth key} travel to a
+        # page-locked mailbox by a copy enqueued between the two stages.  The host then only polls that
+        # mailbox -- the GPU never waits for it (the reference, like the seven-op path, idles around
+        # cudaMemcpy(&P), gausplat.cu:67).  An overflow of the capacity or of the depth-key hint is detected
+        # here, after the fact, and the affected stage is redone.
+        if dev.index not in _mailbox:
+            _mailbox[dev.index] = torch.zeros(2, dtype=torch.int32).pin_memory()
+        box = _mailbox[dev.index]
+        box[0] = -1                                   # sentinel: P is never 0xFFFFFFFF
+        total = torch.empty(2, dtype=i32, device=dev)
+        hint = _gsc._key_bits_hint
+        enqueue_bin(hint, total)
+        gsid_full = torch.empty(cap, dtype=i32, device=dev)
+        ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
+        _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), C.c_void_p(box.data_ptr()), W, H, _ptr(S.rec), pol,
+                                              _ptr(ws_bin), _ptr(ws_draw), ws_draw.numel(), _ptr(image),
+                                              _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full),
+                                              st))
+        spins = 0
+        while int(box[0]) == -1:                      # arrives ~0.2 ms before the draw stage finishes
+            spins += 1
+            if spins > 200000:                        # (never observed) fall back to a real synchronisation
+                torch.cuda.current_stream().synchronize()
+                break
+        patches, mk = int(box[0]) & 0xFFFFFFFF, int(box[1]) & 0xFFFFFFFF
+        need = mk.bit_length()
+        if patches >= 2**31:
+            raise RuntimeError("splat: %d tile patches overflow int32 indexing" % patches)
+        if hint < 32 and need > hint:                 # stale depth-key hint: everything again, full key width
+            _gsc._key_bits_hint = 32
+            patches = _bin_stage(enqueue_bin)
+            draw_exact(patches)
+        else:
+            _gsc._key_bits_hint = min(32, need + 1)
+            if patches > cap:                         # more patches than ever before: redo the draw stage
+                draw_exact(patches)
+            else:
+                S.gsid = gsid_full[:patches]
+    if n > 0:
+        _patch_capacity[(n, W, H)] = max(_patch_capacity.get((n, W, H), 0), patches + patches // 32 + 4096)
     return image, mask, S
 
 

@@ -195,6 +195,17 @@ int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
                        int32_t* gsid_per_patch, void* stream);
+/* As egs_splat_draw_rec, for a host that enqueues the draw stage BEFORE it has read total_patches (no GPU
+ * idle time around the read-back): patch_capacity sizes gsid_per_patch and ws_draw
+ * (egs_splat_draw_ws_bytes(n, patch_capacity, ..)), the real patch count is taken from total_patches[0] on
+ * the device.  host_totals (nullable, page-locked host uint32[2]) receives total_patches[0..1] by an
+ * asynchronous copy enqueued in front of the draw stage.  The caller checks afterwards: if the count exceeds
+ * patch_capacity the outputs are incomplete (nothing is written out of bounds) and the stage must be redone
+ * with the exact count (egs_splat_draw_rec). */
+int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_patches, uint32_t* host_totals,
+                           int width, int height, const void* rec, const EgsPolicy* pol, const void* ws_bin,
+                           void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                           int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream);
 size_t egs_fused_backward_ws_bytes(int n);
 int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
                        const float* rots, const float* scales, const float* shs, const float* alphas,
