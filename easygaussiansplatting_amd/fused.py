@@ -119,7 +119,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
         if dev.index not in _mailbox:
             _mailbox[dev.index] = torch.zeros(2, dtype=torch.int32).pin_memory()
         box = _mailbox[dev.index]
-        box[0] = -1                                   # sentinel: P is never 0xFFFFFFFF
+        box.fill_(-1)                                 # sentinels: neither P nor a depth key is ever 0xFFFFFFFF
         total = torch.empty(2, dtype=i32, device=dev)
         hint = _gsc._key_bits_hint
         enqueue_bin(hint, total)
@@ -130,7 +130,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
                                               _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full),
                                               st))
         spins = 0
-        while int(box[0]) == -1:                      # arrives ~0.2 ms before the draw stage finishes
+        while int(box[0]) == -1 or int(box[1]) == -1:  # arrives ~0.2 ms before the draw stage finishes
             spins += 1
             if spins > 200000:                        # (never observed) fall back to a real synchronisation
                 torch.cuda.current_stream().synchronize()
