@@ -330,6 +330,18 @@ def main():
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 1),
                         "launches": cnt, "share_of_step": round(tot / a.steps / ms, 3)}
+            # the kernel is VALU-issue bound, not HBM bound: say so next to the HBM fraction (SQ counters of the
+            # rocprofv3 --pmc passes in profiles/: busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / (GRBM_GUI_ACTIVE / XCDs))
+            spath = os.path.join(REPO, "profiles", "r1_final_sq_counters.json")
+            if os.path.exists(spath):
+                try:
+                    for kname, c in json.load(open(spath)).items():
+                        if kname.replace("egs::", "").split("<")[0] == dom and "SQ_ACTIVE_INST_VALU" in c:
+                            roofline["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 /
+                                                          (c["GRBM_GUI_ACTIVE"] / 8), 3)
+                            roofline["valu_insts_per_launch"] = int(c["SQ_INSTS_VALU"])
+                except Exception:
+                    pass
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
             if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/)
                 try:
