@@ -811,16 +811,25 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
       sD[lane] = make_float4(A.z * INVQ, A.w * (0.5f * INVQ), B.x * INVQ, __int_as_float(g));
     }
     __syncthreads();
-    // Groups of four entries aligned to 4 (jj = 4m+3): every j = jj-e is >= 0.  Entries above
-    // maxcont-1 in the top group fail `i < cont[k]` in every lane, so they are inert.
-    const int jhi = min(63, maxcont - 1 - c * 64) | 3;
-    for (int jj = jhi; jj >= 0; jj -= 4) {  // entries jj, jj-1, jj-2, jj-3 (descending list order)
+    // Which entries of this chunk can contribute at all?  Every lane answers for the entry it staged: its
+    // reach mask minus the blocks no pixel of which ever got this far (entry index >= the block's largest
+    // contrib, kernel.cu:899); a scalar bit scan then walks the reachable entries in descending list order.
+    // Groups of four: each of the four accumulator slots takes entries until one of them HITS (a quarter
+    // of the entries that reach a live block hit no pixel: they leave the slot zero and cost neither a
+    // re-zeroing nor a share of a wave reduction).
+    int rl = mymask;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (idx >= bmax[k]) rl &= ~(1 << k);
+    unsigned long long todo = __ballot(rl != 0);
+    while (todo != 0ull) {
+      int je[4] = {-1, -1, -1, -1};   // chunk-local entry index held by slot e
       float acc[4][9];
       bool any = false;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         {  // nine zeros from five 64-bit moves (v_mov_b64 on gfx940+): the zeroing runs at full exec once per
-           // entry and this kernel is VALU-issue bound
+           // slot and this kernel is VALU-issue bound
 #pragma unroll
           for (int q = 0; q < 8; q += 2) {
             unsigned long long z = 0ull;
@@ -830,13 +839,12 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
           }
           acc[e][8] = 0.f;
         }
-        const int j = jj - e;
+        while (todo != 0ull) {
+        const int j = 63 - __clzll((long long)todo);
+        todo &= ~(1ull << j);
+        bool any_e = false;
         const int i = c * 64 + j;  // forward index of this entry in the tile list
-        int reach = __builtin_amdgcn_readlane(mymask, j);  // lane j's register: no LDS round trip
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (i >= bmax[k]) reach &= ~(1 << k);  // no pixel of block k ever got this far (kernel.cu:899)
-        if (reach == 0) continue;  // scalar branch (entries past the list end have i >= bmax: inert)
+        const int reach = __builtin_amdgcn_readlane(rl, j);  // lane j's register: no LDS round trip
         const float4 A = sA[j], B = sB[j], C = sC[j];
         bool inx[2] = {true, true}, iny[2] = {true, true};
         if (BOX) {
@@ -880,11 +888,17 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
             acc[e][4] += wx; acc[e][5] += wy;
             acc[e][6] += wx * dx[bx]; acc[e][7] += wx * dy[by]; acc[e][8] += wy * dy[by];
             lq[k] += ap * dq;  // gamma_cur2last <- a' color + (1 - a') gamma_cur2last, dotted with dL/dgamma
-            any = true;
+            any_e = true;
           }
         }
+        if (__any(any_e)) {  // wave-uniform: the entry contributed, the slot is taken
+          je[e] = j;
+          any = true;
+          break;
+        }
+        }  // next reachable entry into the same (still zero) slot
       }
-      if (__any(any)) {  // wave-uniform
+      if (any) {  // wave-uniform
         // quantity order chosen so that the two first moments meet in one quad (lanes 0 and 2):
         //   lane 0: M1x  2: M1y  4: dalpha  6,8,10: dcolor  12: M2xx  14: M2xy  odd: M2yy
         float rows[9];
@@ -893,14 +907,13 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
         for (int q = 0; q < 9; ++q)
           rows[q] = rows_of4(acc[0][ORDER[q]], acc[1][ORDER[q]], acc[2][ORDER[q]], acc[3][ORDER[q]]);
         const float v = rows_to_lanes9(rows, c16);
-        // row r of the wave holds the totals of entry e = {0,2,1,3}[r]
+        // row r of the wave holds the totals of slot e = {0,2,1,3}[r]
         const int row = lane >> 4;
         const int e = ((row & 1) << 1) | (row >> 1);
-        const int j = jj - e;
-        // entries past the end of the list (top group of the last chunk) have stale LDS slots:
-        // they are inert (all partials exactly 0) and must not touch memory
-        const bool rowact = c * 64 + j < n;
-        const float4 D = sD[j];
+        const int j = (e == 0) ? je[0] : (e == 1) ? je[1] : (e == 2) ? je[2] : je[3];
+        // an empty slot (the chunk ran out of entries) holds zeros and no entry: it must not touch memory
+        const bool rowact = j >= 0;
+        const float4 D = sD[j & 63];
         // B.5.2b / B.5.2c from the moments: du = -cinv (M1x, M1y) needs both first moments -> the partner
         // comes from the other lane of the pair (quad_perm [2,3,0,1]); dcinv = -(M2xx/2, M2xy, M2yy/2).
         // The 9 atomics of an entry are ONE instruction on ONE 48-byte gradient record.
