@@ -109,14 +109,31 @@ def test_op_surface_validates_before_touching_the_gpu():
 
 
 def test_product_path_never_imports_the_oracle():
-    pkg = os.path.join(REPO, "easygaussiansplatting_amd")
-    for root, _, files in os.walk(pkg):
-        for f in files:
-            if f.endswith(".py"):
-                src = open(os.path.join(root, f)).read()
-                code = "\n".join(ln for ln in src.splitlines() if re.match(r"\s*(from|import)\s", ln))
-                assert "oracle" not in code, f
-    assert "oracle" not in open(os.path.join(REPO, "gsplatcu", "__init__.py")).read()
+    """The package, the two drop-in shims and the example scripts; only tests/, bench.py's cpu_baseline leg and
+    __graft_entry__.smoke() may touch oracle/."""
+    for pkg in ("easygaussiansplatting_amd", "gsplatcu", "gsplat", "examples"):
+        for root, _, files in os.walk(os.path.join(REPO, pkg)):
+            for f in files:
+                if f.endswith(".py"):
+                    src = open(os.path.join(root, f)).read()
+                    code = "\n".join(ln for ln in src.splitlines() if re.match(r"\s*(from|import)\s", ln))
+                    assert "oracle" not in code, os.path.join(root, f)
+    # bench.py imports the oracle only inside cpu_baseline()
+    bench = open(os.path.join(REPO, "bench.py")).read()
+    top_level = "\n".join(ln for ln in bench.splitlines() if re.match(r"(from|import)\s", ln))
+    assert "oracle" not in top_level
+
+
+def test_reference_module_names_resolve_without_a_gpu():
+    """The gsplat/ shim package imports on a CPU-only box (the HIP library is only loaded on first use)."""
+    import importlib
+    for name in ("gsplat.gau_io", "gsplat.read_write_model", "gsplat.utils", "gsplat.pytorch_ssim",
+                 "gsplat.gausplat_dataset", "gsplat.gsmodel", "gsplatcu"):
+        m = importlib.import_module(name)
+        assert m is not None
+    from gsplat.gsmodel import GSModel, get_training_params            # noqa: F401
+    from gsplat.gau_io import load_gs, save_gs, get_example_gs         # noqa: F401
+    assert get_example_gs().shape == (4,)
 
 
 def test_missing_library_is_a_hard_error(monkeypatch, tmp_path):
