@@ -3,7 +3,8 @@
 436 B/Gaussian of Jacobians ever crossing HBM.
 
 * ``forward``  = project + computeCov3D + computeCov2D + sh2Color + inverseCov2D
-  in ONE kernel, then ``splat`` (bin -> 4-byte read-back -> draw);
+  in ONE kernel (which also does the binning's getRects and depth keys), then ``splat``'s sort and draw;
+  from the second call on the draw stage is enqueued AHEAD of the read-back of the patch count (see below);
 * ``backward`` = ``splatB``'s draw pass into packed per-Gaussian gradient records
   + ONE kernel that re-derives the Jacobians in registers and applies
   backward.md eq (3)(4)(5)(7) (gsmodel.py:71-85).

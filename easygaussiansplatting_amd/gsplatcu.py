@@ -15,7 +15,7 @@ supersets:
 
 * work is enqueued on ``torch.cuda.current_stream()`` with no device-wide
   synchronisation (the reference syncs after every kernel, common.cuh:16-24);
-  ``splat`` performs exactly one 4-byte device->host read (the patch count),
+  ``splat`` performs exactly one 8-byte device->host read (the patch count and the largest depth key),
   where the reference has one too (gausplat.cu:67);
 * bad dtype / device / shape raise ``ValueError``/``TypeError`` instead of
   reading out of bounds; HIP errors raise ``RuntimeError``;

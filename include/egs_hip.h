@@ -97,7 +97,7 @@ int egs_inv_cov2d(int n, const float* cov2ds, float* depths, const EgsPolicy* po
  * The reference needs P (number of tile-patches) on the host between the prefix
  * sum and the key expansion (gausplat.cu:67); so does a drop-in that returns
  * gsid_per_patch[P].  The op is therefore split in two enqueue-only calls with a
- * single 4-byte read-back between them (done by the caller on its own stream):
+ * single 8-byte read-back (total_patches[0..1]) between them (done by the caller on its own stream):
  *
  *   egs_splat_bin()   getRects (kernel.cu:82-122) + depth-key sort of the N
  *                     Gaussians + exclusive scan  -> *total_patches (device u32)
