@@ -5,8 +5,9 @@
 // and how this differs by design:
 //   * reference: expand (tile<<32|depth_mm) keys for all P patches, one 64-bit
 //     thrust sort of P pairs.  Here: sort the N Gaussians by depth key (32-bit
-//     keys, N pairs), expand patches in that order, then ONE-OR-TWO stable 8-bit
-//     passes over P (tile id only).  Same final order (ties in Gaussian-index
+//     keys, N pairs), expand patches in that order, then one or two stable
+//     passes over P on the tile id only, the id's bits spread evenly over the
+//     passes (13 bits = 7 + 6).  Same final order (ties in Gaussian-index
 //     order), ~2x less sort traffic at P/N ~ 4.
 //   * reference draw: 256 threads per 16x16 tile, block barrier + vote per
 //     Gaussian, 4 separate gathers per entry.  Here: ONE wave64 per tile, 4
@@ -14,8 +15,10 @@
 //     read back as wave-uniform (broadcast) ds_read_b128 -- no cross-wave
 //     barrier in the blend loop, early exit by a wave vote.
 //   * reference drawB: 9 same-address float atomics per (pixel, Gaussian).
-//     Here: 4 pixels summed in-lane, DPP wave reduction, one lane issues the 9
-//     atomics per (tile, Gaussian): 256x fewer atomics.
+//     Here: 4 pixels summed in-lane, four entries reduced together by a
+//     transposing wave reduction (permlane swaps + DPP row merges) that leaves
+//     the 9 sums of an entry in 9 different lanes, which issue ONE packed atomic
+//     instruction per (tile, Gaussian) into a 12-float row: 256x fewer atomics.
 #include "egs_gaussian_math.h"
 
 #include <stdlib.h>
@@ -23,7 +26,7 @@
 namespace egs {
 
 // ============================================================================
-// stable LSD radix sort, 8-bit digits, (u32 key, u32 value)
+// stable LSD radix sort, digits of up to 8 bits (dmask), (u32 key, u32 value)
 // ============================================================================
 constexpr int RS_THREADS = 256;
 // items per thread: 16 (4096-item tiles) for long arrays; 8 for short ones, where 4096-item tiles would
@@ -497,9 +500,10 @@ static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(
 // form is evaluated separably: cxx[bx] + cyy[by] + cxy[bx]*dy[by].  (Measured on gfx950,
 // tools/ubench_valu.hip: v_pk_*_f32 costs exactly 2x a plain fp32 op, v_exp/v_rcp 3x,
 // v_max/v_cmp->SGPR 1.6x -- so the kernels minimise instruction count, not pack.)
-// A pixel that is finished (tau < tau_stop) or outside the image carries the
-// sign bit in `cont`, so "still live" is one v_cmp_ge_i32 and "whole tile
-// finished" is the sign of the AND of the four counters.
+// A pixel that is finished or outside the image holds tau < tau_stop, so "still
+// blending" is the one compare `tau >= stop`; the wave-uniform 4-bit `live` mask of
+// blocks with an unfinished pixel is refreshed every eight entries and gates the
+// per-block scalar branches and the early exit.
 // 4-bit reach mask of one list entry over the four 8x8 blocks of a tile (bit k = block
 // (k&1, k>>1)).  Computed ONCE per entry by the lane that stages it (64 entries in
 // parallel) instead of by all 64 lanes of the blend loop.
