@@ -289,6 +289,18 @@ def test_splat_dense_long_lists(gsc):
 def test_splat_policy_a_tile_lists_and_blend(gsc):
     _splat_and_check(gsc, S.small_scene(5000, 256, 256, 3, seed=2), "forward_cpu", O.POLICY_A)
 
+def _needles(n=6000, seed=33):
+    """Long thin Gaussians at every angle: the level-set ellipse fills little of its bounding box."""
+    sc = S.small_scene(n, 320, 208, 3, seed=seed)
+    sc.scales[:, 0] = 0.4
+    sc.scales[:, 1:] = 0.004
+    return sc
+
+
+def test_splat_needles(gsc):
+    _splat_and_check(gsc, _needles())
+
+
 @pytest.mark.parametrize("case", ["giants", "ties", "one_tile"])
 def test_splat_adversarial_binning(gsc, case):
     """Patch-list shapes the cooperative emit / scan / sort must survive bit-exactly: a few Gaussians that
