@@ -11,7 +11,9 @@
 //                dL/dx = (1-lambda)/M sign(x-y) - lambda/M dS_total/dx.
 //   k_loss_finalize : deterministic reduction of the per-workgroup partials.
 //
-// HBM-bound: 275 MB per 1080p image (x,y in; 3 maps out; 3 maps + x,y in; grad out).
+// 275 MB of HBM traffic per 1080p image (x,y in; 3 maps out; 3 maps + x,y in; grad out); the window
+// passes are what costs: both are register-blocked (a thread slides the 11 taps over a run of 8 outputs of a
+// row / 4 outputs of a column, reading every LDS value once per run instead of once per tap).
 #include "egs_common.h"
 
 namespace egs {
@@ -19,75 +21,143 @@ namespace egs {
 constexpr int LW = 11, LR = 5;            // window size / radius (pytorch_ssim.py:52: window_size=11)
 constexpr int TW = 64, TH = 16;           // output tile
 constexpr int IW = TW + 2 * LR, IH = TH + 2 * LR;  // input tile with halo: 74 x 26
+constexpr int HRUN = 8, VRUN = 4;         // outputs per thread: horizontal pass (row run), vertical pass (column run)
+constexpr int HSEG = TW / HRUN;           // 8 runs per tile row -> IH * HSEG = 208 of the 256 threads work
+constexpr int NLOAD = (IH * IW + 255) / 256;  // halo-tile elements per thread
+static_assert(IH * HSEG <= 256 && TW * (TH / VRUN) == 256, "pass shapes are tied to the 256-thread workgroup");
 
 struct LossWin { float g[LW]; };          // normalised 1-D Gaussian, sigma = 1.5 (pytorch_ssim.py:11-13,17)
 
-__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, LossWin win, const float* __restrict__ img,
-                                                  const float* __restrict__ gt, float* __restrict__ Pm,
-                                                  float* __restrict__ P11, float* __restrict__ P12,
-                                                  float* __restrict__ partials /* [nblocks][2] */) {
+// image pixel (or 0: F.conv2d padding=5) of halo-tile element i
+__device__ __forceinline__ bool tile_src(int i, int x0, int y0, int H, int W, int& r, int& c, size_t& off) {
+  r = i / IW; c = i - r * IW;
+  const int yy = y0 + r - LR, xx = x0 + c - LR;
+  off = (size_t)yy * W + xx;
+  return yy >= 0 && yy < H && xx >= 0 && xx < W;
+}
+
+// Persistent workgroups: workgroup b takes tiles b, b + gridDim.x, ...; the halo tile of the NEXT tile is
+// fetched into registers while the two window passes of the current one run, so the HBM latency is paid
+// once per workgroup instead of once per tile (3 workgroups per CU fit: 49 KB of LDS each).
+struct TileAt { int x0, y0; size_t plane; };
+__device__ __forceinline__ TileAt tile_at(int t, int gx, int gy, int H, int W) {
+  const int bx = t % gx, by = (t / gx) % gy, ch = t / (gx * gy);
+  return {bx * TW, by * TH, (size_t)ch * H * W};
+}
+
+__global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int gx, int gy, LossWin win,
+                                                  const float* __restrict__ img, const float* __restrict__ gt,
+                                                  float* __restrict__ Pm, float* __restrict__ P11,
+                                                  float* __restrict__ P12,
+                                                  float* __restrict__ partials /* [ntiles][2] */) {
   __shared__ float sx[IH][IW + 1], sy[IH][IW + 1];
   __shared__ float h[5][IH][TW + 1];      // horizontally filtered x, y, xx, yy, xy
   __shared__ float red[2][4];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, ch = blockIdx.z;
-  const size_t plane = (size_t)ch * H * W;
-  for (int i = tid; i < IH * IW; i += 256) {  // zero padding outside the image (F.conv2d padding=5)
-    const int r = i / IW, c = i - r * IW;
-    const int yy = y0 + r - LR, xx = x0 + c - LR;
-    float a = 0.f, b = 0.f;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      a = img[plane + (size_t)yy * W + xx];
-      b = gt[plane + (size_t)yy * W + xx];
+  const int ntiles = gx * gy * 3;
+  float fa[NLOAD], fb[NLOAD];             // halo tile in flight: element tid + 256 j
+  auto fetch = [&](int t) {               // every load is issued before anything waits on one
+    const TileAt T = tile_at(t, gx, gy, H, W);
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+      int r, c; size_t off;
+      fa[j] = 0.f; fb[j] = 0.f;
+      const int i = tid + 256 * j;
+      if (i < IH * IW && tile_src(i, T.x0, T.y0, H, W, r, c, off)) { fa[j] = img[T.plane + off]; fb[j] = gt[T.plane + off]; }
     }
-    sx[r][c] = a; sy[r][c] = b;
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+  const TileAt T = tile_at(t, gx, gy, H, W);
+  const int x0 = T.x0, y0 = T.y0;
+  const size_t plane = T.plane;
+#pragma unroll
+  for (int j = 0; j < NLOAD; ++j) {
+    const int i = tid + 256 * j;
+    if (i < IH * IW) { const int r = i / IW, c = i - r * IW; sx[r][c] = fa[j]; sy[r][c] = fb[j]; }
   }
   __syncthreads();
-  for (int i = tid; i < IH * TW; i += 256) {  // horizontal 11-tap pass
-    const int r = i / TW, c = i - r * TW;
-    float a = 0.f, b = 0.f, aa = 0.f, bb = 0.f, ab = 0.f;
+  if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+  if (tid < IH * HSEG) {  // horizontal 11-tap pass: HRUN outputs of row r from HRUN + 10 inputs
+    const int r = tid % IH, c0 = (tid / IH) * HRUN;  // lanes of a wave walk down the rows: odd row stride, few bank conflicts
+    float u[HRUN + LW - 1], v[HRUN + LW - 1];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k], u = sx[r][c + k], v = sy[r][c + k];
-      a += w * u; b += w * v; aa += w * (u * u); bb += w * (v * v); ab += w * (u * v);
+    for (int k = 0; k < HRUN + LW - 1; ++k) { u[k] = sx[r][c0 + k]; v[k] = sy[r][c0 + k]; }
+    float a[HRUN], b[HRUN], aa[HRUN], bb[HRUN], ab[HRUN];
+#pragma unroll
+    for (int o = 0; o < HRUN; ++o) { a[o] = 0.f; b[o] = 0.f; aa[o] = 0.f; bb[o] = 0.f; ab[o] = 0.f; }
+#pragma unroll
+    for (int k = 0; k < HRUN + LW - 1; ++k) {
+      const float uu = u[k] * u[k], vv = v[k] * v[k], uv = u[k] * v[k];
+#pragma unroll
+      for (int o = 0; o < HRUN; ++o) {
+        const int tp = k - o;  // tap index of input k for output o (ascending k == ascending tap: the reference's order)
+        if (tp >= 0 && tp < LW) {
+          const float w = win.g[tp];
+          a[o] += w * u[k]; b[o] += w * v[k]; aa[o] += w * uu; bb[o] += w * vv; ab[o] += w * uv;
+        }
+      }
     }
-    h[0][r][c] = a; h[1][r][c] = b; h[2][r][c] = aa; h[3][r][c] = bb; h[4][r][c] = ab;
+#pragma unroll
+    for (int o = 0; o < HRUN; ++o) {
+      h[0][r][c0 + o] = a[o]; h[1][r][c0 + o] = b[o]; h[2][r][c0 + o] = aa[o]; h[3][r][c0 + o] = bb[o];
+      h[4][r][c0 + o] = ab[o];
+    }
   }
   __syncthreads();
   float sum_l1 = 0.f, sum_s = 0.f;
   constexpr float C1 = 0.01f * 0.01f, C2 = 0.03f * 0.03f;  // pytorch_ssim.py:39-40
-  for (int i = tid; i < TH * TW; i += 256) {  // vertical pass + SSIM + partials
-    const int r = i / TW, c = i - r * TW;
-    const int yy = y0 + r, xx = x0 + c;
-    if (yy >= H || xx >= W) continue;
-    float mu1 = 0.f, mu2 = 0.f, e11 = 0.f, e22 = 0.f, e12 = 0.f;
+  {  // vertical pass + SSIM + partials: VRUN outputs of column c from VRUN + 10 rows
+    const int c = tid % TW, r0 = (tid / TW) * VRUN;
+    float acc[5][VRUN];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k];
-      mu1 += w * h[0][r + k][c]; mu2 += w * h[1][r + k][c];
-      e11 += w * h[2][r + k][c]; e22 += w * h[3][r + k][c]; e12 += w * h[4][r + k][c];
+    for (int m = 0; m < 5; ++m)
+#pragma unroll
+      for (int o = 0; o < VRUN; ++o) acc[m][o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < VRUN + LW - 1; ++k) {
+      float hv[5];
+#pragma unroll
+      for (int m = 0; m < 5; ++m) hv[m] = h[m][r0 + k][c];
+#pragma unroll
+      for (int o = 0; o < VRUN; ++o) {
+        const int tp = k - o;
+        if (tp >= 0 && tp < LW) {
+#pragma unroll
+          for (int m = 0; m < 5; ++m) acc[m][o] += win.g[tp] * hv[m];
+        }
+      }
     }
-    const float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
-    const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
-    const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
-    const float inv = 1.f / (B1 * B2);
-    const float S = A1 * A2 * inv;  // pytorch_ssim.py:42-43
-    // dS/d(mu1, E11, E12) with sigma1_sq = E11 - mu1^2, sigma12 = E12 - mu1 mu2
-    const float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -S / B1, dB2 = -S / B2;
-    const size_t o = plane + (size_t)yy * W + xx;
-    Pm[o] = 2.f * mu2 * (dA1 - dA2) + 2.f * mu1 * (dB1 - dB2);
-    P11[o] = dB2;
-    P12[o] = 2.f * dA2;
-    sum_s += S;
-    sum_l1 += fabsf(sx[r + LR][c + LR] - sy[r + LR][c + LR]);
+    const int xx = x0 + c;
+#pragma unroll
+    for (int o = 0; o < VRUN; ++o) {
+      const int r = r0 + o, yy = y0 + r;
+      if (yy >= H || xx >= W) continue;
+      const float mu1 = acc[0][o], mu2 = acc[1][o], e11 = acc[2][o], e22 = acc[3][o], e12 = acc[4][o];
+      const float s11 = e11 - mu1 * mu1, s22 = e22 - mu2 * mu2, s12 = e12 - mu1 * mu2;
+      const float A1 = 2.f * mu1 * mu2 + C1, A2 = 2.f * s12 + C2;
+      const float B1 = mu1 * mu1 + mu2 * mu2 + C1, B2 = s11 + s22 + C2;
+      const float inv = 1.f / (B1 * B2);
+      const float S = A1 * A2 * inv;  // pytorch_ssim.py:42-43
+      // dS/d(mu1, E11, E12) with sigma1_sq = E11 - mu1^2, sigma12 = E12 - mu1 mu2
+      const float dA1 = A2 * inv, dA2 = A1 * inv, dB1 = -S / B1, dB2 = -S / B2;
+      const size_t off = plane + (size_t)yy * W + xx;
+      Pm[off] = 2.f * mu2 * (dA1 - dA2) + 2.f * mu1 * (dB1 - dB2);
+      P11[off] = dB2;
+      P12[off] = 2.f * dA2;
+      sum_s += S;
+      sum_l1 += fabsf(sx[r + LR][c + LR] - sy[r + LR][c + LR]);
+    }
   }
   sum_l1 = wave_sum(sum_l1); sum_s = wave_sum(sum_s);
   if ((tid & 63) == 0) { red[0][tid >> 6] = sum_l1; red[1][tid >> 6] = sum_s; }
   __syncthreads();
-  if (tid == 0) {
-    const size_t b = ((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    partials[2 * b] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
-    partials[2 * b + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  if (tid == 0) {  // one pair per TILE (not per workgroup): the summation order does not depend on the grid size
+    partials[2 * (size_t)t] = red[0][0] + red[0][1] + red[0][2] + red[0][3];
+    partials[2 * (size_t)t + 1] = red[1][0] + red[1][1] + red[1][2] + red[1][3];
+  }
+  __syncthreads();  // the next tile overwrites sx / sy / red
   }
 }
 
@@ -110,53 +180,112 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int nparts, const float* 
   }
 }
 
-__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, LossWin win, const float* __restrict__ img,
-                                                  const float* __restrict__ gt, const float* __restrict__ Pm,
-                                                  const float* __restrict__ P11, const float* __restrict__ P12,
-                                                  float c_l1, float c_ssim, float* __restrict__ dimg) {
+__global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int gx, int gy, LossWin win,
+                                                  const float* __restrict__ img, const float* __restrict__ gt,
+                                                  const float* __restrict__ Pm, const float* __restrict__ P11,
+                                                  const float* __restrict__ P12, float c_l1, float c_ssim,
+                                                  float* __restrict__ dimg) {
   __shared__ float s[3][IH][IW + 1];
   __shared__ float h[3][IH][TW + 1];
   const int tid = threadIdx.x;
-  const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, ch = blockIdx.z;
-  const size_t plane = (size_t)ch * H * W;
-  for (int i = tid; i < IH * IW; i += 256) {
-    const int r = i / IW, c = i - r * IW;
-    const int yy = y0 + r - LR, xx = x0 + c - LR;
-    float a = 0.f, b = 0.f, d = 0.f;
-    if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
-      const size_t o = plane + (size_t)yy * W + xx;
-      a = Pm[o]; b = P11[o]; d = P12[o];
+  const int ntiles = gx * gy * 3;
+  float fa[NLOAD], fb[NLOAD], fd[NLOAD];  // halo tile of the three derivative maps in flight (see k_ssim_fwd)
+  auto fetch = [&](int t) {
+    const TileAt T = tile_at(t, gx, gy, H, W);
+#pragma unroll
+    for (int j = 0; j < NLOAD; ++j) {
+      int r, c; size_t off;
+      fa[j] = 0.f; fb[j] = 0.f; fd[j] = 0.f;
+      const int i = tid + 256 * j;
+      if (i < IH * IW && tile_src(i, T.x0, T.y0, H, W, r, c, off)) {
+        fa[j] = Pm[T.plane + off]; fb[j] = P11[T.plane + off]; fd[j] = P12[T.plane + off];
+      }
     }
-    s[0][r][c] = a; s[1][r][c] = b; s[2][r][c] = d;
+  };
+  int t = blockIdx.x;
+  if (t < ntiles) fetch(t);
+  for (; t < ntiles; t += gridDim.x) {
+  const TileAt T = tile_at(t, gx, gy, H, W);
+  const int x0 = T.x0, y0 = T.y0;
+  const size_t plane = T.plane;
+  // this thread's VRUN output pixels: x, y are only needed at the very end -- fetched first, consumed last
+  const int oc = tid % TW, or0 = (tid / TW) * VRUN;
+  float px[VRUN], py[VRUN];
+#pragma unroll
+  for (int o = 0; o < VRUN; ++o) {
+    const int yy = y0 + or0 + o, xx = x0 + oc;
+    px[o] = 0.f; py[o] = 0.f;
+    if (yy < H && xx < W) { px[o] = img[plane + (size_t)yy * W + xx]; py[o] = gt[plane + (size_t)yy * W + xx]; }
+  }
+#pragma unroll
+  for (int j = 0; j < NLOAD; ++j) {
+    const int i = tid + 256 * j;
+    if (i < IH * IW) { const int r = i / IW, c = i - r * IW; s[0][r][c] = fa[j]; s[1][r][c] = fb[j]; s[2][r][c] = fd[j]; }
   }
   __syncthreads();
-  for (int i = tid; i < IH * TW; i += 256) {
-    const int r = i / TW, c = i - r * TW;
-    float a = 0.f, b = 0.f, d = 0.f;
+  if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+  if (tid < IH * HSEG) {  // horizontal pass, HRUN outputs per thread (see k_ssim_fwd)
+    const int r = tid % IH, c0 = (tid / IH) * HRUN;
+    float acc[3][HRUN];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k];
-      a += w * s[0][r][c + k]; b += w * s[1][r][c + k]; d += w * s[2][r][c + k];
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int o = 0; o < HRUN; ++o) acc[m][o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < HRUN + LW - 1; ++k) {
+      float sv[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) sv[m] = s[m][r][c0 + k];
+#pragma unroll
+      for (int o = 0; o < HRUN; ++o) {
+        const int tp = k - o;
+        if (tp >= 0 && tp < LW) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) acc[m][o] += win.g[tp] * sv[m];
+        }
+      }
     }
-    h[0][r][c] = a; h[1][r][c] = b; h[2][r][c] = d;
+#pragma unroll
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int o = 0; o < HRUN; ++o) h[m][r][c0 + o] = acc[m][o];
   }
   __syncthreads();
-  for (int i = tid; i < TH * TW; i += 256) {
-    const int r = i / TW, c = i - r * TW;
-    const int yy = y0 + r, xx = x0 + c;
-    if (yy >= H || xx >= W) continue;
-    float a = 0.f, b = 0.f, d = 0.f;
+  {  // vertical pass, VRUN outputs per thread
+    const int c = oc, r0 = or0;
+    float acc[3][VRUN];
 #pragma unroll
-    for (int k = 0; k < LW; ++k) {
-      const float w = win.g[k];
-      a += w * h[0][r + k][c]; b += w * h[1][r + k][c]; d += w * h[2][r + k][c];
+    for (int m = 0; m < 3; ++m)
+#pragma unroll
+      for (int o = 0; o < VRUN; ++o) acc[m][o] = 0.f;
+#pragma unroll
+    for (int k = 0; k < VRUN + LW - 1; ++k) {
+      float hv[3];
+#pragma unroll
+      for (int m = 0; m < 3; ++m) hv[m] = h[m][r0 + k][c];
+#pragma unroll
+      for (int o = 0; o < VRUN; ++o) {
+        const int tp = k - o;
+        if (tp >= 0 && tp < LW) {
+#pragma unroll
+          for (int m = 0; m < 3; ++m) acc[m][o] += win.g[tp] * hv[m];
+        }
+      }
     }
-    const size_t o = plane + (size_t)yy * W + xx;
-    const float x = img[o], y = gt[o];
-    const float dS = a + 2.f * x * b + y * d;   // d(sum of the SSIM map)/dx
-    const float df = x - y;
-    const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);  // torch.abs' subgradient: sign(0) = 0
-    dimg[o] = c_l1 * sg + c_ssim * dS;
+    const int xx = x0 + c;
+#pragma unroll
+    for (int o = 0; o < VRUN; ++o) {
+      const int yy = y0 + r0 + o;
+      if (yy >= H || xx >= W) continue;
+      const size_t off = plane + (size_t)yy * W + xx;
+      const float x = px[o], y = py[o];
+      const float dS = acc[0][o] + 2.f * x * acc[1][o] + y * acc[2][o];   // d(sum of the SSIM map)/dx
+      const float df = x - y;
+      const float sg = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);  // torch.abs' subgradient: sign(0) = 0
+      dimg[off] = c_l1 * sg + c_ssim * dS;
+    }
+  }
+  __syncthreads();  // the next tile overwrites s / h
   }
 }
 
@@ -191,8 +320,16 @@ extern "C" int egs_gau_loss(int height, int width, const float* image, const flo
   double sum = 0.0, g[LW];
   for (int i = 0; i < LW; ++i) { g[i] = exp(-(double)((i - LR) * (i - LR)) / (2.0 * 1.5 * 1.5)); sum += g[i]; }
   for (int i = 0; i < LW; ++i) win.g[i] = (float)(g[i] / sum);
-  dim3 grid(div_up(width, TW), div_up(height, TH), 3);
-  EGS_LAUNCH("k_ssim_fwd", k_ssim_fwd, grid, dim3(256), s, height, width, win, image, gt_image, Pm, P11, P12,
+  const int gx = div_up(width, TW), gy = div_up(height, TH);
+  static const int resident = [] {  // persistent workgroups: 3 per CU (LDS), every CU of the current device
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    return 3 * cus;
+  }();
+  const dim3 grid(nb < resident ? nb : resident);
+  EGS_LAUNCH("k_ssim_fwd", k_ssim_fwd, grid, dim3(256), s, height, width, gx, gy, win, image, gt_image, Pm, P11, P12,
              partials);
   const float inv_count = (float)(1.0 / (double)npix);
   EGS_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), s, nb, partials, loss_lambda, inv_count,
@@ -200,8 +337,8 @@ extern "C" int egs_gau_loss(int height, int width, const float* image, const flo
   if (dloss_dimage) {
     const float c_l1 = grad_scale * (1.f - loss_lambda) * inv_count;
     const float c_ssim = -grad_scale * loss_lambda * inv_count;
-    EGS_LAUNCH("k_ssim_bwd", k_ssim_bwd, grid, dim3(256), s, height, width, win, image, gt_image, Pm, P11, P12, c_l1,
-               c_ssim, dloss_dimage);
+    EGS_LAUNCH("k_ssim_bwd", k_ssim_bwd, grid, dim3(256), s, height, width, gx, gy, win, image, gt_image, Pm, P11, P12,
+               c_l1, c_ssim, dloss_dimage);
   }
   EGS_LAUNCH_OK();
   return 0;
