@@ -617,13 +617,25 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
       sC[lane] = make_float4(B.z, B.w, C.x, C.z);   // colour; y pixel box (BOX)
     }
     __syncthreads();
+    // The reach masks of eight consecutive entries packed into one dword (4 bits each), gathered into the
+    // group's first lane through the LDS permute path (ds_bpermute: no VALU issue slot): the blend loop
+    // reads ONE SGPR per group of eight entries, skips the whole group when none of them reaches a live
+    // block, and is fully unrolled over the group -- LDS addresses are an immediate offset from one base,
+    // no per-entry v_readlane / v_mov / loop counter.  (Entries past the end of the list staged mask 0.)
+    int pk = mymask;
+    pk |= __shfl_down(pk, 1, 64) << 4;
+    pk |= __shfl_down(pk, 2, 64) << 8;
+    pk |= __shfl_down(pk, 4, 64) << 16;
     const int m = __builtin_amdgcn_readfirstlane(min(64, n - base));
     for (int j0 = 0; j0 < m && live != 0; j0 += 8) {  // eight entries, then the live-mask refresh
-    const int jend = min(j0 + 8, m);
-    for (int j = j0; j < jend; ++j) {
-      // the entry's mask comes straight out of lane j's register (v_readlane): no LDS round trip
-      const int reach = __builtin_amdgcn_readlane(mymask, j) & live;
+    const uint32_t act = (uint32_t)__builtin_amdgcn_readlane(pk, j0) & ((uint32_t)live * 0x11111111u);
+    if (act != 0u) {
+    const int vidx0 = base + j0 + 1;
+#pragma unroll
+    for (int t = 0; t < 8; ++t) {
+      const int reach = (int)((act >> (4 * t)) & 0xFu);
       if (reach != 0) {  // scalar branch: some live block is within reach of this entry
+        const int j = j0 + t;
         const float4 Q = sA[j], P = sB[j], K = sC[j];  // wave-uniform address: LDS broadcast
         bool inx[2] = {true, true}, iny[2] = {true, true};
         if (BOX) {
@@ -635,7 +647,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
             iny[b] = (pyb[b] >= y0) && (pyb[b] < y1);
           }
         }
-        const int idx = base + j + 1;
+        const int idx = vidx0 + t;
 #pragma unroll
         for (int k = 0; k < 4; ++k) {
           const int bx = k & 1, by = k >> 1;
@@ -659,6 +671,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
           }
         }
       }
+    }
     }
     // Finished pixels fail `tau >= stop` on their own, so the live-block mask only saves work: it is
     // refreshed every 8 entries instead of tracking "some pixel just finished" per block; when it
