@@ -672,13 +672,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void
         }
       }
     }
-    }
     // Finished pixels fail `tau >= stop` on their own, so the live-block mask only saves work: it is
-    // refreshed every 8 entries instead of tracking "some pixel just finished" per block; when it
-    // empties, every pixel of the tile is finished and both loops end (scalar exit).
+    // refreshed after a group that blended something instead of tracking "some pixel just finished" per
+    // block; when it empties, every pixel of the tile is finished and both loops end (scalar exit).
 #pragma unroll
     for (int k = 0; k < 4; ++k)
       if ((live & (1 << k)) && !__any(tau[k] >= stop)) live &= ~(1 << k);
+    }
     }
   }
   const size_t HW = (size_t)p.W * p.H;
