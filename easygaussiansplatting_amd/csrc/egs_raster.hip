@@ -537,7 +537,7 @@ __device__ __forceinline__ float min_hi(float x, float hi) {
 }
 
 template <bool BOX, bool FLOOR, bool CLAMP, bool SKIP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKIP) ? 8 : 6, 8))) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
