@@ -360,11 +360,14 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
                                                   const uint32_t* __restrict__ offsets,
                                                   const uint4* __restrict__ rects,
                                                   uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid,
-                                                  uint32_t cap) {
+                                                  uint32_t cap, int32_t* __restrict__ ranges, int n_ranges) {
   __shared__ uint32_t s_off[257];   // offsets relative to the workgroup's first one; [256] = span length
   __shared__ uint32_t s_g[256], s_xy[256], s_w[256];
   const int tid = threadIdx.x;
   const int j = blockIdx.x * 256 + tid;
+  // tiles without patches keep (0, 0): k_tile_ranges, three sorts further down the stream, only writes the
+  // tiles that have some -- zeroed here instead of by a separate 5-us fill in front of this kernel
+  for (int i = j; i < n_ranges; i += gridDim.x * 256) ranges[i] = 0;
   uint32_t off = 0, cnt = 0, g = 0, x0 = 0, y0 = 0, w = 1;
   if (j < n) {
     g = ids[j];
@@ -1159,9 +1162,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
   hipStream_t s = (hipStream_t)stream;
   const DrawParams dp = make_draw_params(width, height, pol);
-  EGS_HIP(hipMemsetAsync(patch_range_per_tile, 0, (size_t)dp.T * 8, s));
   if (n == 0 || patches == 0) {  // nothing to draw: all outputs are zero
     const size_t hw = (size_t)width * height;
+    EGS_HIP(hipMemsetAsync(patch_range_per_tile, 0, (size_t)dp.T * 8, s));
     EGS_HIP(hipMemsetAsync(image, 0, 12 * hw, s));
     EGS_HIP(hipMemsetAsync(contrib, 0, 4 * hw, s));
     EGS_HIP(hipMemsetAsync(final_tau, 0, 4 * hw, s));
@@ -1185,7 +1188,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
   EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
-                     v0, (uint32_t)patches);
+                     v0, (uint32_t)patches, patch_range_per_tile, 2 * dp.T);
   const float4* rec = rec_in ? rec_in : D.rec;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
