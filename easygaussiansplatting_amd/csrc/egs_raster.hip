@@ -499,14 +499,16 @@ static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(
 // One wave64 per 16x16 tile.  The tile is walked as four 8x8 pixel blocks
 // (k = 0..3, block (k&1, k>>1)); lane l owns pixel (l&7, l>>3) of each block.  Per
 // list entry a block is skipped outright when the entry's certain-miss box (pack
-// kernel) or pixel box does not reach it -- a wave-uniform branch.  The quadratic
-// form is evaluated separably: cxx[bx] + cyy[by] + cxy[bx]*dy[by].  (Measured on gfx950,
+// kernel) or pixel box does not reach it -- a wave-uniform branch.  The forward kernel
+// evaluates the exponent as a polynomial about the tile centre (below), the backward kernel
+// separably from the differences it also needs for the moments: cxx[bx] + cyy[by] +
+// cxy[bx]*dy[by].  (Measured on gfx950,
 // tools/ubench_valu.hip: v_pk_*_f32 costs exactly 2x a plain fp32 op, v_exp/v_rcp 3x,
 // v_max/v_cmp->SGPR 1.6x -- so the kernels minimise instruction count, not pack.)
 // A pixel that is finished or outside the image holds tau < tau_stop, so "still
 // blending" is the one compare `tau >= stop`; the wave-uniform 4-bit `live` mask of
-// blocks with an unfinished pixel is refreshed every eight entries and gates the
-// per-block scalar branches and the early exit.
+// blocks with an unfinished pixel is refreshed after every group of eight entries and gates
+// the per-block scalar branches and the early exit.
 // 4-bit reach mask of one list entry over the four 8x8 blocks of a tile (bit k = block
 // (k&1, k>>1)).  Computed ONCE per entry by the lane that stages it (64 entries in
 // parallel) instead of by all 64 lanes of the blend loop.
