@@ -5,22 +5,31 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-One "step" = one pass of the rasterizer hot path over one batch of synthetic
-input, exactly as a training step drives it (reference gsplat/gsmodel.py:6-93):
-the six forward ops with calc_J=True, then splatB + the chain rule, producing
-the 59 parameter-gradient floats per Gaussian.  With N > 1 every rank renders
-its own camera view of the same scene (one view per GPU, weak scaling) and the
-step ends with an RCCL all-reduce of the parameter gradients (236 MB at 1 M
-Gaussians); `value` is the whole-job rate: N * W*H / t_step.
+One "step" = one pass of the rasterizer hot path over one batch of synthetic input, exactly as a training
+step drives it (reference gsplat/gsmodel.py:6-93): ``GSFunction`` forward + backward producing the 59
+parameter-gradient floats per Gaussian.  The default ``--mode fused`` evaluates it with the fused kernels
+(one preprocess kernel that also bins, sort, draw; draw-backward, one Jacobian-free chain-rule kernel);
+``--mode ops`` is the reference's seven-op structure (six ops with calc_J=True, splat, splatB, chain rule) --
+its time is also reported as ``ops_ms_per_step`` of the default run.  The step validates its patch count the
+way ``Trainer.step`` does (``fused.deferred()`` + ``commit()``): nothing is skipped inside the timed region.
+With N > 1 every rank renders its own camera view of the same scene (one view per GPU, weak scaling) and the
+step ends with an RCCL all-reduce of the parameter gradients (236 MB at 1 M Gaussians); `value` is the
+whole-job rate: N * W*H / t_step.
 
 Rank 0 prints ONE JSON line carrying, besides the contract fields,
-  roofline     -- the dominant kernel of the timed region (by HIP-event time,
-                  measured on the stream it is launched on), algorithmic bytes per
-                  launch / average launch duration vs the 8 TB/s HBM peak;
-  cpu_baseline -- the reference-equivalent CPU path (oracle/gs_oracle.py policy A
-                  == forward_cpu.py, single thread) timed on a bounded sample.
+  gpu_busy_ms_per_step -- sum of the HIP-event durations of all kernels of a step (untimed pre-pass), next to
+                  the wall-clock ms_per_step: a ratio above 1.03 means the host, not the GPU, set the pace
+                  (a warning goes to stderr);
+  roofline     -- the dominant kernel of the timed region (by HIP-event time, measured on the stream it is
+                  launched on), algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
+                  and vs a device-to-device copy timed on this box (peak_measured);
+  cpu_baseline -- the reference-equivalent CPU path (oracle/gs_oracle.py policy A == forward_cpu.py, single
+                  thread) timed on a bounded sample.
 """
 import argparse
+import contextlib
+import glob
+import hashlib
 import json
 import os
 import sys
@@ -32,12 +41,25 @@ REPO = os.path.dirname(os.path.abspath(__file__))
 if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+XGMI_LINK_GBS = 153.0    # per link and direction, 7 links per GPU (prompt / SURVEY 8e)
+
+
+def kernel_source_hash():
+    """Fingerprint of the kernel sources: counters stored under profiles/ are only quoted when they were
+    collected from exactly this code (there is no .git on the GPU box)."""
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(REPO, "easygaussiansplatting_amd", "csrc", "*.hip")) +
+                    glob.glob(os.path.join(REPO, "easygaussiansplatting_amd", "csrc", "*.h")) +
+                    [os.path.join(REPO, "include", "egs_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
 
 
 def algorithmic_bytes(kernel, N, P, T, HW, K):
-    """Algorithmic HBM bytes of ONE launch of `kernel` (each input read once, each
-    output written once; atomics as read-modify-write)."""
+    """Algorithmic HBM bytes of ONE launch of `kernel` (each input read once, each output written once;
+    atomics as read-modify-write)."""
     nc = K // 3
     table = {
         # per-Gaussian stages with Jacobians: inputs + outputs + Jacobians
@@ -51,14 +73,17 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         "k_bin_emit": N * (4 + 4 + 16) + P * 8,
         "k_radix_hist": None, "k_radix_rowscan": None, "k_radix_scatter": None,  # size depends on the pass
         "k_tile_ranges": P * 4 + T * 8,
-        # draw: gather 40 B per patch (u 8, cinv 12, alpha 4, color 12, gsid 4) + ranges + 20 B per pixel out
+        "k_tile_order": T * 12,
+        # draw, at the mandated op surface: 40 B per patch (u 8, cinv 12, alpha 4, color 12, gsid 4)
+        # + ranges + 20 B per pixel out.  (The kernel gathers ONE packed 48-B record + 4-B list value instead.)
         "k_draw": 40 * P + 8 * T + 20 * HW,
-        # drawB: same gather + 9 fp32 atomics (RMW = 72 B) per patch + 20 B per pixel in
+        # drawB: the same gather + 9 fp32 atomics (RMW = 72 B) per patch + 20 B per pixel in
         "k_draw_bwd": 112 * P + 8 * T + 20 * HW,
         "k_chain_rule": N * (436 - 24 + 24 + 36 + 4 * (3 + 3 * nc + 3 + 4)),
-        # fused path: parameters in (pw 12, rot 16, scale 12, sh 4K) + 2D records out (44 B)
-        "k_preprocess_fwd": N * (40 + 4 * K + 44),
-        # parameters + depth + packed gradient record in, 59 gradient floats + du out
+        # fused path: parameters in (pw 12, rot 16, scale 12, sh 4K, alpha 4); out: depth 4, mask 1, the packed
+        # 48-B record, and the binning's rect 16 + count 4 + depth key 4 + id 4      (= 317 N at K = 48)
+        "k_preprocess_fwd": N * (44 + 4 * K + 4 + 1 + 48 + 28),
+        # parameters + depth + packed gradient record in, 59 gradient floats + du out (= 528 N at K = 48)
         "k_preprocess_bwd": N * (40 + 4 * K + 4 + 48 + 4 * (3 + K + 1 + 3 + 4 + 2)),
         "k_unpack_grads": N * (48 + 36),
     }
@@ -102,18 +127,22 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--gaussians", type=int, default=1_000_000)
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-dim", type=int, default=48)
     ap.add_argument("--cpu-sample", type=int, default=250_000, help="Gaussians in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
+    ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
     ap.add_argument("--extras", action="store_true",
                     help="also time render+loss+backward and the whole optimizer step (other dL/dimage, so their "
                          "kernel launches would blur a rocprofv3 summary of the headline step)")
-    ap.add_argument("--mode", default="fused", choices=["fused", "ops", "ops_bmm"],
+    ap.add_argument("--mode", default="fused", choices=["fused", "ops"],
                     help="GSFunction evaluation: fused kernels (default) or the reference's 7-op structure")
+    ap.add_argument("--immediate", action="store_true",
+                    help="fused mode: validate the patch count inside forward (one host wait per render) instead of "
+                         "at the step's commit()")
     a = ap.parse_args()
 
     import torch
@@ -144,6 +173,7 @@ def main():
     lib = _lib.load()
     gsc.set_policy("gsplatcu")
     GSFunction.mode = a.mode
+    from easygaussiansplatting_amd import dist_views as DV
     from easygaussiansplatting_amd import fused as fused_path
 
     def forward_only():
@@ -166,25 +196,57 @@ def main():
     HW = a.width * a.height
     dl = torch.from_numpy(S.normal(1, 77, (3, a.height, a.width)).astype(np.float32)).to(dev) / (3 * HW)
     order = ("pws", "shs", "alphas", "scales", "rots")
+    # the exchange may overlap the tail of the backward pass (chunked preprocess-backward, dist_views):
+    # it is then launched from inside backward and only finished here
+    overlap = DV.ChunkedExchange(world) if exchange and a.mode == "fused" else None
+    # deferred validation needs every rank to take the same decision about a redo BEFORE any collective is
+    # issued; with the overlapped exchange the collectives start inside backward, so renders are then
+    # validated at once (the step is exchange-bound there and the host has time to spare)
+    deferred = a.mode == "fused" and not a.immediate and overlap is None
+    ev_render, ev_done = [], []
+    redone = [0]
 
-    def step():
+    def render_step():
         for p in params.values():
             p.grad = None
         us0.grad = None
         image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
                                        params["rots"], us0, cam)
         image.backward(dl)
+        return image
+
+    def step(timing=False):
+        if timing:
+            e0 = torch.cuda.Event(enable_timing=True); e0.record()
+        if deferred:
+            with fused_path.deferred() as d:
+                image = render_step()
+                bad = d.commit()       # waits for the 8-byte read-back of THIS step's binning stage only
+            if bad:                    # patch list outgrew the buffers (never in steady state): exact redo
+                redone[0] += 1
+                image = render_step()
+        else:
+            with (overlap.attach() if overlap is not None else contextlib.nullcontext()):
+                image = render_step()
+        if timing:
+            e1 = torch.cuda.Event(enable_timing=True); e1.record()
         if exchange:  # gradient exchange: 59 floats per Gaussian, SUM then mean
-            flat = fused_path.flat_grad_buffer([params[k] for k in order])
-            if flat is not None:      # the fused backward hands out slices of one buffer: ONE all-reduce
-                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                flat.div_(float(world))
+            if overlap is not None and overlap.finish():
+                pass                  # issued chunk by chunk from inside backward; now complete
             else:
-                grads = [params[k].grad for k in order]
-                hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
-                for h in hs:
-                    h.wait()
-                torch._foreach_div_(grads, float(world))
+                flat = fused_path.flat_grad_buffer([params[k] for k in order])
+                if flat is not None:      # the fused backward hands out slices of one buffer: ONE all-reduce
+                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                    flat.div_(float(world))
+                else:
+                    grads = [params[k].grad for k in order]
+                    hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
+                    for h in hs:
+                        h.wait()
+                    torch._foreach_div_(grads, float(world))
+        if timing:
+            e2 = torch.cuda.Event(enable_timing=True); e2.record()
+            ev_render.append((e0, e1)); ev_done.append((e1, e2))
         return image
 
     def sync():
@@ -205,9 +267,9 @@ def main():
         return parse_report(buf.value.decode())
 
     # Untimed pre-pass with EVERY launch bracketed by HIP events: per-kernel table + which kernel
-    # dominates.  (Bracketing all ~35 launches serialises dispatch and costs ~0.2 ms/step, so the
+    # dominates.  (Bracketing all ~30 launches serialises dispatch and costs ~0.2 ms/step, so the
     # timed region below brackets only the dominant kernel.)
-    kernels, dom = {}, None
+    kernels, dom, gpu_busy_ms = {}, None, None
     if prof:
         pre = 3
         lib.egs_prof_set_filter(None); lib.egs_prof_reset(); lib.egs_prof_enable(1)
@@ -219,6 +281,7 @@ def main():
         kernels = {k: {"launches_per_step": c // pre, "avg_us": round(tot / c * 1e3, 2),
                        "ms_per_step": round(tot / pre, 4)}
                    for k, (c, tot) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+        gpu_busy_ms = sum(tot for _, tot in rep.values()) / pre
         dom = max(rep.items(), key=lambda kv: kv[1][1])[0]
         lib.egs_prof_set_filter(dom.encode()); lib.egs_prof_reset(); lib.egs_prof_enable(1)
         sync()
@@ -239,7 +302,33 @@ def main():
     dt = float(dt_t.item())
     ms = dt / a.steps * 1e3
 
-    # realised scene statistics (bytes depend on them; SURVEY §8d)
+    roofline_rep = read_report() if prof else None   # only the dominant kernel, recorded over the timed region
+    if prof:
+        lib.egs_prof_set_filter(None)
+
+    # per-rank anatomy of a step (outside the timed region): render = forward + backward kernels,
+    # exchange = what the gradient all-reduce adds behind them
+    exch = None
+    if exchange:
+        for _ in range(5):
+            step(timing=True)
+        sync()
+        tr = float(np.mean([x.elapsed_time(y) for x, y in ev_render]))
+        te = float(np.mean([x.elapsed_time(y) for x, y in ev_done]))
+        mine = torch.tensor([tr, te], dtype=torch.float64, device=dev)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        nbytes = DV.grad_exchange_bytes(sc.n)
+        te_max = max(float(x[1]) for x in allr)
+        exch = {"bytes": nbytes, "t_render_ms": [round(float(x[0]), 4) for x in allr],
+                "t_exchange_ms": [round(float(x[1]), 4) for x in allr],
+                "overlapped_with_backward": bool(overlap is not None and overlap.used),
+                "bus_GBs": round(2 * (world - 1) / world * nbytes / (te_max * 1e-3) / 1e9, 1) if world > 1 else None,
+                "xgmi_bound_ms": None if world == 1 else {
+                    "ring_one_link": round(2 * (world - 1) / world * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3, 3),
+                    "direct_all_links": round(2 * nbytes / world / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}}
+
+    # realised scene statistics (bytes depend on them; SURVEY 8d)
     with torch.no_grad():
         _, ranges, gsid = forward_only()
         lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64)
@@ -255,20 +344,59 @@ def main():
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
 
+    # the unmodified-caller surface: GSFunction over the seven ops (six with calc_J=True, splat, splatB and the
+    # chain-rule kernel over the stored Jacobians) -- an extra, outside the timed region
+    ops_ms = None
+    if a.mode == "fused" and not a.no_ops and rank == 0 and world == 1:
+        GSFunction.mode = "ops"
+        for _ in range(2):
+            render_step()
+        torch.cuda.synchronize()
+        to0 = time.perf_counter()
+        for _ in range(10):
+            render_step()
+        torch.cuda.synchronize()
+        ops_ms = (time.perf_counter() - to0) / 10 * 1e3
+        GSFunction.mode = a.mode
+        for p in params.values():
+            p.grad = None
+        torch.cuda.empty_cache()
+
+    # achievable HBM bandwidth on THIS box: a device-to-device float4 copy ("confirm on the box
+    # with a device-to-device copy kernel and report both")
+    peak_measured = None
+    if rank == 0:
+        nb = 1 << 30
+        src = torch.empty(nb, dtype=torch.uint8, device=dev).fill_(1)
+        dst = torch.empty(nb, dtype=torch.uint8, device=dev)
+        st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for _ in range(2):
+            _lib.check(lib.egs_hbm_copy_probe(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nb, st))
+        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+        c0.record()
+        reps = 10
+        for _ in range(reps):
+            _lib.check(lib.egs_hbm_copy_probe(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nb, st))
+        c1.record()
+        torch.cuda.synchronize()
+        peak_measured = round(2.0 * nb * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)   # read + write
+        del src, dst
+
     # informative extra (outside the timed region): render + fused L1/SSIM loss + backward, i.e. a
     # training step without the optimizer (the torch loss of the reference costs 10.9 ms at 1080p)
     from easygaussiansplatting_amd.loss import gau_loss
-    gt = torch.rand((3, a.height, a.width), device=dev)
     loss_step_ms = None
-
-    def step_with_loss():
-        for p in params.values():
-            p.grad = None
-        us0.grad = None
-        img, _ = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
-                                  params["rots"], us0, cam)
-        gau_loss(img, gt).backward()
+    train_extra = None
     if a.extras:
+        gt = torch.rand((3, a.height, a.width), device=dev)
+
+        def step_with_loss():
+            for p in params.values():
+                p.grad = None
+            us0.grad = None
+            img, _ = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
+                                      params["rots"], us0, cam)
+            gau_loss(img, gt).backward()
         for _ in range(2):
             step_with_loss()
         torch.cuda.synchronize()
@@ -278,76 +406,70 @@ def main():
         torch.cuda.synchronize()
         loss_step_ms = (time.perf_counter() - tl0) / nf * 1e3
 
-    # informative extra: the whole optimizer step of the train.py counterpart (raw parameters ->
-    # activations -> render -> loss -> backward -> Adam) and the two Adam implementations alone
-    train_extra = None
-    if rank == 0 and world == 1 and a.extras:
-        from easygaussiansplatting_amd.optim import FusedAdam, adam_groups
-        from easygaussiansplatting_amd.trainer import activate, raw_params_from_scene
+        # the whole optimizer step of the train.py counterpart (raw parameters -> activations -> render ->
+        # loss -> backward -> Adam) and the two Adam implementations alone
+        if rank == 0 and world == 1:
+            from easygaussiansplatting_amd.optim import FusedAdam, adam_groups
+            from easygaussiansplatting_amd.trainer import activate, raw_params_from_scene
 
-        def timed(fn, n):
-            for _ in range(2):
-                fn()
-            torch.cuda.synchronize()
-            t0_ = time.perf_counter()
-            for _ in range(n):
-                fn()
-            torch.cuda.synchronize()
-            return (time.perf_counter() - t0_) / n * 1e3
-        raw = raw_params_from_scene(sc, dev)
-        opts = {"fused": FusedAdam(adam_groups(raw), eps=1e-15),
-                "torch": torch.optim.Adam(adam_groups(raw), lr=0.0, eps=1e-15)}
+            def timed(fn, n):
+                for _ in range(2):
+                    fn()
+                torch.cuda.synchronize()
+                t0_ = time.perf_counter()
+                for _ in range(n):
+                    fn()
+                torch.cuda.synchronize()
+                return (time.perf_counter() - t0_) / n * 1e3
+            raw = raw_params_from_scene(sc, dev)
+            opts = {"fused": FusedAdam(adam_groups(raw), eps=1e-15),
+                    "torch": torch.optim.Adam(adam_groups(raw), lr=0.0, eps=1e-15)}
 
-        from easygaussiansplatting_amd.function import GSRawFunction
+            from easygaussiansplatting_amd.function import GSRawFunction
 
-        def train_step(opt, fused_act=False):
-            opt.zero_grad(set_to_none=True)
-            us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-            if fused_act:   # activations inside the HIP kernels
-                img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
-                                             raw["scales_raw"], raw["rots_raw"], us, cam)
-            else:           # the reference's structure: torch activations around GSFunction
-                img, _ = GSFunction.apply(*activate(raw), us, cam)
-            gau_loss(img, gt).backward()
-            opt.step()
-        train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
-        train_extra["train_step_ms_fused_activations_fused_adam"] = round(
-            timed(lambda: train_step(opts["fused"], True), nf), 4)
-        for name, opt in opts.items():
-            train_extra["train_step_ms_torch_activations_%s_adam" % name] = round(timed(lambda: train_step(opt), nf), 4)
-            train_extra["adam_only_ms_%s" % name] = round(timed(opt.step, nf), 4)
+            def train_step(opt, fused_act=False):
+                opt.zero_grad(set_to_none=True)
+                us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+                if fused_act:   # activations inside the HIP kernels
+                    img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                                 raw["scales_raw"], raw["rots_raw"], us, cam)
+                else:           # the reference's structure: torch activations around GSFunction
+                    img, _ = GSFunction.apply(*activate(raw), us, cam)
+                gau_loss(img, gt).backward()
+                opt.step()
+            train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
+            train_extra["train_step_ms_fused_activations_fused_adam"] = round(
+                timed(lambda: train_step(opts["fused"], True), nf), 4)
+            for name, opt in opts.items():
+                train_extra["train_step_ms_torch_activations_%s_adam" % name] = round(
+                    timed(lambda: train_step(opt), nf), 4)
+                train_extra["adam_only_ms_%s" % name] = round(timed(opt.step, nf), 4)
 
     roofline = None
-    if prof:
-        rep = read_report()          # only the dominant kernel, recorded over the timed region
-        lib.egs_prof_set_filter(None)
-        cnt, tot = rep[dom]
+    src_hash = kernel_source_hash()
+    if prof and roofline_rep and dom in roofline_rep:
+        cnt, tot = roofline_rep[dom]
         avg_s = tot / cnt * 1e-3
         ab = algorithmic_bytes(dom, sc.n, P, T, HW, a.sh_dim)
         if ab is not None:
             ach = ab / avg_s / 1e9
             roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                        "peak_measured": peak_measured,
+                        "frac_of_measured": None if not peak_measured else round(ach / peak_measured, 4),
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 1),
                         "launches": cnt, "share_of_step": round(tot / a.steps / ms, 3)}
-            # the kernel is VALU-issue bound, not HBM bound: say so next to the HBM fraction (SQ counters of the
-            # rocprofv3 --pmc passes in profiles/: busy = SQ_ACTIVE_INST_VALU x 4 / SIMDs / (GRBM_GUI_ACTIVE / XCDs))
-            spath = os.path.join(REPO, "profiles", "r1_final_sq_counters.json")
-            if os.path.exists(spath):
-                try:
-                    for kname, c in json.load(open(spath)).items():
-                        if kname.replace("egs::", "").split("<")[0] == dom and "SQ_ACTIVE_INST_VALU" in c:
-                            roofline["valu_busy"] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / 1024 /
-                                                          (c["GRBM_GUI_ACTIVE"] / 8), 3)
-                            roofline["valu_insts_per_launch"] = int(c["SQ_INSTS_VALU"])
-                except Exception:
-                    pass
+            # HBM bytes per launch and the calibrated VALU-issue utilisation come from rocprofv3 --pmc passes stored
+            # under profiles/ -- quoted only when those passes ran on exactly these kernel sources
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
-            if os.path.exists(tpath):  # HBM bytes per launch from the rocprofv3 --pmc passes (profiles/)
+            if os.path.exists(tpath):
                 try:
                     tj = json.load(open(tpath))
-                    if tj.get("gaussians") == sc.n and tj.get("width") == a.width and dom in tj.get("kernels", {}):
+                    if (tj.get("source_hash") == src_hash and tj.get("gaussians") == sc.n and
+                            tj.get("width") == a.width and dom in tj.get("kernels", {})):
                         roofline["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
+                        if "valu_issue_util" in tj["kernels"][dom]:
+                            roofline["valu_issue_util"] = tj["kernels"][dom]["valu_issue_util"]
                 except Exception:
                     pass
 
@@ -368,15 +490,24 @@ def main():
                                       ", RCCL all-reduce of 59 fp32 grads/Gaussian" if world > 1 else ""),
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
                        "views_per_step": world, "policy": "gsplatcu", "mode": a.mode,
+                       "validation": "deferred (commit per step)" if deferred else "immediate",
                        "patches": P, "tiles": T, "max_list_len": max_len, "pixel_gaussian_pairs": pairs},
+            "gpu_busy_ms_per_step": None if gpu_busy_ms is None else round(gpu_busy_ms, 4),
+            "wall_over_gpu_busy": None if not gpu_busy_ms else round(ms / gpu_busy_ms, 4),
+            "redone_steps": redone[0],
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
+            "ops_ms_per_step": None if ops_ms is None else round(ops_ms, 4),
             "fwd_loss_bwd": None if loss_step_ms is None else {
                 "ms": round(loss_step_ms, 4), "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
-            "train_step": train_extra,
-            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels,
+            "train_step": train_extra, "exchange": exch,
+            "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_source_hash": src_hash,
         }
         if cpu:
             line["fwd_speedup_vs_cpu"] = round(line["fwd_only"]["Mpix/s"] / cpu["value"], 1)
+        if gpu_busy_ms and world == 1 and ms > 1.03 * gpu_busy_ms:
+            print("bench.py: WARNING: wall-clock %.4f ms/step is %.1f %% above the %.4f ms the kernels take: the "
+                  "host, not the GPU, set the pace of this run" % (ms, (ms / gpu_busy_ms - 1) * 100, gpu_busy_ms),
+                  file=sys.stderr)
     if exchange:
         dist.destroy_process_group()
     if rank == 0:

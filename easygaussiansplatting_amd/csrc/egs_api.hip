@@ -103,6 +103,93 @@ extern "C" int egs_prof_report(char* buf, size_t cap) {
   return (int)out.size();
 }
 
+// ---- HBM bandwidth probe: the device-to-device copy bench.py calibrates its roofline peak with --------
+namespace egs {
+__global__ __launch_bounds__(256) void k_hbm_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+}
+}  // namespace egs
+
+extern "C" int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream) {
+  EGS_CHECK_ARG(dst && src && bytes >= 16 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0);
+  const size_t n4 = bytes / 16;
+  // 16 workgroups per CU, each lane streaming float4s with a grid stride: the copy shape MI355X_MICROARCH.md
+  // quotes 6.29 TB/s for
+  hipLaunchKernelGGL(egs::k_hbm_copy, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
+                     (float4*)dst, n4);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// ---- mailbox: page-locked landing slots for the read-back of the enqueue-ahead path ------------------
+namespace egs {
+struct Mailbox {
+  int slots;
+  uint32_t* host;                 // slots x 4 words, page-locked
+  std::vector<hipEvent_t> ev;     // recorded behind the copy into the slot
+};
+}  // namespace egs
+
+extern "C" void* egs_mailbox_create(int slots) {
+  if (slots <= 0 || slots > 4096) return nullptr;
+  egs::Mailbox* m = new egs::Mailbox();
+  m->slots = slots;
+  m->host = nullptr;
+  if (hipHostMalloc((void**)&m->host, (size_t)slots * 16, hipHostMallocDefault) != hipSuccess) {
+    delete m;
+    return nullptr;
+  }
+  memset(m->host, 0xFF, (size_t)slots * 16);
+  m->ev.resize(slots, nullptr);
+  for (int i = 0; i < slots; ++i)
+    if (hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) != hipSuccess) {
+      for (int j = 0; j < i; ++j) (void)hipEventDestroy(m->ev[j]);
+      (void)hipHostFree(m->host);
+      delete m;
+      return nullptr;
+    }
+  return m;
+}
+
+extern "C" void egs_mailbox_destroy(void* mb) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  if (!m) return;
+  for (auto e : m->ev) (void)hipEventDestroy(e);
+  (void)hipHostFree(m->host);
+  delete m;
+}
+
+extern "C" int egs_mailbox_post(void* mb, int slot, const uint32_t* total_patches, void* stream) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots && total_patches);
+  hipStream_t s = (hipStream_t)stream;
+  EGS_HIP(hipMemcpyAsync(m->host + 4 * (size_t)slot, total_patches, 8, hipMemcpyDeviceToHost, s));
+  EGS_HIP(hipEventRecord(m->ev[slot], s));
+  return 0;
+}
+
+extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  if (!m || slot < 0 || slot >= m->slots || !out) {
+    egs::set_error(EGS_ERR_BAD_ARG, "bad argument: mailbox / slot / out", __FILE__, __LINE__);
+    return -EGS_ERR_BAD_ARG;
+  }
+  hipError_t e = hipEventQuery(m->ev[slot]);
+  if (e == hipErrorNotReady) {
+    if (!blocking) return 0;
+    e = hipEventSynchronize(m->ev[slot]);
+  }
+  if (e != hipSuccess) {
+    egs::set_error((int)e, hipGetErrorString(e), __FILE__, __LINE__);
+    return -(int)e;
+  }
+  const volatile uint32_t* h = m->host + 4 * (size_t)slot;
+  out[0] = h[0];
+  out[1] = h[1];
+  return 1;
+}
+
 extern "C" const char* egs_last_error_string(void) { return egs::g_err; }
 extern "C" int egs_abi_version(void) { return EGS_ABI_VERSION; }
 

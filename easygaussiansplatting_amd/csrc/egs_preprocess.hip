@@ -790,8 +790,15 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
                                const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                float* dloss_dshs, float* dloss_dshs_high, float* dloss_dalphas, float* dloss_dscales,
-                               float* dloss_drots, float* dloss_dus, void* stream) {
+                               float* dloss_drots, float* dloss_dus, int phase, int row_begin, int row_count,
+                               void* stream) {
+  // phase 0: everything; 1: only the draw pass (-> packed gradient records in ws); 2: only the per-Gaussian
+  // chain rule, for rows [row_begin, row_begin + row_count) -- a data-parallel caller launches the rows in a
+  // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && patches >= 0);
+  EGS_CHECK_ARG(phase >= 0 && phase <= 2);
+  if (phase != 2) { row_begin = 0; row_count = n; }
+  EGS_CHECK_ARG(row_begin >= 0 && row_count >= 0 && row_begin + (int64_t)row_count <= n && row_begin % 256 == 0);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
   if (n == 0) return 0;
   EGS_CHECK_ARG(pws && rots && scales && shs && alphas && Rcw && tcw && twc && depths && ws && dloss_dpws &&
@@ -801,17 +808,27 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
     set_error(EGS_ERR_WORKSPACE, "fused_backward workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
-  float* gpack = nullptr;
-  int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
-                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec);
-  if (rc) return rc;
+  float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));   // where splat_bwd_packed puts the records
+  if (phase != 2) {
+    int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
+                              patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec);
+    if (rc) return rc;
+    if (phase == 1) return 0;
+  }
+  if (row_count == 0) return 0;
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
-  dim3 g(div_up(n, 256)), b(256);
+  const int kh = sh_dim - 3;
+  const size_t r0 = (size_t)row_begin;
+  dim3 g(div_up(row_count, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
-#define EGS_PREB(NC, RAW)                                                                                       \
-  EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW>), g, b, s, n, pp, pws, rots, scales, shs, shs_high, \
-             alphas, Rcw, tcw, twc, depths, (const float4*)gpack, dloss_dpws, dloss_dshs, dloss_dshs_high,       \
-             dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus)
+  // row_begin is a multiple of the workgroup's 256 rows: every offset pointer keeps its 16-B alignment
+#define EGS_PREB(NC, RAW)                                                                                         \
+  EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW>), g, b, s, row_count, pp, pws + 3 * r0, rots + 4 * r0, \
+             scales + 3 * r0, shs + (RAW ? 3 : sh_dim) * r0, (RAW && shs_high) ? shs_high + kh * r0 : shs_high,    \
+             alphas + r0, Rcw, tcw, twc, depths + r0, (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0,           \
+             dloss_dshs + (RAW ? 3 : sh_dim) * r0,                                                                 \
+             (RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high, dloss_dalphas + r0,           \
+             dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0)
   switch (sh_dim * 2 + (raw ? 1 : 0)) {
     case 6: EGS_PREB(1, false); break;
     case 7: EGS_PREB(1, true); break;
@@ -836,11 +853,13 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
                                   const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                   const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                   float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                                  float* dloss_drots, float* dloss_dus, void* stream) {
+                                  float* dloss_drots, float* dloss_dus, int phase, int row_begin, int row_count,
+                                  void* stream) {
   return fused_backward_impl(false, n, sh_dim, patches, width, height, pws, rots, scales, shs, nullptr, alphas, Rcw,
                              tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths, contrib,
                              final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, dloss_dpws,
-                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, stream);
+                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, phase, row_begin,
+                             row_count, stream);
 }
 
 extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
@@ -854,10 +873,10 @@ extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int wi
                                       const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                       float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                                       float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
-                                      void* stream) {
+                                      int phase, int row_begin, int row_count, void* stream) {
   return fused_backward_impl(true, n, sh_dim, patches, width, height, pws, rots_raw, scales_raw, low_shs, high_shs,
                              alphas_raw, Rcw, tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths,
                              contrib, final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes,
                              dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
-                             dloss_drots_raw, dloss_dus, stream);
+                             dloss_drots_raw, dloss_dus, phase, row_begin, row_count, stream);
 }

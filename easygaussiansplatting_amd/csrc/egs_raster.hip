@@ -23,6 +23,14 @@
 
 #include <stdlib.h>
 
+// default dispatch order of the tiles for the forward / backward draw kernel (k_tile_order modes)
+#ifndef EGS_TILE_ORDER_F_DEFAULT
+#define EGS_TILE_ORDER_F_DEFAULT 0
+#endif
+#ifndef EGS_TILE_ORDER_B_DEFAULT
+#define EGS_TILE_ORDER_B_DEFAULT 0
+#endif
+
 namespace egs {
 
 // ============================================================================
@@ -423,6 +431,71 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
   if (p == P - 1) ranges[2 * (size_t)cur + 1] = (int32_t)P;
 }
 
+// Longest-list-first dispatch order of the tiles for the two draw kernels.  A tile is one wave whose run
+// time is proportional to its list length (0 ... ~2x the mean on the 1 M scene); workgroups are handed to
+// the SIMDs in index order, so with tiles in IMAGE order a launch ends with whichever SIMD drew the longest
+// lists while the others idle.  Sorted by length (descending) the long tiles start first and the short ones
+// fill the gaps (LPT scheduling); when every tile is resident at once (k_draw: 8 waves per SIMD) the
+// sorted order is dealt out in a serpentine of `period` slots so that every SIMD receives one tile of each
+// length stratum, alternately from its top and its bottom.
+//   mode 1: one global order           mode 2: global, serpentine
+//   mode 3: per XCD (tile row % 8 stays on XCD b % 8: horizontal neighbours share one L2), sorted
+//   mode 4: per XCD, serpentine
+// One workgroup: counting sort on (class, length / 4) in LDS -- 8160 tiles take a few microseconds.
+constexpr int TO_BINS = 1024;
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges, int T, int gx, int mode,
+                                                     int period, int32_t* __restrict__ order, int ngrid) {
+  __shared__ uint32_t bins[8 * TO_BINS];
+  __shared__ uint32_t wsum[16];
+  __shared__ uint32_t cbase[9];
+  const int tid = threadIdx.x;
+  const bool per_xcd = mode >= 3;
+  for (int i = tid; i < 8 * TO_BINS; i += 1024) bins[i] = 0u;
+  for (int i = tid; i < ngrid; i += 1024) order[i] = -1;
+  __syncthreads();
+  for (int t = tid; t < T; t += 1024) {
+    const int len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+    const int q = min(max(len, 0), 4 * TO_BINS - 1) >> 2;
+    const int cls = per_xcd ? ((t / gx) & 7) : 0;
+    atomicAdd(&bins[cls * TO_BINS + (TO_BINS - 1 - q)], 1u);
+  }
+  __syncthreads();
+  {  // exclusive scan of the 8192 bins: thread t owns bins [8 t, 8 t + 8)
+    uint32_t v[8], s = 0u;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { v[k] = bins[8 * tid + k]; s += v[k]; }
+    const uint32_t inc = wave_inclusive_scan(s);
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t pre = 0u;
+    for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+    uint32_t ex = pre + inc - s;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { bins[8 * tid + k] = ex; ex += v[k]; }
+  }
+  __syncthreads();
+  if (tid < 8) cbase[tid] = bins[tid * TO_BINS];
+  if (tid == 8) cbase[8] = (uint32_t)T;
+  __syncthreads();
+  const bool serp = (mode == 2 || mode == 4) && period > 0;
+  for (int t = tid; t < T; t += 1024) {
+    const int len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+    const int q = min(max(len, 0), 4 * TO_BINS - 1) >> 2;
+    const int cls = per_xcd ? ((t / gx) & 7) : 0;
+    const uint32_t pos = atomicAdd(&bins[cls * TO_BINS + (TO_BINS - 1 - q)], 1u);
+    int r = (int)(pos - cbase[cls]);
+    if (serp) {
+      const int cnt = (int)(cbase[cls + 1] - cbase[cls]);
+      const int st = r / period, ps = r - st * period;
+      if (st & 1) r = st * period + (min(period, cnt - st * period) - 1 - ps);
+    }
+    const int slot = per_xcd ? 8 * r + cls : r;
+    if (slot < ngrid) order[slot] = t;
+  }
+}
+// capacity of an order buffer: the per-XCD modes pad every class to the largest one
+static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
+
 // 48-byte packed 2D record per Gaussian: one aligned gather (3 x dwordx4)
 // instead of the reference's four (fetch2shared, kernel.cu:13-44).
 //   A = {u.x, u.y, qxx, qxy}   B = {qyy, alpha, col.r, col.g}   C = {col.b, c1, c2, thr}
@@ -463,12 +536,16 @@ struct DrawParams {
   float lskip;   // log2(alpha_skip), -inf when there is no skip test
   int maha_floor, alpha_clamp;
   int map_mode;  // 0: tile = block; 1: contiguous band per XCD; 2: tile rows interleaved over XCDs
+  // longest-list-first dispatch (k_tile_order): workgroup b draws tile order[b] (-1: padding) when set
+  const int32_t* order;
+  int ngrid;     // entries of `order` (= workgroups launched)
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
 // XCD a contiguous band of tiles so that its private 4-MiB L2 serves 1/8 of the
 // Gaussian records instead of all of them.  Bijective for any T.
 __device__ __forceinline__ int xcd_tile(int b, const DrawParams& p) {
+  if (p.order) return b < p.ngrid ? p.order[b] : -1;
   if (p.map_mode == 0) return b < p.T ? b : -1;
   const int xcd = b & 7, k = b >> 3;
   if (p.map_mode == 1) {
@@ -491,7 +568,10 @@ static size_t draw_lds_pad(int which) {
       [] { const char* e = getenv("EGS_DRAWB_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }()};
   return pad[which];
 }
-static int draw_grid(const DrawParams& p) { return p.map_mode == 2 ? 8 * div_up(p.gy, 8) * p.gx : p.T; }
+static int draw_grid(const DrawParams& p) {
+  if (p.order) return p.ngrid;
+  return p.map_mode == 2 ? 8 * div_up(p.gy, 8) * p.gx : p.T;
+}
 
 // Policy is compiled in (BOX: pixel-box footprint; FLOOR: max(0,m); CLAMP: min(0.99,.));
 // the two thresholds stay runtime scalars (SGPR operands of the compares).
@@ -599,11 +679,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   // alpha' >= alpha_skip (kernel.cu:246) in the exponent domain: e >= log2(skip), a kernel constant (SKIP =
   // the policy has a skip threshold, compiled in); without one only a NaN exponent fails the compare
   const float lthr = SKIP ? lskip : -INFINITY;
+  // the list value of the NEXT chunk is fetched one chunk ahead: the staging of a chunk then pays one global
+  // latency (the record gather), not two dependent ones
+  int gnext = (lane < n) ? gsid[r0 + lane] : 0;
   for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     int mymask = 0;   // reach mask of the entry THIS lane staged (lane j <-> entry base + j)
+    const int g = gnext;
+    if (base + 64 + lane < n) gnext = gsid[r0 + base + 64 + lane];
     if (base + lane < n) {
-      const int g = gsid[r0 + base + lane];
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
       // the record's thr = log2(skip / alpha), +inf for an entry that never blends (alpha < skip, or
       // alpha < 0 when there is no skip test): such an entry reaches nothing
@@ -811,6 +895,13 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
     maxcont = max(maxcont, bmax[k]);
   }
   if (maxcont <= 0) return;
+  // The loads above must be WAITED FOR here, not at their first use inside the loop: gfx9 counts stores and
+  // atomics in the same in-order vmcnt as loads, so a wait the compiler places at the first use (inside the
+  // hit body) would, from the second group on, also wait for the previous group's gradient atomics --
+  // a round trip to L2 per group of four entries on the critical path of the wave.
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+    asm volatile("" ::"v"(tau[k]), "v"(lr[k]), "v"(lg[k]), "v"(lb[k]), "v"(cont[k]));
   // where the transposing reduction leaves the nine totals inside a row of 16 lanes, and what each of
   // those lanes adds to the packed gradient record {dalpha, dcolor[3], du[2], dcinv[3]}
   const int c16 = lane & 15;
@@ -826,12 +917,15 @@ __global__ __launch_bounds__(64) void k_draw_bwd(DrawParams p, const int32_t* __
   else if (c16 == 12) { qoff = 6; kscale = -0.5f; }                     // M2xx -> dcinv.x
   else { qoff = 7; kscale = -1.f; }                                     // M2xy -> dcinv.y  (lane 14)
 
-  for (int c = (maxcont - 1) >> 6; c >= 0; --c) {
+  const int c_first = (maxcont - 1) >> 6;
+  int gnext = (c_first * 64 + lane < n) ? gsid[r0 + c_first * 64 + lane] : 0;   // one chunk ahead, as in k_draw
+  for (int c = c_first; c >= 0; --c) {
     __syncthreads();
     const int idx = c * 64 + lane;
     int mymask = 0;  // reach mask of the entry THIS lane staged (lane j <-> entry c*64 + j)
+    const int g = gnext;
+    if (c > 0) gnext = gsid[r0 + idx - 64];
     if (idx < n) {
-      const int g = gsid[r0 + idx];
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
       mymask = reach_mask<BOX>(A, C, tx0, ty0);
       sA[lane] = A;
@@ -1010,19 +1104,22 @@ static int tile_bits(int T) {
 struct DrawLayout {
   uint32_t *tkeys, *tkeys_alt, *gsid_alt;
   float4* rec;
+  int32_t* order;   // dispatch order of the tiles (k_tile_order)
   SortWs sort;
 };
-static size_t draw_ws_bytes(int n, int64_t P) {
+static size_t draw_ws_bytes(int n, int64_t P, int width, int height) {
   const size_t N = (size_t)(n > 0 ? n : 1), PP = (size_t)(P > 0 ? P : 1);
-  return 3 * align_up(PP * 4, 256) + align_up(N * 48, 256) + sort_ws_bytes(P) + 4096;
+  const size_t ord = (size_t)tile_order_len(div_up(width, EGS_TILE), div_up(height, EGS_TILE));
+  return 3 * align_up(PP * 4, 256) + align_up(N * 48, 256) + align_up(ord * 4, 256) + sort_ws_bytes(P) + 4096;
 }
-static bool draw_carve(void* ws, size_t bytes, int n, int64_t P, DrawLayout* L) {
+static bool draw_carve(void* ws, size_t bytes, int n, int64_t P, int width, int height, DrawLayout* L) {
   Carver cv(ws, bytes);
   const size_t N = (size_t)(n > 0 ? n : 1), PP = (size_t)(P > 0 ? P : 1);
   L->tkeys = cv.take<uint32_t>(PP);
   L->tkeys_alt = cv.take<uint32_t>(PP);
   L->gsid_alt = cv.take<uint32_t>(PP);
   L->rec = cv.take<float4>(3 * N);
+  L->order = cv.take<int32_t>((size_t)tile_order_len(div_up(width, EGS_TILE), div_up(height, EGS_TILE)));
   return sort_ws_carve(cv, P, &L->sort) && cv.ok();
 }
 
@@ -1040,10 +1137,37 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
     return e ? atoi(e) : -1;
   }();
   p.map_mode = forced >= 0 ? forced : (backward ? 0 : 2);
+  p.order = nullptr;
+  p.ngrid = 0;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
   return p;
+}
+
+// Longest-list-first dispatch (k_tile_order) for one of the draw kernels: which = 0 forward, 1 backward.
+// Mode by measurement (same-box A/B at 1 M / 1080p); EGS_TILE_ORDER_F / _B = 0..4 and
+// EGS_TILE_SERP override (tuning knobs).
+static int tile_order_mode(int which) {
+  static const int mode[2] = {
+      [] { const char* e = getenv("EGS_TILE_ORDER_F"); return e ? atoi(e) : EGS_TILE_ORDER_F_DEFAULT; }(),
+      [] { const char* e = getenv("EGS_TILE_ORDER_B"); return e ? atoi(e) : EGS_TILE_ORDER_B_DEFAULT; }()};
+  return mode[which];
+}
+static int tile_order_enqueue(DrawParams& p, int which, int32_t* buf, size_t buf_len,
+                              const int32_t* ranges, hipStream_t s) {
+  const int mode = tile_order_mode(which);
+  if (mode <= 0 || !buf) return 0;
+  const bool per_xcd = mode >= 3;
+  const int ngrid = per_xcd ? tile_order_len(p.gx, p.gy) : p.T;
+  if ((size_t)ngrid > buf_len) return 0;     // (images beyond the workspace bound keep the plain map)
+  static const int serp = [] { const char* e = getenv("EGS_TILE_SERP"); return e ? atoi(e) : 0; }();
+  const int period = serp > 0 ? serp : (per_xcd ? 128 : 1024);   // SIMDs per XCD / per chip
+  EGS_LAUNCH("k_tile_order", k_tile_order, dim3(1), dim3(1024), s, ranges, p.T, p.gx, mode, period, buf, ngrid);
+  EGS_LAUNCH_OK();
+  p.order = buf;
+  p.ngrid = ngrid;
+  return 0;
 }
 
 }  // namespace egs
@@ -1086,8 +1210,7 @@ extern "C" int egs_exclusive_scan_u32(int64_t n, const uint32_t* in, const uint3
 
 extern "C" size_t egs_splat_bin_ws_bytes(int n) { return bin_ws_bytes(n); }
 extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height) {
-  (void)width; (void)height;
-  return draw_ws_bytes(n, patches);
+  return draw_ws_bytes(n, patches, width, height);
 }
 
 extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas, float* depths,
@@ -1166,7 +1289,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   EGS_CHECK_ARG(n >= 0 && patches >= 0 && patches < (int64_t)0x7FFFFFFF && width > 0 && height > 0 && pol);
   EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
   hipStream_t s = (hipStream_t)stream;
-  const DrawParams dp = make_draw_params(width, height, pol);
+  DrawParams dp = make_draw_params(width, height, pol);
   if (n == 0 || patches == 0) {  // nothing to draw: all outputs are zero
     const size_t hw = (size_t)width * height;
     EGS_HIP(hipMemsetAsync(patch_range_per_tile, 0, (size_t)dp.T * 8, s));
@@ -1180,7 +1303,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   BinLayout B;
   if (!bin_carve(const_cast<void*>(ws_bin), bin_ws_bytes(n), n, &B)) return EGS_ERR_WORKSPACE;
   DrawLayout D;
-  if (!draw_carve(ws_draw, ws_draw_bytes, n, patches, &D)) {
+  if (!draw_carve(ws_draw, ws_draw_bytes, n, patches, width, height, &D)) {
     set_error(EGS_ERR_WORKSPACE, "draw workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
@@ -1203,6 +1326,8 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   if (rc) return rc;
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile, patches_dev);
+  rc = tile_order_enqueue(dp, 0, D.order, (size_t)tile_order_len(dp.gx, dp.gy), patch_range_per_tile, s);
+  if (rc) return rc;
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                         \
   do {                                                                                                      \
@@ -1268,7 +1393,11 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                          patch_range_per_tile, gsid_per_patch, stream, total_patches);
 }
 
-extern "C" size_t egs_splat_bwd_ws_bytes(int n) { return 2 * align_up((size_t)(n > 0 ? n : 1) * 48, 256) + 256; }
+// [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]
+constexpr size_t BWD_ORDER_CAP = (size_t)1 << 18;   // tiles: up to 8192 x 8192 pixels
+extern "C" size_t egs_splat_bwd_ws_bytes(int n) {
+  return 2 * align_up((size_t)(n > 0 ? n : 1) * 48, 256) + BWD_ORDER_CAP * 4 + 256;
+}
 
 namespace egs {
 int splat_bwd_packed(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
@@ -1286,10 +1415,15 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   EGS_CHECK_ARG(contrib && final_tau && patch_range_per_tile && gsid_per_patch && dloss_dgammas);
   EGS_CHECK_ARG(rec_in || (us && cinv2ds && alphas && colors && (areas || pol->footprint != 1)));
   EGS_CHECK_ARG(rec_in || (us && alphas && colors && (pol->footprint == 0 || areas)));
-  const DrawParams dp = make_draw_params(width, height, pol, true);
+  DrawParams dp = make_draw_params(width, height, pol, true);
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
+  {
+    int32_t* order = (int32_t*)((char*)ws + 2 * align_up((size_t)n * 48, 256));
+    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s);
+    if (rc) return rc;
+  }
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP>), dim3(draw_grid(dp)), dim3(64), draw_lds_pad(1), s, \
                  dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, gpack)

@@ -82,6 +82,75 @@ def flat_grad_buffer(tensors):
     return torch.empty(0, dtype=torch.float32, device=grads[0].device).set_(st, 0, (total,))
 
 
+class ChunkedExchange:
+    """Gradient exchange overlapped with the tail of the backward pass ("overlap the all-reduce of
+    early buckets with the tail of backward").
+
+    While attached, ``fused.backward`` computes the per-Gaussian chain rule in ``chunks`` row chunks and calls
+    ``on_chunk`` with the gradient slices of each chunk right after enqueueing its kernel; the slices are
+    all-reduced (SUM) on a side stream that waits for exactly that kernel, so chunk k travels over xGMI while
+    chunk k + 1 is computed -- with 4 chunks three quarters of the 236 MB are on their way before the backward
+    pass ends.  ``finish()`` makes the caller's stream wait for the exchange and turns the sums into means.
+    One collective per chunk (its five or six slices as one coalesced RCCL group call).  Every rank must
+    attach for the same backward passes (the collectives have to match)."""
+
+    def __init__(self, world=None, group=None, chunks=4):
+        self.group = group
+        self.world = _world(group) if world is None else world
+        self.chunks = chunks
+        self.side = None
+        self.works, self.tensors = [], []
+        self.used = False
+
+    def attach(self):
+        import contextlib
+        from . import fused
+
+        @contextlib.contextmanager
+        def cm():
+            prev, fused._exchange_hook = fused._exchange_hook, self
+            try:
+                yield self
+            finally:
+                fused._exchange_hook = prev
+        return cm()
+
+    def on_chunk(self, tensors):
+        tensors = [t for t in tensors if t is not None and t.numel() > 0]
+        if not tensors or not (dist.is_available() and dist.is_initialized()):
+            return
+        if self.side is None:
+            self.side = torch.cuda.Stream(device=tensors[0].device)
+        ev = torch.cuda.Event()
+        ev.record()                              # behind the kernel that produced this chunk
+        self.side.wait_event(ev)
+        with torch.cuda.stream(self.side):
+            for t in tensors:
+                t.record_stream(self.side)
+            try:
+                w = dist.all_reduce_coalesced(tensors, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                self.works.append(w)
+            except (RuntimeError, NotImplementedError, AttributeError):
+                self.works += [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                               for t in tensors]
+        self.tensors += tensors
+        self.used = True
+
+    def finish(self) -> bool:
+        """Wait (stream-wise) for everything handed over since the last call; False when nothing was."""
+        if not self.works:
+            return False
+        with torch.cuda.stream(self.side):
+            for w in self.works:
+                if w is not None:
+                    w.wait()
+            if self.world > 1:
+                torch._foreach_div_(self.tensors, float(self.world))
+        torch.cuda.current_stream().wait_stream(self.side)
+        self.works, self.tensors = [], []
+        return True
+
+
 def coalesce_grads(tensors: Sequence[torch.Tensor]) -> List[torch.Tensor]:
     """``[flat]`` when the gradients of ``tensors`` are slices of one buffer (the fused backward allocates
     them that way: one 236-MB collective instead of five or six latency-bound ones), else the gradients."""

@@ -80,7 +80,6 @@ class GSFunction(torch.autograd.Function):
             pws, shs, alphas, scales, rots = ctx.saved_tensors
             dpws, dshs, dalphas, dscales, drots, dus = _fused.backward(
                 pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous())
-            ctx.state = None
             return dpws, dshs, dalphas, dscales, drots, dus, None
         (us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
          dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs,
@@ -129,7 +128,6 @@ class GSRawFunction(torch.autograd.Function):
         dpws, dlow, dhigh, dalphas, dscales, drots, dus = _fused.backward(
             pws, low_shs, alphas_raw, scales_raw, rots_raw, ctx.cam, ctx.state, dloss_dgammas.contiguous(),
             high_shs=high_shs)
-        ctx.state = None
         return dpws, dlow, dhigh, dalphas, dscales, drots, dus, None
 
 

@@ -14,8 +14,10 @@ Results equal the seven-op path (same device functions, csrc/egs_gaussian_math.h
 """
 from __future__ import annotations
 
+import collections
 import ctypes as C
 import os
+import threading
 
 import torch
 
@@ -26,14 +28,147 @@ from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _
 
 
 ENQUEUE_AHEAD = os.environ.get("EGS_ENQUEUE_AHEAD", "1") != "0"   # knob for A/B measurements and tests
-_patch_capacity = {}     # (N, W, H) -> patch-list allocation size learnt from earlier calls
-_mailbox = {}            # device index -> page-locked int32[2]: landing zone of {P, max depth key}
+MAILBOX_SLOTS = 64
 
 
 class FusedState:
-    """Tensors the backward pass needs (all produced by ``forward``)."""
+    """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
+    patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "width", "height")
+                 "width", "height", "ticket", "_patches")
+
+    def patch_count(self) -> int:
+        """P of this render (waits for its read-back if it has not been looked at yet)."""
+        if self.ticket is not None:
+            _settle(self.ticket, True)
+        return self._patches
+
+
+class _Ticket:
+    """One enqueue-ahead render whose {P, max depth key} read-back is still in flight."""
+    __slots__ = ("ctx", "slot", "key", "cap", "hint", "state", "status", "patches", "need", "collected")
+    PENDING, OK, FAILED = 0, 1, 2
+
+
+class _DeviceCtx:
+    """Per-device host state of the fused path: the mailbox, what was learnt about each problem size
+    (patch-list capacity, significant depth-key bits) and the renders awaiting validation.  Nothing here
+    is shared between devices; access is serialised by ``lock`` (autograd runs backward on its own thread)."""
+
+    def __init__(self, lib, index):
+        self.index = index
+        self.lib = lib
+        self.mb = lib.egs_mailbox_create(MAILBOX_SLOTS)
+        if not self.mb:
+            raise RuntimeError("egs_mailbox_create failed (page-locked host memory)")
+        self.free = list(range(MAILBOX_SLOTS))
+        self.pending = collections.deque()
+        self.failed = []
+        self.capacity = {}      # (N, W, H) -> patch-list allocation size learnt from earlier renders
+        self.lock = threading.RLock()
+
+
+_contexts = {}
+_tls = threading.local()
+_exchange_hook = None    # dist_views.ChunkedExchange while attached (process-wide: backward runs on autograd's thread)
+
+
+def _ctx(dev) -> _DeviceCtx:
+    c = _contexts.get(dev.index)
+    if c is None:
+        c = _contexts.setdefault(dev.index, _DeviceCtx(_lib.load(), dev.index))
+    return c
+
+
+def _grow(p):
+    return p + p // 16 + 4096
+
+
+def _settle(t: _Ticket, blocking: bool) -> bool:
+    """Look at the read-back of one render: True once it has been validated (either way)."""
+    ctx = t.ctx
+    with ctx.lock:
+        if t.status != _Ticket.PENDING:
+            return True
+        out = (C.c_uint32 * 2)()
+    rc = ctx.lib.egs_mailbox_fetch(ctx.mb, t.slot, 1 if blocking else 0, out)   # (the wait holds no lock, no GIL)
+    if rc == 0:
+        return False
+    if rc < 0:
+        _lib.check(-rc)
+    with ctx.lock:
+        if t.status != _Ticket.PENDING:
+            return True
+        t.patches, mk = int(out[0]), int(out[1])
+        t.need = mk.bit_length()
+        ctx.free.append(t.slot)
+        try:
+            ctx.pending.remove(t)
+        except ValueError:
+            pass
+        ok = t.patches <= t.cap and not (t.hint < 32 and t.need > t.hint) and t.patches < 2**31
+        # what the next render of this size starts from
+        _gsc._set_key_bits(ctx.index, t.key, 32 if (t.hint < 32 and t.need > t.hint) else min(32, t.need + 1))
+        ctx.capacity[t.key] = max(ctx.capacity.get(t.key, 0), _grow(min(t.patches, 2**31 - 1)))
+        t.status = _Ticket.OK if ok else _Ticket.FAILED
+        S = t.state
+        if S is not None:
+            S._patches = t.patches
+            S.ticket = None
+            if ok:
+                S.gsid = S.gsid[:t.patches]
+        if not ok and not t.collected:
+            ctx.failed.append(t)
+    return True
+
+
+class deferred:
+    """``with fused.deferred() as d: ...; bad = d.commit()`` -- renders inside the block are NOT validated
+    when ``forward`` returns: the host never waits for the 8-byte read-back of the patch count inside a
+    step and can run a whole step ahead of the GPU.  ``commit()`` validates everything rendered so far
+    (it waits for the binning stage of the last render, not for its draw or backward kernels) and returns the
+    ``FusedState`` objects whose patch list outgrew the enqueue-ahead capacity or whose depth keys outgrew the
+    sort's bit hint: their images and gradients are INCOMPLETE and must be recomputed before anything
+    consumes them (the learnt capacity / hint are already raised, so recomputing succeeds).  Leaving the
+    block with such a failure uncollected raises."""
+
+    def __enter__(self):
+        self._prev = getattr(_tls, "deferred", False)
+        _tls.deferred = True
+        return self
+
+    def commit(self):
+        return commit()
+
+    def __exit__(self, et, ev, tb):
+        _tls.deferred = self._prev
+        if et is None and not self._prev:
+            bad = commit()
+            if bad:
+                raise RuntimeError("%d enqueue-ahead render(s) were incomplete (patch capacity or depth-key hint "
+                                   "exceeded) and nobody collected them with commit(): their results must not be used"
+                                   % len(bad))
+        return False
+
+
+def commit(device=None):
+    """Validate every render of ``device`` (default: the current one) that is still awaiting its read-back;
+    -> list of the FusedState objects that turned out incomplete since the last commit."""
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    ctx = _contexts.get(index)
+    if ctx is None:
+        return []
+    while True:
+        with ctx.lock:
+            t = ctx.pending[0] if ctx.pending else None
+        if t is None:
+            break
+        _settle(t, True)
+    with ctx.lock:
+        bad, ctx.failed = ctx.failed, []
+    for t in bad:
+        t.collected = True
+    return [t.state for t in bad]
 
 
 def _split_sh(low_shs, high_shs, n):
@@ -75,6 +210,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
     f32, i32 = torch.float32, torch.int32
     S = FusedState()
     S.width, S.height = W, H
+    S.ticket, S._patches = None, None
     # the draw kernels (forward and backward) work from the packed records alone: us / cinv2ds / colors /
     # areas are not materialised
     S.us = S.cinv2ds = S.colors = S.areas = None
@@ -106,52 +242,68 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward(
             n, K, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *tail(hint, total)))
 
-    cap = _patch_capacity.get((n, W, H), 0) if ENQUEUE_AHEAD else 0
-    if cap == 0 or n == 0:
-        patches = _bin_stage(enqueue_bin)            # first call for this size: synchronous read-back of P
+    ctx = _ctx(dev)
+    key = (n, W, H)
+    S.ticket = None
+    cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
+
+    def render_exact():
+        """Synchronous form: read P back (8 bytes, as the reference does at gausplat.cu:67), then draw."""
+        patches = _bin_stage(enqueue_bin, dev, key)
         draw_exact(patches)
-    else:
-        # The draw stage is enqueued AHEAD of the read-back: buffers sized by the largest patch count seen so
-        # far, the kernels take the real count from device memory, and {P, max depth key} travel to a
-        # page-locked mailbox by a copy enqueued between the two stages.  The host then only polls that
-        # mailbox -- the GPU never waits for it (the reference, like the seven-op path, idles around
-        # cudaMemcpy(&P), gausplat.cu:67).  An overflow of the capacity or of the depth-key hint is detected
-        # here, after the fact, and the affected stage is redone.
-        if dev.index not in _mailbox:
-            _mailbox[dev.index] = torch.zeros(2, dtype=torch.int32).pin_memory()
-        box = _mailbox[dev.index]
-        box.fill_(-1)                                 # sentinels: neither P nor a depth key is ever 0xFFFFFFFF
-        total = torch.empty(2, dtype=i32, device=dev)
-        hint = _gsc._key_bits_hint
-        enqueue_bin(hint, total)
-        gsid_full = torch.empty(cap, dtype=i32, device=dev)
-        ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), C.c_void_p(box.data_ptr()), W, H, _ptr(S.rec), pol,
-                                              _ptr(ws_bin), _ptr(ws_draw), ws_draw.numel(), _ptr(image),
-                                              _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full),
-                                              st))
-        spins = 0
-        while int(box[0]) == -1 or int(box[1]) == -1:  # arrives ~0.2 ms before the draw stage finishes
-            spins += 1
-            if spins > 200000:                        # (never observed) fall back to a real synchronisation
-                torch.cuda.current_stream().synchronize()
+        S._patches = patches
+        if n > 0:
+            with ctx.lock:
+                ctx.capacity[key] = max(ctx.capacity.get(key, 0), _grow(patches))
+
+    if cap == 0 or n == 0:
+        render_exact()                               # first render of this size
+        return image, mask, S
+    # The draw stage is enqueued AHEAD of the read-back: buffers sized by the largest patch count seen so
+    # far, the kernels take the real count from device memory, and {P, max depth key} travel to a page-locked
+    # mailbox slot by a copy enqueued between the two stages (egs_mailbox_post).  The GPU never waits for the
+    # host (the reference, like the seven-op path, idles around cudaMemcpy(&P), gausplat.cu:67).  An overflow
+    # of the capacity or of the depth-key hint is detected after the fact -- here (one C-side wait on the
+    # slot's event) or, inside a ``deferred()`` block, at ``commit()`` -- and the render is redone.
+    t = _Ticket()
+    t.ctx, t.key, t.cap, t.state, t.status, t.collected = ctx, key, cap, S, _Ticket.PENDING, False
+    t.hint = _gsc._get_key_bits(dev.index, key)
+    while True:
+        with ctx.lock:
+            if ctx.free:
+                t.slot = ctx.free.pop()
                 break
-        patches, mk = int(box[0]) & 0xFFFFFFFF, int(box[1]) & 0xFFFFFFFF
-        need = mk.bit_length()
-        if patches >= 2**31:
-            raise RuntimeError("splat: %d tile patches overflow int32 indexing" % patches)
-        if hint < 32 and need > hint:                 # stale depth-key hint: everything again, full key width
-            _gsc._key_bits_hint = 32
-            patches = _bin_stage(enqueue_bin)
-            draw_exact(patches)
-        else:
-            _gsc._key_bits_hint = min(32, need + 1)
-            if patches > cap:                         # more patches than ever before: redo the draw stage
-                draw_exact(patches)
-            else:
-                S.gsid = gsid_full[:patches]
-    if n > 0:
-        _patch_capacity[(n, W, H)] = max(_patch_capacity.get((n, W, H), 0), patches + patches // 32 + 4096)
+            oldest = ctx.pending[0]
+        _settle(oldest, True)                         # every slot in flight: wait for the oldest render
+    total = torch.empty(2, dtype=i32, device=dev)
+    enqueue_bin(t.hint, total)
+    _lib.check(lib.egs_mailbox_post(ctx.mb, t.slot, _ptr(total), st))
+    gsid_full = torch.empty(cap, dtype=i32, device=dev)
+    ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
+    _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
+                                          _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
+                                          _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), st))
+    S.gsid = gsid_full                                # entries past P are unused (the kernels walk `ranges`)
+    S._patches = None
+    S.ticket = t
+    with ctx.lock:
+        ctx.pending.append(t)
+    if getattr(_tls, "deferred", False):
+        with ctx.lock:                                # look at whatever has landed meanwhile (no waiting)
+            waiting = list(ctx.pending)
+        for old in waiting:
+            if old is not t and not _settle(old, False):
+                break
+        return image, mask, S
+    t.collected = True                                # validated right here: never reported by commit()
+    _settle(t, True)
+    if t.status == _Ticket.FAILED:
+        if t.patches >= 2**31:
+            raise RuntimeError("splat: %d tile patches overflow int32 indexing" % t.patches)
+        if t.hint < 32 and t.need > t.hint:           # stale depth-key hint: everything again
+            render_exact()
+        else:                                         # more patches than ever before: redo the draw stage
+            draw_exact(t.patches)
     return image, mask, S
 
 
@@ -199,11 +351,30 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
            float(cam.cy), C.byref(_pol()), _ptr(S.us), _ptr(S.cinv2ds), _ptr(S.colors), _ptr(S.areas), _ptr(S.rec),
            _ptr(S.depths), _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), _ptr(dl), _ptr(ws),
            ws_bytes, _ptr(dpws), _ptr(dshs))
+    st = _stream()
     if raw:
-        _lib.check(lib.egs_fused_backward_raw(n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales),
-                                              _ptr(shs), _ptr(high_shs), *mid, _ptr(dhigh), _ptr(dalphas),
-                                              _ptr(dscales), _ptr(drots), _ptr(dus), _stream()))
+        launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward_raw(
+            n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *mid,
+            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), phase, b, c, st))
+    else:
+        launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward(
+            n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *mid, _ptr(dalphas),
+            _ptr(dscales), _ptr(drots), _ptr(dus), phase, b, c, st))
+    hook = _exchange_hook
+    chunks = hook.chunks if hook is not None else 1
+    rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups
+    if hook is None or chunks <= 1 or rows >= n:
+        launch(0, 0, n)
+        if hook is not None:
+            hook.on_chunk(parts)
+    else:
+        # The chain rule runs in a few row chunks; each chunk's gradient slices go to the exchange as soon as
+        # its kernel is enqueued, so the all-reduce of chunk k overlaps the computation of chunk k + 1
+        launch(1, 0, 0)
+        for b in range(0, n, rows):
+            c = min(rows, n - b)
+            launch(2, b, c)
+            hook.on_chunk([p[b:b + c] for p in parts])
+    if raw:
         return dpws, dshs, dhigh, dalphas, dscales, drots, dus
-    _lib.check(lib.egs_fused_backward(n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs),
-                                      *mid, _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _stream()))
     return dpws, dshs, dalphas, dscales, drots, dus

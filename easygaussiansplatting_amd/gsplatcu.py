@@ -190,19 +190,27 @@ def inverseCov2D(cov2ds, depths, calc_J):
     return [cinv, areas, J] if calc_J else [cinv, areas]
 
 
-_key_bits_hint = 32   # learned from the previous call (depth keys rarely need more than 16 bits)
+_key_bits = {}   # (device index, problem key) -> significant depth-key bits learnt from the previous call
 
 
-def _bin_stage(enqueue, while_waiting=None):
+def _get_key_bits(dev_index, key=None) -> int:
+    return _key_bits.get((dev_index, key), 32)
+
+
+def _set_key_bits(dev_index, key, bits) -> None:
+    _key_bits[(dev_index, key)] = int(bits)
+
+
+def _bin_stage(enqueue, device, key=None, while_waiting=None):
     """Run the binning stage with the depth-key bit-count hint protocol of egs_splat_bin:
     ``enqueue(hint, total)`` enqueues the stage; returns the patch count P.  The single
     8-byte read-back (reference: gausplat.cu:67) also brings the largest depth key, which
-    sizes the next call's sort; a too-small hint triggers one full-width re-run.
+    sizes the next call's sort (depth keys rarely need more than 16 of their 32 bits; the hint is kept
+    per device and problem ``key``); a too-small hint triggers one full-width re-run.
     ``while_waiting()`` runs between the enqueue and the blocking read: host work that does not need
     P (output allocations) belongs there, so that the GPU idles as briefly as possible afterwards."""
-    global _key_bits_hint
-    total = torch.empty(2, dtype=torch.int32, device="cuda")
-    hint = _key_bits_hint
+    total = torch.empty(2, dtype=torch.int32, device=device)
+    hint = _get_key_bits(device.index, key)
     enqueue(hint, total)
     if while_waiting is not None:
         while_waiting()
@@ -211,7 +219,7 @@ def _bin_stage(enqueue, while_waiting=None):
     if hint < 32 and need > hint:
         enqueue(32, total)
         p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
-    _key_bits_hint = min(32, need + 1)
+    _set_key_bits(device.index, key, min(32, need + 1))
     if p >= 2**31:
         raise RuntimeError("splat: %d tile patches overflow int32 indexing" % p)
     return p
@@ -254,7 +262,7 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     st = _stream()
     patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_splat_bin(
         n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
-        _ptr(total), st)))
+        _ptr(total), st)), dev, (n, width, height))
     gsid = torch.empty(patches, dtype=torch.int32, device=dev)
     ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
     ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)

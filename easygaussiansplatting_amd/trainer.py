@@ -30,6 +30,7 @@ import torch
 import torch.distributed as dist
 
 from . import dist_views as DV
+from . import fused as _fused
 from .density import DensityControl, expon_lr
 from .function import Camera, GSFunction, GSRawFunction
 from .loss import gau_loss
@@ -89,11 +90,10 @@ class Trainer:
         n = self.params["pws"].shape[0]
         self.grad_accum = torch.zeros(n, device=device)             # gsmodel.py:214-230 statistics
         self.vis_count = torch.zeros(n, dtype=torch.int32, device=device)
+        self.redone_steps = 0        # steps rendered twice because a view outgrew the enqueue-ahead buffers
 
-    def step(self, view_ids: Sequence[int]) -> float:
-        """One optimizer step on the mean gradient over ``view_ids`` (all ranks pass the same list)."""
-        mine = [view_ids[i] for i in DV.views_for_rank(len(view_ids), self.rank, self.world)]
-        self.opt.zero_grad(set_to_none=True)
+    def _render_views(self, mine, n_views):
+        """forward + loss + backward of this rank's views; leaves accumulate the mean over ALL views of the step."""
         n = self.params["pws"].shape[0]
         loss_sum = torch.zeros((), device=self.device)
         gnorm = torch.zeros(n, device=self.device)
@@ -107,12 +107,37 @@ class Trainer:
             else:
                 image, mask = GSFunction.apply(*activate(self.params), us, self.cams[v])
             loss = gau_loss(image, self.gts[v])
-            (loss / len(view_ids)).backward()           # leaves accumulate the mean over ALL views of the step
+            (loss / n_views).backward()
             loss_sum += loss.detach()
             with torch.no_grad():                       # per-view ||dL/du|| (undo the 1/len scaling)
-                g = torch.norm(us.grad * len(view_ids), dim=-1)
+                g = torch.norm(us.grad * n_views, dim=-1)
                 gnorm += torch.where(mask, g, torch.zeros_like(g))
                 count += mask.to(torch.int32)
+        return loss_sum, gnorm, count
+
+    def step(self, view_ids: Sequence[int], sync: bool = True):
+        """One optimizer step on the mean gradient over ``view_ids`` (all ranks pass the same list, which must
+        give every rank at least one view: a rank without a view would have no gradient to contribute and
+        its peers would wait in the all-reduce for ever).  Returns the mean loss: a float (``sync=True``: the
+        ``loss.item()`` of train.py:58, one host-device synchronisation per step) or, with ``sync=False``, a
+        0-dim device tensor -- the host then never waits for the GPU inside the step (``fit`` uses this and
+        reads the losses once per epoch)."""
+        if len(view_ids) < self.world:
+            raise ValueError("step() got %d view(s) for %d ranks: every rank needs at least one view per step"
+                             % (len(view_ids), self.world))
+        mine = [view_ids[i] for i in DV.views_for_rank(len(view_ids), self.rank, self.world)]
+        self.opt.zero_grad(set_to_none=True)
+        # The views are rendered with deferred validation: the host does not wait for a patch count inside the
+        # step.  commit() (one wait for the binning stage of the last view, while its draw and backward
+        # kernels are still queued) tells whether some view outgrew the buffers sized from earlier renders;
+        # that happens while the trainer still meets new views, and the step is then redone exactly.
+        with _fused.deferred() as d:
+            loss_sum, gnorm, count = self._render_views(mine, len(view_ids))
+            incomplete = d.commit()
+        if incomplete:
+            self.redone_steps += 1
+            self.opt.zero_grad(set_to_none=True)
+            loss_sum, gnorm, count = self._render_views(mine, len(view_ids))   # validated render by render
         if self.world > 1:   # sum over ranks of (sum over local views)/V == mean over all views
             DV.allreduce_sum_(DV.coalesce_grads(list(self.params.values())) + [gnorm, count, loss_sum])
         self.grad_accum += gnorm
@@ -120,7 +145,8 @@ class Trainer:
         self.opt.step()
         self.density.update_pws_lr(self.opt)                                     # gsmodel.py:180-183, 332-338
         self.iteration += 1
-        return float(loss_sum) / len(view_ids)
+        mean = loss_sum / len(view_ids)
+        return float(mean) if sync else mean
 
     def densify(self, verbose: bool = False):
         """Prune / clone / split on the statistics gathered since the last call (train.py:71-73 ->
@@ -141,15 +167,24 @@ class Trainer:
         """The epoch loop of train.py:44-80: shuffled views, ``views_per_step`` views per optimizer step
         (1 in the reference), densification every 5th and alpha reset every 15th epoch in (1, 50]."""
         vps = views_per_step or self.world
+        if vps < self.world or len(self.cams) < self.world:
+            raise ValueError("views_per_step=%d, %d cameras: every one of the %d ranks needs a view in each step"
+                             % (vps, len(self.cams), self.world))
         order_rng = np.random.default_rng(rng_seed)            # same permutation on every rank
         history = []
         for epoch in range(epochs):
             idxs = order_rng.permutation(len(self.cams))
-            total, steps = 0.0, 0
-            for i in range(0, len(idxs) - vps + 1, vps):
-                total += self.step([int(v) for v in idxs[i:i + vps]])
+            total, steps = torch.zeros((), device=self.device), 0
+            # every view is visited each epoch (train.py:48): the last step of an epoch takes the remaining
+            # views when they still give every rank one, otherwise they join the step before it
+            cuts = list(range(0, len(idxs), vps))
+            if len(cuts) > 1 and len(idxs) - cuts[-1] < self.world:
+                cuts.pop()
+            for j, i in enumerate(cuts):
+                end = cuts[j + 1] if j + 1 < len(cuts) else len(idxs)
+                total += self.step([int(v) for v in idxs[i:end]], sync=False)
                 steps += 1
-            history.append(total / max(steps, 1))
+            history.append(float(total) / max(steps, 1))
             if verbose and self.rank == 0:
                 print("epoch:%d avg_loss:%f" % (epoch, history[-1]))
             if 1 < epoch <= densify_until:

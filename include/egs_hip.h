@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 1
+#define EGS_ABI_VERSION 2
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -206,7 +206,24 @@ int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_
                            int width, int height, const void* rec, const EgsPolicy* pol, const void* ws_bin,
                            void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                            int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream);
+/* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
+ * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
+int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
+/* Mailbox for that read-back: `slots` page-locked landing zones, each with a HIP event.  egs_mailbox_post
+ * enqueues the asynchronous 8-byte copy of total_patches[0..1] into a slot on `stream` and records the
+ * slot's event behind it; egs_mailbox_fetch returns 1 and the two words once the copy has landed, 0 when it
+ * has not (blocking == 0), or waits for it on the slot's event (blocking != 0): ONE C-side wait where the
+ * reference blocks in cudaMemcpy (gausplat.cu:67); a negative value is -(error code).  A slot may be re-posted
+ * after it was fetched. */
+void* egs_mailbox_create(int slots);
+void egs_mailbox_destroy(void* mailbox);
+int egs_mailbox_post(void* mailbox, int slot, const uint32_t* total_patches, void* stream);
+int egs_mailbox_fetch(void* mailbox, int slot, int blocking, uint32_t* out2);
 size_t egs_fused_backward_ws_bytes(int n);
+/* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
+ * phase 2: only the per-Gaussian chain rule for rows [row_begin, row_begin + row_count), row_begin a multiple
+ * of 256, reading the records phase 1 left in the SAME ws: a data-parallel caller launches the rows in a few
+ * chunks and hands each chunk's gradients to RCCL while the next chunk is computed (dist_views.ChunkedExchange). */
 int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
                        const float* rots, const float* scales, const float* shs, const float* alphas,
                        const float* Rcw, const float* tcw, const float* twc, float fx, float fy, float cx,
@@ -216,7 +233,7 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                        const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                       float* dloss_drots, float* dloss_dus, void* stream);
+                       float* dloss_drots, float* dloss_dus, int phase, int row_begin, int row_count, void* stream);
 
 /* The same pair on the OPTIMIZER's tensors (gsplat/gsmodel.py:96-129: alphas_raw, scales_raw, rots_raw,
  * low_shs [N,3], high_shs [N,sh_dim-3]): the activations of gsplat/utils.py:121-150 (sigmoid, exp,
@@ -238,7 +255,8 @@ int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int he
                            const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                            const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                            float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
-                           float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus, void* stream);
+                           float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus, int phase,
+                           int row_begin, int row_count, void* stream);
 
 /* ---- fused training loss -----------------------------------------
  * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the

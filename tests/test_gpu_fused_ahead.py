@@ -30,26 +30,27 @@ def test_ahead_equals_exact_and_survives_overflow(policy):
     try:
         args, cam = _scene(6000, 200, 120, 3)
         key = (6000, 200, 120)
-        fused._patch_capacity.pop(key, None)
+        cap = fused._ctx(torch.device("cuda", 0)).capacity
+        cap.pop(key, None)
         ref = _run(args, cam)                               # no capacity yet: synchronous read-back
-        assert fused._patch_capacity[key] > ref[3].shape[0] > 1000
+        assert cap[key] > ref[3].shape[0] > 1000
         got = _run(args, cam)                               # enqueued ahead
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b)
-        fused._patch_capacity[key] = 64                     # far too small: nothing out of bounds, draw redone
+        cap[key] = 64                                       # far too small: nothing out of bounds, draw redone
         got = _run(args, cam)
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b)
-        assert fused._patch_capacity[key] > ref[3].shape[0]
-        fused._patch_capacity[key] = ref[3].shape[0] - 7    # just too small
+        assert cap[key] > ref[3].shape[0]
+        cap[key] = ref[3].shape[0] - 7                      # just too small
         got = _run(args, cam)
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b)
-        gsc._key_bits_hint = 1                              # stale hint: detected from the returned max key
+        gsc._set_key_bits(0, key, 1)                        # stale hint: detected from the returned max key
         got = _run(args, cam)
         for a, b in zip(ref, got):
             np.testing.assert_array_equal(a, b)
-        assert 8 <= gsc._key_bits_hint <= 32
+        assert 8 <= gsc._get_key_bits(0, key) <= 32
         s = torch.cuda.Stream()                             # and on a non-default stream
         with torch.cuda.stream(s):
             got = _run(args, cam)
@@ -60,3 +61,91 @@ def test_ahead_equals_exact_and_survives_overflow(policy):
         assert out[3].shape[0] == 0 and not out[0].any() and not out[5].any()
     finally:
         gsc.set_policy("gsplatcu")
+
+
+def test_deferred_validation_reports_incomplete_renders():
+    """Inside ``fused.deferred()`` nothing waits for the patch count; ``commit()`` names the renders whose
+    capacity / depth-key hint was exceeded (and only those), and a re-render is exact."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    args, cam = _scene(6000, 200, 120, 5)
+    key = (6000, 200, 120)
+    cap = fused._ctx(torch.device("cuda", 0)).capacity
+    cap.pop(key, None)
+    ref = _run(args, cam)
+    P = ref[3].shape[0]
+    with fused.deferred() as d:
+        outs = [fused.forward(*args, cam) for _ in range(3)]
+        assert all(o[2].ticket is not None or o[2]._patches is not None for o in outs)
+        assert d.commit() == []                              # all complete
+        for img, mask, st in outs:
+            assert st.ticket is None and st.patch_count() == P and st.gsid.shape[0] == P
+            np.testing.assert_array_equal(img.cpu().numpy(), ref[0])
+            np.testing.assert_array_equal(st.gsid.cpu().numpy(), ref[3])
+        cap[key] = P - 5                                     # the next render cannot hold its patch list
+        img_bad, _, st_bad = fused.forward(*args, cam)
+        bad = d.commit()
+        assert len(bad) == 1 and bad[0] is st_bad and st_bad.patch_count() == P
+        assert cap[key] > P                                  # learnt: the re-render fits
+        img2, _, st2 = fused.forward(*args, cam)
+        assert d.commit() == []
+        np.testing.assert_array_equal(img2.cpu().numpy(), ref[0])
+        gsc._set_key_bits(0, key, 2)                         # stale depth-key hint: same report
+        _, _, st3 = fused.forward(*args, cam)
+        bad = d.commit()
+        assert len(bad) == 1 and bad[0] is st3
+        img4, _, st4 = fused.forward(*args, cam)
+        assert d.commit() == []
+        np.testing.assert_array_equal(img4.cpu().numpy(), ref[0])
+    # an uncollected failure must not pass silently
+    cap[key] = 64
+    with pytest.raises(RuntimeError, match="incomplete"):
+        with fused.deferred():
+            fused.forward(*args, cam)
+    torch.cuda.synchronize()
+
+
+def test_deferred_backward_equals_immediate():
+    """Gradients of a render validated at commit() (capacity-sized patch list) == the immediate path."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import GSFunction
+    args, cam = _scene(5000, 160, 96, 9)
+    dl = torch.randn((3, 96, 160), device="cuda") / (3 * 96 * 160)
+
+    def grads(deferred):
+        ps = [a.clone().requires_grad_(True) for a in args]
+        ps[2] = ps[2].detach().reshape(-1, 1).clone().requires_grad_(True)
+        us = torch.zeros((5000, 2), device="cuda", requires_grad=True)
+        if deferred:
+            with fused.deferred() as d:
+                img, _ = GSFunction.apply(ps[0], ps[1], ps[2], ps[3], ps[4], us, cam)
+                img.backward(dl)
+                assert d.commit() == []
+        else:
+            img, _ = GSFunction.apply(ps[0], ps[1], ps[2], ps[3], ps[4], us, cam)
+            img.backward(dl)
+        torch.cuda.synchronize()
+        return [img.detach().cpu().numpy()] + [p.grad.cpu().numpy() for p in ps] + [us.grad.cpu().numpy()]
+    a = grads(False); a = grads(False)      # second call: enqueue-ahead, validated at once
+    b = grads(True)
+    np.testing.assert_array_equal(a[0], b[0])
+    for x, y in zip(a[1:], b[1:]):          # atomics: order of float additions differs from run to run
+        np.testing.assert_allclose(x, y, rtol=0, atol=2e-6 * max(1.0, np.abs(x).max()))
+
+
+def test_second_backward_with_retain_graph():
+    """``retain_graph=True`` keeps the saved state alive: a second backward gives the same gradients."""
+    from easygaussiansplatting_amd.function import GSFunction
+    args, cam = _scene(3000, 128, 96, 11)
+    ps = [a.clone().requires_grad_(True) for a in args]
+    ps[2] = ps[2].detach().reshape(-1, 1).clone().requires_grad_(True)
+    us = torch.zeros((3000, 2), device="cuda", requires_grad=True)
+    img, _ = GSFunction.apply(ps[0], ps[1], ps[2], ps[3], ps[4], us, cam)
+    dl = torch.randn_like(img) / img.numel()
+    img.backward(dl, retain_graph=True)
+    g1 = ps[0].grad.clone()
+    ps[0].grad = None
+    img.backward(dl)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(ps[0].grad.cpu().numpy(), g1.cpu().numpy(), rtol=0,
+                               atol=2e-6 * max(1.0, float(g1.abs().max())))

@@ -578,13 +578,13 @@ def test_depth_key_bit_hint_protocol(gsc):
     cam = sc.cam
     for hint in (1, 8, 32, 11):
         g = gpu_stages(gsc, sc, False, "gsplatcu")
-        mod._key_bits_hint = hint
+        mod._set_key_bits(0, (6000, cam.width, cam.height), hint)
         out = gsc.splat(cam.height, cam.width, g["us"], g["cinv2ds"], g["alphas"], g["depths"], g["colors"],
                         g["areas"])
         o_ranges, o_gsid, _, _ = O.bin_tiles(host(g["us"]), host(g["areas"]).copy(), host(g["depths"]).copy(),
                                              cam.width, cam.height, O.POLICY_G)
         assert np.array_equal(host(out[3]), o_ranges) and np.array_equal(host(out[4]), o_gsid), hint
-        assert 8 <= mod._key_bits_hint <= 16      # depth 3..7 m -> mm keys of 12-13 bits (+1 margin)
+        assert 8 <= mod._get_key_bits(0, (6000, cam.width, cam.height)) <= 16   # depth 3..7 m -> mm keys of 12-13 bits (+1 margin)
 
 
 # --------------------------------------------------------------------------- fused loss
