@@ -104,7 +104,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                     float** gpack, void* stream, const void* rec_in /* packed records or NULL */);
+                     float** gpack, void* stream, const void* rec_in /* packed records or NULL */,
+                     const int32_t* tile_order /* dispatch order left by the forward pass, or NULL */);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

@@ -790,8 +790,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
                                const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                float* dloss_dshs, float* dloss_dshs_high, float* dloss_dalphas, float* dloss_dscales,
-                               float* dloss_drots, float* dloss_dus, int phase, int row_begin, int row_count,
-                               void* stream) {
+                               float* dloss_drots, float* dloss_dus, const int32_t* tile_order, int phase,
+                               int row_begin, int row_count, void* stream) {
   // phase 0: everything; 1: only the draw pass (-> packed gradient records in ws); 2: only the per-Gaussian
   // chain rule, for rows [row_begin, row_begin + row_count) -- a data-parallel caller launches the rows in a
   // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
@@ -811,7 +811,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));   // where splat_bwd_packed puts the records
   if (phase != 2) {
     int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
-                              patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec);
+                              patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec,
+                              tile_order);
     if (rc) return rc;
     if (phase == 1) return 0;
   }
@@ -853,13 +854,13 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
                                   const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                   const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                   float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                                  float* dloss_drots, float* dloss_dus, int phase, int row_begin, int row_count,
-                                  void* stream) {
+                                  float* dloss_drots, float* dloss_dus, const int32_t* tile_order, int phase,
+                                  int row_begin, int row_count, void* stream) {
   return fused_backward_impl(false, n, sh_dim, patches, width, height, pws, rots, scales, shs, nullptr, alphas, Rcw,
                              tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths, contrib,
                              final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, dloss_dpws,
-                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, phase, row_begin,
-                             row_count, stream);
+                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, tile_order, phase,
+                             row_begin, row_count, stream);
 }
 
 extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
@@ -873,10 +874,11 @@ extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int wi
                                       const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                       float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                                       float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
-                                      int phase, int row_begin, int row_count, void* stream) {
+                                      const int32_t* tile_order, int phase, int row_begin, int row_count,
+                                      void* stream) {
   return fused_backward_impl(true, n, sh_dim, patches, width, height, pws, rots_raw, scales_raw, low_shs, high_shs,
                              alphas_raw, Rcw, tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths,
                              contrib, final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes,
                              dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
-                             dloss_drots_raw, dloss_dus, phase, row_begin, row_count, stream);
+                             dloss_drots_raw, dloss_dus, tile_order, phase, row_begin, row_count, stream);
 }

@@ -25,10 +25,10 @@
 
 // default dispatch order of the tiles for the forward / backward draw kernel (k_tile_order modes)
 #ifndef EGS_TILE_ORDER_F_DEFAULT
-#define EGS_TILE_ORDER_F_DEFAULT 0
+#define EGS_TILE_ORDER_F_DEFAULT 1
 #endif
 #ifndef EGS_TILE_ORDER_B_DEFAULT
-#define EGS_TILE_ORDER_B_DEFAULT 0
+#define EGS_TILE_ORDER_B_DEFAULT 1
 #endif
 
 namespace egs {
@@ -443,6 +443,11 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 //   mode 4: per XCD, serpentine
 // One workgroup: counting sort on (class, length / 4) in LDS -- 8160 tiles take a few microseconds.
 constexpr int TO_BINS = 1024;
+constexpr int TO_REGS = 16;    // list lengths a thread keeps in registers between the two passes (T <= 16384)
+__device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, int t) {
+  const int2 r = reinterpret_cast<const int2*>(ranges)[t];
+  return r.y - r.x;
+}
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges, int T, int gx, int mode,
                                                      int period, int32_t* __restrict__ order, int ngrid) {
   __shared__ uint32_t bins[8 * TO_BINS];
@@ -450,20 +455,38 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   __shared__ uint32_t cbase[9];
   const int tid = threadIdx.x;
   const bool per_xcd = mode >= 3;
-  for (int i = tid; i < 8 * TO_BINS; i += 1024) bins[i] = 0u;
-  for (int i = tid; i < ngrid; i += 1024) order[i] = -1;
+  const int ncls = per_xcd ? 8 : 1;
+  // all loads in flight at once: the kernel is a chain of latencies, not of bytes
+  int lenr[TO_REGS];
+#pragma unroll
+  for (int r = 0; r < TO_REGS; ++r) {
+    const int t = tid + r * 1024;
+    lenr[r] = t < T ? tile_len(ranges, t) : 0;
+  }
+  for (int i = tid; i < ncls * TO_BINS; i += 1024) bins[i] = 0u;
+  if (per_xcd)   // classes are padded to the largest one: slots without a tile stay -1
+    for (int i = tid; i < ngrid; i += 1024) order[i] = -1;
   __syncthreads();
-  for (int t = tid; t < T; t += 1024) {
-    const int len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
+  auto key_of = [&](int t, int len, int& cls) {
     const int q = min(max(len, 0), 4 * TO_BINS - 1) >> 2;
-    const int cls = per_xcd ? ((t / gx) & 7) : 0;
-    atomicAdd(&bins[cls * TO_BINS + (TO_BINS - 1 - q)], 1u);
+    cls = per_xcd ? ((t / gx) & 7) : 0;
+    return cls * TO_BINS + (TO_BINS - 1 - q);
+  };
+#pragma unroll
+  for (int r = 0; r < TO_REGS; ++r) {
+    const int t = tid + r * 1024;
+    int cls;
+    if (t < T) atomicAdd(&bins[key_of(t, lenr[r], cls)], 1u);
+  }
+  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) {
+    int cls;
+    atomicAdd(&bins[key_of(t, tile_len(ranges, t), cls)], 1u);
   }
   __syncthreads();
-  {  // exclusive scan of the 8192 bins: thread t owns bins [8 t, 8 t + 8)
+  {  // exclusive scan of the ncls * 1024 bins: thread t owns bins [ncls t, ncls t + ncls)
     uint32_t v[8], s = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = bins[8 * tid + k]; s += v[k]; }
+    for (int k = 0; k < 8; ++k) { v[k] = k < ncls ? bins[ncls * tid + k] : 0u; s += v[k]; }
     const uint32_t inc = wave_inclusive_scan(s);
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
@@ -471,18 +494,17 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
     uint32_t ex = pre + inc - s;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { bins[8 * tid + k] = ex; ex += v[k]; }
+    for (int k = 0; k < 8; ++k)
+      if (k < ncls) { bins[ncls * tid + k] = ex; ex += v[k]; }
   }
   __syncthreads();
-  if (tid < 8) cbase[tid] = bins[tid * TO_BINS];
+  if (tid < 8) cbase[tid] = tid < ncls ? bins[tid * TO_BINS] : (uint32_t)T;
   if (tid == 8) cbase[8] = (uint32_t)T;
   __syncthreads();
   const bool serp = (mode == 2 || mode == 4) && period > 0;
-  for (int t = tid; t < T; t += 1024) {
-    const int len = ranges[2 * (size_t)t + 1] - ranges[2 * (size_t)t];
-    const int q = min(max(len, 0), 4 * TO_BINS - 1) >> 2;
-    const int cls = per_xcd ? ((t / gx) & 7) : 0;
-    const uint32_t pos = atomicAdd(&bins[cls * TO_BINS + (TO_BINS - 1 - q)], 1u);
+  auto place = [&](int t, int len) {
+    int cls;
+    const uint32_t pos = atomicAdd(&bins[key_of(t, len, cls)], 1u);
     int r = (int)(pos - cbase[cls]);
     if (serp) {
       const int cnt = (int)(cbase[cls + 1] - cbase[cls]);
@@ -491,7 +513,13 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     }
     const int slot = per_xcd ? 8 * r + cls : r;
     if (slot < ngrid) order[slot] = t;
+  };
+#pragma unroll
+  for (int r = 0; r < TO_REGS; ++r) {
+    const int t = tid + r * 1024;
+    if (t < T) place(t, lenr[r]);
   }
+  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) place(t, tile_len(ranges, t));
 }
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
@@ -1209,6 +1237,9 @@ extern "C" int egs_exclusive_scan_u32(int64_t n, const uint32_t* in, const uint3
 }
 
 extern "C" size_t egs_splat_bin_ws_bytes(int n) { return bin_ws_bytes(n); }
+extern "C" size_t egs_tile_order_len(int width, int height) {
+  return (size_t)tile_order_len(div_up(width, EGS_TILE), div_up(height, EGS_TILE));
+}
 extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height) {
   return draw_ws_bytes(n, patches, width, height);
 }
@@ -1283,7 +1314,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
                            size_t ws_draw_bytes, const float4* rec_in, float* image, int32_t* contrib,
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
-                           void* stream, const uint32_t* patches_dev = nullptr) {
+                           void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr) {
+  // tile_order != NULL (egs_tile_order_len ints): the dispatch order of the tiles is written there, for the
+  // backward pass to reuse (otherwise it lives in ws_draw and the backward pass computes its own)
   // patches_dev != NULL: `patches` is only the capacity of gsid_per_patch / ws_draw, the real count is read on
   // the device (the host has not seen it yet)
   EGS_CHECK_ARG(n >= 0 && patches >= 0 && patches < (int64_t)0x7FFFFFFF && width > 0 && height > 0 && pol);
@@ -1326,7 +1359,8 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   if (rc) return rc;
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile, patches_dev);
-  rc = tile_order_enqueue(dp, 0, D.order, (size_t)tile_order_len(dp.gx, dp.gy), patch_range_per_tile, s);
+  rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
+                          patch_range_per_tile, s);
   if (rc) return rc;
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                         \
@@ -1370,11 +1404,12 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
 extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec,
                                   const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                   float* image, int32_t* contrib, float* final_tau,
-                                  int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+                                  int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
+                                  void* stream) {
   EGS_CHECK_ARG(rec || n == 0);
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
-                         patch_range_per_tile, gsid_per_patch, stream);
+                         patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order);
 }
 
 // as egs_splat_draw_rec, enqueued BEFORE the host has read total_patches: patch_capacity sizes
@@ -1384,13 +1419,14 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                                       uint32_t* host_totals, int width, int height, const void* rec,
                                       const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                       float* image, int32_t* contrib, float* final_tau,
-                                      int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+                                      int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
+                                      void* stream) {
   EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
   if (host_totals)
     EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
-                         patch_range_per_tile, gsid_per_patch, stream, total_patches);
+                         patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]
@@ -1404,7 +1440,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                     float** gpack_out, void* stream, const void* rec_in) {
+                     float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order) {
   hipStream_t s = (hipStream_t)stream;
   const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
   float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));  // [N][12] packed gradient records
@@ -1419,7 +1455,11 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
-  {
+  if (tile_order && tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0) {
+    // the forward pass left its dispatch order behind (same mode): no second k_tile_order
+    dp.order = tile_order;
+    dp.ngrid = tile_order_mode(1) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
+  } else {
     int32_t* order = (int32_t*)((char*)ws + 2 * align_up((size_t)n * 48, 256));
     const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s);
     if (rc) return rc;
@@ -1460,7 +1500,8 @@ extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, cons
   }
   float* gpack = nullptr;
   int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
-                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, nullptr);
+                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, nullptr,
+                            nullptr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,

@@ -35,7 +35,7 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "width", "height", "ticket", "_patches")
+                 "order", "width", "height", "ticket", "_patches")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
@@ -227,13 +227,14 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
     S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
     S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
+    S.order = torch.empty(lib.egs_tile_order_len(W, H), dtype=i32, device=dev)   # tile dispatch order, reused by backward
 
     def draw_exact(patches):
         S.gsid = torch.empty(patches, dtype=i32, device=dev)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
-                                          _ptr(S.ranges), _ptr(S.gsid), st))
+                                          _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -282,7 +283,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
     ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
     _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
                                           _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
-                                          _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), st))
+                                          _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order), st))
     S.gsid = gsid_full                                # entries past P are unused (the kernels walk `ranges`)
     S._patches = None
     S.ticket = t
@@ -355,11 +356,11 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     if raw:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward_raw(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *mid,
-            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), phase, b, c, st))
+            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), phase, b, c, st))
     else:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *mid, _ptr(dalphas),
-            _ptr(dscales), _ptr(drots), _ptr(dus), phase, b, c, st))
+            _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), phase, b, c, st))
     hook = _exchange_hook
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups

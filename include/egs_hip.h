@@ -194,7 +194,11 @@ int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, co
 int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
-                       int32_t* gsid_per_patch, void* stream);
+                       int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/, void* stream);
+/* The draw kernels hand the tiles to the SIMDs longest list first (k_tile_order, one workgroup, after the
+ * tile ranges are known).  tile_order (nullable, egs_tile_order_len(width, height) ints) receives that dispatch
+ * order so that egs_fused_backward can reuse it instead of computing its own. */
+size_t egs_tile_order_len(int width, int height);
 /* As egs_splat_draw_rec, for a host that enqueues the draw stage BEFORE it has read total_patches (no GPU
  * idle time around the read-back): patch_capacity sizes gsid_per_patch and ws_draw
  * (egs_splat_draw_ws_bytes(n, patch_capacity, ..)), the real patch count is taken from total_patches[0] on
@@ -205,7 +209,8 @@ int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void
 int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_patches, uint32_t* host_totals,
                            int width, int height, const void* rec, const EgsPolicy* pol, const void* ws_bin,
                            void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
-                           int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream);
+                           int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
+                           void* stream);
 /* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
  * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
 int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
@@ -233,7 +238,8 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                        const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                       float* dloss_drots, float* dloss_dus, int phase, int row_begin, int row_count, void* stream);
+                       float* dloss_drots, float* dloss_dus, const int32_t* tile_order /*nullable*/, int phase,
+                       int row_begin, int row_count, void* stream);
 
 /* The same pair on the OPTIMIZER's tensors (gsplat/gsmodel.py:96-129: alphas_raw, scales_raw, rots_raw,
  * low_shs [N,3], high_shs [N,sh_dim-3]): the activations of gsplat/utils.py:121-150 (sigmoid, exp,
@@ -255,8 +261,9 @@ int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int he
                            const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                            const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                            float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
-                           float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus, int phase,
-                           int row_begin, int row_count, void* stream);
+                           float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
+                           const int32_t* tile_order /*nullable*/, int phase, int row_begin, int row_count,
+                           void* stream);
 
 /* ---- fused training loss -----------------------------------------
  * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the

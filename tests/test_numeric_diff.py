@@ -1,0 +1,268 @@
+"""Numeric-derivative checks of the backward pass -- the counterpart of the reference's own self-check
+(/root/reference/backward_cpu.py:47-65 ``numerical_derivative`` / ``check`` and its ``__main__``, :502-698).
+
+CPU part (no GPU): every Jacobian of the oracle's stage functions, the per-pixel blend backward
+(``O.draw_backward``) and the whole parameter-gradient chain are compared with finite differences of the
+oracle's forward functions in float64.  The reference uses forward differences with delta = 1e-8 and accepts
+|numeric - analytic| < 1e-4; central differences are used here (truncation error O(delta^2), so the same 1e-4
+rule holds with margin on the large-valued covariance Jacobians the reference's rule fails on).
+
+GPU part (``-m gpu``): directional derivatives (L(theta + eps d) - L(theta - eps d)) / 2 eps of the loss
+evaluated with the HIP forward pass against <grad L, d> from the HIP backward pass, for every parameter
+tensor, on the multi-tile G5-sized scene and the 10 k scene of BASELINE configs[0].
+"""
+import numpy as np
+import pytest
+
+from easygaussiansplatting_amd import scene as S
+from oracle import gs_oracle as O
+
+
+def check(a, b, tol=1e-4):
+    """backward_cpu.py:61-65 (absolute), relaxed to relative for entries larger than one."""
+    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
+    return np.all(np.abs(a - b) < tol * np.maximum(1.0, np.abs(b)))
+
+
+def central(f, x, delta=1e-6):
+    """d f / d x by central differences; f: R^n -> R^m (flattened)."""
+    x = np.asarray(x, np.float64)
+    f0 = np.asarray(f(x), np.float64).reshape(-1)
+    J = np.zeros((f0.size, x.size))
+    for j in range(x.size):
+        d = np.zeros(x.size); d[j] = delta
+        J[:, j] = (np.asarray(f(x + d.reshape(x.shape))).reshape(-1) -
+                   np.asarray(f(x - d.reshape(x.shape))).reshape(-1)) / (2 * delta)
+    return J
+
+
+def _scene(n=12, seed=4):
+    sc = S.small_scene(n, 64, 48, 48, seed=seed)
+    return sc, sc.cam
+
+
+# ------------------------------------------------------------------ stage Jacobians (backward_cpu.py:540-600)
+def test_stage_jacobians_match_central_differences():
+    sc, cam = _scene()
+    P = O.POLICY_B    # the stage functions of backward_cpu.py: no culls, no fov clamp
+    f64 = lambda a: np.asarray(a, np.float64)
+    pws, rots, scales, shs = f64(sc.pws), f64(sc.rots), f64(sc.scales), f64(sc.shs)
+    us, pcs, depths, du_dpcs = O.project(pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P, True)
+    cov3ds, dcov3d_drots, dcov3d_dscales = O.compute_cov3d(rots, scales, depths, P, True)
+    cov2ds, dcov2d_dcov3ds, dcov2d_dpcs = O.compute_cov2d(cov3ds, pcs, cam.Rcw, depths, cam.fx, cam.fy,
+                                                          cam.width, cam.height, P, True)
+    colors, dcolor_dshs, dcolor_dpws = O.sh2color(shs, pws, cam.twc, True)
+    cinv2ds, areas, dcinv2d_dcov2ds = O.inverse_cov2d(cov2ds, depths, P, True)
+    Rcw = f64(cam.Rcw)
+    for i in range(sc.n):
+        one = lambda a: a[i:i + 1]
+        # du/dpw = du/dpc Rcw (B.1.2 after the rigid transform)
+        num = central(lambda x: O.project(x.reshape(1, 3), cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P)[0],
+                      pws[i])
+        assert check(num, du_dpcs[i] @ Rcw), ("du_dpw", i)
+        num = central(lambda x: O.compute_cov3d(x.reshape(1, 4), one(scales), one(depths), P), rots[i])
+        assert check(num, dcov3d_drots[i]), ("dcov3d_drot", i)
+        num = central(lambda x: O.compute_cov3d(one(rots), x.reshape(1, 3), one(depths), P), scales[i], 1e-7)
+        assert check(num, dcov3d_dscales[i]), ("dcov3d_dscale", i)
+        f2 = lambda c3, pc: O.compute_cov2d(c3.reshape(1, 6), pc.reshape(1, 3), cam.Rcw, one(depths), cam.fx, cam.fy,
+                                            cam.width, cam.height, P)
+        assert check(central(lambda x: f2(x, pcs[i]), cov3ds[i], 1e-7), dcov2d_dcov3ds[i]), ("dcov2d_dcov3d", i)
+        assert check(central(lambda x: f2(cov3ds[i], x), pcs[i]), dcov2d_dpcs[i]), ("dcov2d_dpc", i)
+        num = central(lambda x: O.sh2color(x.reshape(1, 48), one(pws), cam.twc), shs[i])
+        for c in range(3):   # dcolor[c]/dsh[3 k + c] = basis[k]; all other entries are zero
+            assert check(num[c, c::3], dcolor_dshs[i][0]), ("dcolor_dsh", i)
+            mask = np.ones(48, bool); mask[c::3] = False
+            assert np.abs(num[c, mask]).max() < 1e-7
+        num = central(lambda x: O.sh2color(one(shs), x.reshape(1, 3), cam.twc), pws[i])
+        assert check(num, dcolor_dpws[i]), ("dcolor_dpw", i)
+        num = central(lambda x: O.inverse_cov2d(x.reshape(1, 3), one(depths), P)[0], cov2ds[i], 1e-7)
+        assert check(num, dcinv2d_dcov2ds[i]), ("dcinv2d_dcov2d", i)
+
+
+def test_cov_known_answers_pass_the_reference_rule_with_central_differences():
+    """The hard-coded inputs of the reference's test/test_cov3d.py:112-113 and test_cov2d.py:104-110: its own
+    forward differences miss the 1e-4 rule on the cov2d case (values ~1e4: errors 1.1e-4 / 2.2e-4, SURVEY
+    appendix); relative to the Jacobian's magnitude both pass."""
+    q = np.array([[0.606, -0.002, -0.755, 0.252]]); s = np.array([[1.2, 3.2, 0.5]])
+    c3, dq, ds = O.compute_cov3d(q, s, None, O.POLICY_B, True)
+    assert check(central(lambda x: O.compute_cov3d(x.reshape(1, 4), s, None, O.POLICY_B), q[0]), dq[0])
+    assert check(central(lambda x: O.compute_cov3d(q, x.reshape(1, 3), None, O.POLICY_B), s[0]), ds[0])
+    Rcw = np.array([[-0.267058, -0.302404, -0.916068], [0.308444, 0.872984, -0.378096],
+                    [0.914052, -0.382944, -0.140058]])
+    pc = np.array([[1.0, 2.0, 3.0]]); depths = np.array([3.0])
+    f2 = lambda c, p: O.compute_cov2d(c.reshape(1, 6), p.reshape(1, 3), Rcw, depths, 200.0, 100.0, 1e9, 1e9,
+                                      O.POLICY_B)
+    c2, d3, dpc = O.compute_cov2d(c3, pc, Rcw, depths, 200.0, 100.0, 1e9, 1e9, O.POLICY_B, True)
+    assert check(central(lambda x: f2(x, pc[0]), c3[0], 1e-6), d3[0])
+    assert check(central(lambda x: f2(c3[0], x), pc[0], 1e-6), dpc[0])
+
+
+# ------------------------------------------------------------------ per-pixel blend (backward_cpu.py:610-660)
+def _raster_inputs(policy, n=40, w=48, h=32, seed=8):
+    sc = S.small_scene(n, w, h, 3, seed=seed)
+    cam = sc.cam
+    st = O.forward_pipeline((sc.pws, sc.rots, sc.scales, sc.alphas, sc.shs), cam, policy)
+    rng = np.random.default_rng(seed)
+    dl = rng.normal(size=(3, h, w)) / 8.0
+    return sc, cam, st, dl
+
+
+@pytest.mark.parametrize("pname", ["gsplatcu", "backward_cpu"])
+def test_draw_backward_matches_central_differences_of_draw(pname):
+    """dL/d(us, cinv2ds, alphas, colors) of O.draw_backward vs central differences of L = <dL/dimage, O.draw>
+    (the calc_loss check of backward_cpu.py:643-660 on a multi-tile scene with tile lists)."""
+    policy = O.POLICY_G if pname == "gsplatcu" else O.POLICY_B
+    sc, cam, st, dl = _raster_inputs(O.POLICY_G)     # tile lists and 2D Gaussians of the CUDA definition
+    W, H = cam.width, cam.height
+    base = dict(us=st["us"], cinv2ds=st["cinv2ds"], alphas=np.asarray(sc.alphas, np.float64), colors=st["colors"])
+    if pname == "backward_cpu":   # that definition blends every Gaussian on every pixel, in input order
+        n = sc.n
+        ranges = np.tile(np.array([[0, n]], np.int32), (st["ranges"].shape[0], 1))
+        ranges = np.cumsum(np.full(ranges.shape[0], n), dtype=np.int64)[:, None] + np.array([[-n, 0]])
+        gsid = np.tile(np.argsort(st["depths"], kind="stable").astype(np.int32), ranges.shape[0])
+        base["alphas"] = np.minimum(base["alphas"], 0.8)
+    else:
+        ranges, gsid = st["ranges"], st["gsid"]
+
+    def loss(**kw):
+        a = dict(base); a.update(kw)
+        img, cont, tau = O.draw(W, H, ranges, gsid, a["us"], a["cinv2ds"], a["alphas"], a["colors"], None, policy)
+        return float((img * dl).sum()), cont, tau
+    L0, cont, tau = loss()
+    g = O.draw_backward(W, H, ranges, gsid, base["us"], base["cinv2ds"], base["alphas"], base["colors"], cont, tau,
+                        dl, None, policy)
+    grads = dict(us=g[0], cinv2ds=g[1], alphas=g[2], colors=g[3])
+    rng = np.random.default_rng(1)
+    worst = 0.0
+    for name, ana in grads.items():
+        x0 = base[name]
+        scale = np.abs(ana).max()
+        assert scale > 0
+        flat_idx = rng.choice(x0.size, size=min(x0.size, 60), replace=False)
+        bad = 0
+        for j in flat_idx:
+            d = np.zeros(x0.size); d[j] = 1e-6
+            d = d.reshape(x0.shape)
+            num = (loss(**{name: x0 + d})[0] - loss(**{name: x0 - d})[0]) / 2e-6
+            err = abs(num - ana.reshape(-1)[j])
+            # the blend is discontinuous where alpha' crosses the 0.002 skip threshold or tau the 1e-4 stop:
+            # a difference quotient that straddles one is off by a jump / 2e-6 -- huge, unmistakable, rare
+            if err > 1e-4 * max(1.0, scale):
+                bad += 1
+            else:
+                worst = max(worst, err / max(1.0, scale))
+        assert bad <= 1, (name, bad)
+    assert worst < 1e-5
+
+
+def test_parameter_gradients_match_directional_differences():
+    """The whole chain (backward_cpu.py:662-698): d L / d (rots, scales, shs, alphas, pws) from draw_backward +
+    chain_rule vs central differences of L through the full forward pipeline, along random directions."""
+    policy = O.POLICY_G
+    sc, cam, st, dl = _raster_inputs(policy, n=60, seed=5)
+    W, H = cam.width, cam.height
+    P = {k: np.asarray(getattr(sc, k), np.float64) for k in ("pws", "rots", "scales", "alphas", "shs")}
+
+    def loss(p):
+        s = O.forward_pipeline((p["pws"], p["rots"], p["scales"], p["alphas"], p["shs"]), cam, policy)
+        return float((s["image"] * dl).sum()), s
+    L0, s = loss(P)
+    g2 = O.draw_backward(W, H, s["ranges"], s["gsid"], s["us"], s["cinv2ds"], P["alphas"], s["colors"], s["contrib"],
+                         s["final_tau"], dl, None, policy)
+    J = {}
+    _, pcs, depths, J["du_dpcs"] = O.project(P["pws"], cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, policy, True)
+    c3, J["dcov3d_drots"], J["dcov3d_dscales"] = O.compute_cov3d(P["rots"], P["scales"], depths, policy, True)
+    c2, J["dcov2d_dcov3ds"], J["dcov2d_dpcs"] = O.compute_cov2d(c3, pcs, cam.Rcw, depths, cam.fx, cam.fy, W, H,
+                                                                policy, True)
+    _, J["dcolor_dshs"], J["dcolor_dpws"] = O.sh2color(P["shs"], P["pws"], cam.twc, True)
+    _, _, J["dcinv2d_dcov2ds"] = O.inverse_cov2d(c2, depths.copy(), policy, True)
+    g = O.chain_rule(g2[0], g2[1], g2[2], g2[3], cam.Rcw, J)
+    grads = dict(pws=g["dpws"], rots=g["drots"], scales=g["dscales"], alphas=g["dalphas"], shs=g["dshs"])
+    rng = np.random.default_rng(3)
+    for name, ana in grads.items():
+        for trial in range(3):
+            d = rng.normal(size=P[name].shape)
+            eps = 1e-7 * (np.abs(P[name]).mean() + 1e-3) / np.abs(d).mean()
+            hi = dict(P); hi[name] = P[name] + eps * d
+            lo = dict(P); lo[name] = P[name] - eps * d
+            num = (loss(hi)[0] - loss(lo)[0]) / (2 * eps)
+            want = float((ana.reshape(P[name].shape) * d).sum())
+            assert abs(num - want) < 1e-4 * max(1.0, abs(want)), (name, trial, num, want)
+
+
+# ------------------------------------------------------------------ GPU: directional derivatives of the HIP path
+def _oracle_loss(P, cam, dl, n):
+    s = O.forward_pipeline((P["pws"], P["rots"], P["scales"], P["alphas"].reshape(-1), P["shs"]), cam, O.POLICY_G)
+    return float((s["image"] * dl).sum())
+
+
+def _gpu_directional(n, w, h, sh_dim, seed, mode):
+    torch = pytest.importorskip("torch")
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from easygaussiansplatting_amd import gsplatcu
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    gsplatcu.set_policy("gsplatcu")
+    sc = S.small_scene(n, w, h, sh_dim, seed=seed)
+    cam = Camera.from_scene(sc.cam)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    # an L1-against-zeros style dL/dimage (one sign per channel, backward_cpu.py:388-397) with a smooth spatial
+    # modulation
+    yy, xx = np.meshgrid(np.linspace(0, 1, h), np.linspace(0, 1, w), indexing="ij")
+    dl = np.stack([1.0 + 0.5 * xx, 0.8 + 0.4 * yy, 1.2 - 0.3 * xx * yy]) / (3 * w * h)
+    dl_t = dev(dl)
+    P0 = dict(pws=sc.pws, shs=sc.shs, alphas=sc.alphas.reshape(-1, 1), scales=sc.scales, rots=sc.rots)
+    P0 = {k: np.ascontiguousarray(v, np.float32) for k, v in P0.items()}
+    order = ("pws", "shs", "alphas", "scales", "rots")
+    prev = GSFunction.mode
+    GSFunction.mode = mode
+    try:
+        def loss_of(P):   # fp32 image from the device, summed in float64 on the host
+            with torch.no_grad():
+                img, _ = GSFunction.apply(*[dev(P[k]) for k in order], torch.zeros((n, 2), device="cuda"), cam)
+            return float((img.double().cpu().numpy() * dl).sum())
+        leaves = [dev(P0[k]).requires_grad_(True) for k in order]
+        us = torch.zeros((n, 2), device="cuda", requires_grad=True)
+        img, _ = GSFunction.apply(*leaves, us, cam)
+        img.backward(dl_t)
+        grads = {k: t.grad.double().cpu().numpy() for k, t in zip(order, leaves)}
+        rng = np.random.default_rng(seed)
+        out = {}
+        for k in order:
+            # every component moves DOWNHILL-aligned (d = |random| * sign(grad)): the terms of <grad, d> add up
+            # instead of cancelling, so the quotient is well conditioned.  Steps of 1e-4 of the tensor's scale:
+            # fp32 rounding of the image is ~1e-3 of the resulting change of L, curvature is smaller still
+            d = np.abs(rng.normal(size=P0[k].shape)) * np.sign(grads[k])
+            eps = 1e-4 * max(np.abs(P0[k]).mean(), 1e-3) / max(np.abs(d).mean(), 1e-30)
+            hi = dict(P0); hi[k] = (P0[k].astype(np.float64) + eps * d).astype(np.float32)
+            lo = dict(P0); lo[k] = (P0[k].astype(np.float64) - eps * d).astype(np.float32)
+            step = hi[k].astype(np.float64) - lo[k].astype(np.float64)    # the step actually taken in fp32
+            num = loss_of(hi) - loss_of(lo)
+            want = float((grads[k] * step).sum())
+            ref = _oracle_loss({a: b.astype(np.float64) for a, b in hi.items()}, sc.cam, dl, n) - \
+                _oracle_loss({a: b.astype(np.float64) for a, b in lo.items()}, sc.cam, dl, n)
+            out[k] = (num, want, ref)
+        return out
+    finally:
+        GSFunction.mode = prev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", ["fused", "ops"])
+@pytest.mark.parametrize("cfg", [(160, 48, 32, 48, 31), (10_000, 256, 256, 3, 0), (10_000, 256, 256, 48, 2)])
+def test_gpu_directional_derivatives(cfg, mode):
+    """L(theta + eps d) - L(theta - eps d) of the HIP forward pass vs <grad L, 2 eps d> of the HIP backward pass,
+    per parameter tensor, and vs the same difference of the float64 oracle.
+
+    Two tolerances, because the rasterizer is not a smooth function: pixels enter and leave a Gaussian's
+    alpha' >= 0.002 support (kernel.cu:246) as it moves, each crossing a jump the analytic gradient -- the
+    reference's as much as this one -- does not contain.  The float64 oracle's own difference quotient sits
+    1-3 % from its analytic gradient on these scenes for pws / scales / rots at ANY step size (none for shs and
+    alphas, which do not move the support... alphas does, slightly), so
+      * HIP difference vs HIP gradient: 5 %;
+      * HIP difference vs float64-oracle difference of the SAME step (same function, jumps included): 0.5 %."""
+    out = _gpu_directional(*cfg, mode)
+    for k, (num, want, ref) in out.items():
+        assert abs(want) > 0, k
+        assert abs(num - want) <= 5e-2 * abs(want), (k, num, want)
+        assert abs(num - ref) <= 5e-3 * abs(ref) + 1e-9, (k, num, ref)

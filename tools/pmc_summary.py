@@ -9,7 +9,7 @@ for d in sys.argv[1:]:
             k = r["Kernel_Name"].split("(")[0].replace("void ", "")
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"]); disp[k].add(r["Dispatch_Id"])
         for k, v in agg.items():
-            if "egs::" in k:
+            if "egs::" in k or "--any" in sys.argv:
                 for c, x in v.items():
                     res[k][c] = x / len(disp[k])
                 res[k]["launches"] = len(disp[k])

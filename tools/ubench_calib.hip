@@ -1,0 +1,70 @@
+// Calibration micro-benchmarks for the SQ counters and for the instruction mix of the draw kernels (gfx950).
+// Each kernel issues ONE kind of VALU instruction in 8 independent chains at 8 waves per SIMD, so the VALU pipe
+// is the only limit: run plain it prints nominal cycles per wave-instruction per SIMD; run under
+//   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
+// the ratio SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the pure-FMA kernel is what the
+// counter reads at 100 % issue utilisation -- the factor every "VALU busy" figure under profiles/ is divided by.
+//   hipcc --offload-arch=gfx950 -O3 tools/ubench_calib.hip -o gpurun_out/ubench_calib && gpurun_out/ubench_calib
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+
+#define CHAINS 8
+#define ITERS 4096
+
+namespace egs {
+enum { FMA, EXP, RCP, SWAP32, SWAP16, DPPADD, CNDMASK, READLANE, MOV64, MED3, CMPS, NOPS };
+
+template <int OP>
+__global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
+  float a[CHAINS], b[CHAINS];
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) { a[i] = seed + i + threadIdx.x * 1e-3f; b[i] = seed * 0.5f + i; }
+  float c = seed * 1.0001f;
+  for (int it = 0; it < ITERS; ++it) {
+#pragma unroll
+    for (int i = 0; i < CHAINS; ++i) {
+      if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
+      if (OP == EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(a[i]));
+      if (OP == RCP) asm volatile("v_rcp_f32 %0, %0" : "+v"(a[i]));
+      if (OP == SWAP32) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b[i]));
+      if (OP == SWAP16) asm volatile("v_permlane16_swap_b32 %0, %1" : "+v"(a[i]), "+v"(b[i]));
+      if (OP == DPPADD) asm volatile("v_add_f32_dpp %0, %1, %0 row_mirror row_mask:0xf bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]));
+      if (OP == CNDMASK) asm volatile("v_cndmask_b32 %0, %0, %1, s[20:21]" : "+v"(a[i]) : "v"(b[i]));
+      if (OP == READLANE) asm volatile("v_readlane_b32 s22, %0, 3" :: "v"(a[i]) : "s22");
+      if (OP == MOV64) asm volatile("v_mov_b64 %0, 0" : "=v"(*(double*)&a[i & ~1]));
+      if (OP == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
+      if (OP == CMPS) asm volatile("v_cmp_lt_f32 s[24:25], %0, %1" :: "v"(a[i]), "v"(c) : "s24", "s25");
+    }
+  }
+  float s = 0;
+#pragma unroll
+  for (int i = 0; i < CHAINS; ++i) s += a[i] + b[i];
+  if (s == 12345.678f) out[0] = s;
+}
+}  // namespace egs
+
+template <int OP>
+static void run(const char* name, float* d) {
+  const int blocks = 2048;
+  hipEvent_t e0, e1;
+  hipEventCreate(&e0); hipEventCreate(&e1);
+  hipLaunchKernelGGL(egs::k_ub<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5f);
+  hipDeviceSynchronize();
+  hipEventRecord(e0);
+  hipLaunchKernelGGL(egs::k_ub<OP>, dim3(blocks), dim3(256), 0, 0, d, 1.5f);
+  hipEventRecord(e1);
+  hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  const double winst = (double)blocks * 4 * ITERS * CHAINS / 1024.0;   // wave-instructions per SIMD
+  printf("%-10s %8.3f ms  %6.3f ns per wave-instr per SIMD (= %.2f cycles @2.4 GHz nominal)\n", name, ms,
+         ms * 1e6 / winst, ms * 1e6 / winst * 2.4);
+}
+
+int main() {
+  float* d; hipMalloc(&d, 1024);
+  run<egs::FMA>("v_fma", d); run<egs::EXP>("v_exp", d); run<egs::RCP>("v_rcp", d);
+  run<egs::SWAP32>("swap32", d); run<egs::SWAP16>("swap16", d); run<egs::DPPADD>("add_dpp", d);
+  run<egs::CNDMASK>("cndmask", d); run<egs::READLANE>("readlane", d); run<egs::MOV64>("mov_b64", d);
+  run<egs::MED3>("med3", d); run<egs::CMPS>("cmp->sgpr", d);
+  return 0;
+}
