@@ -1,0 +1,160 @@
+"""Two ranks, HIP path: every rank renders ITS camera view with ``GSFunction`` (fused kernels) on the GPU and
+the ranks exchange the parameter gradients -- once as the single flat all-reduce, once chunk by chunk from
+inside the backward pass (``dist_views.ChunkedExchange``).  The property pinned is the one the 8-GPU run of
+BASELINE configs[3] relies on (SURVEY 8a': the counterpart of the reference's one-view-per-step loop,
+train.py:48-57): the all-reduced mean of one view per rank == the two-view gradient accumulation of ONE process.
+
+Both ranks share ``cuda:0`` (the box has one GPU), so the collectives go through gloo (host staging); RCCL
+refuses two ranks on one device.  ``Trainer.step`` over the two views on two ranks == on one rank likewise."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.distributed as dist          # noqa: E402
+import torch.multiprocessing as mp        # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N, W, H, K = 6000, 160, 96, 48
+
+
+def _setup():
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera
+    sc = S.small_scene(N, W, H, K, seed=17)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 2, radius=5.0)]
+    dl = torch.from_numpy(S.normal(5, 2, (3, H, W)).astype(np.float32)).cuda() / (3 * H * W)
+    return sc, cams, dl
+
+
+def _params(sc):
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda().requires_grad_(True)
+    return dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas.reshape(-1, 1)), scales=t(sc.scales), rots=t(sc.rots))
+
+
+ORDER = ("pws", "shs", "alphas", "scales", "rots")
+
+
+def _render(P, cam, dl):
+    from easygaussiansplatting_amd.function import GSFunction
+    us = torch.zeros((N, 2), device="cuda", requires_grad=True)
+    img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us, cam)
+    img.backward(dl)
+
+
+def _worker(rank, world, port, q, chunked):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easygaussiansplatting_amd import dist_views as DV
+        from easygaussiansplatting_amd import fused
+        torch.cuda.set_device(0)
+        sc, cams, dl = _setup()
+        P = _params(sc)
+        out = {}
+        for rep in range(2):               # the second pass runs the enqueue-ahead forward
+            for p in P.values():
+                p.grad = None
+            if chunked:
+                ex = DV.ChunkedExchange(world, chunks=4)
+                with ex.attach():
+                    _render(P, cams[rank], dl)
+                assert ex.finish() and ex.used
+                calls = None
+            else:
+                _render(P, cams[rank], dl)
+                flat = fused.flat_grad_buffer([P[k] for k in ORDER])
+                assert flat is not None
+                dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                flat.div_(world)
+            torch.cuda.synchronize()
+            out = {k: P[k].grad.cpu().numpy().copy() for k in ORDER}
+        q.put((rank, out))
+    finally:
+        dist.destroy_process_group()
+
+
+def _free_port():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close()
+    return p
+
+
+def _spawn(target, args):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=target, args=(r, 2, port, q) + args) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=600) for _ in range(2)]
+    for p in procs:
+        p.join(120)
+        assert p.exitcode == 0
+    return sorted(res, key=lambda r: r[0])
+
+
+@pytest.mark.parametrize("chunked", [False, True])
+def test_two_rank_hip_gradients_equal_one_process_two_view_accumulation(chunked):
+    res = _spawn(_worker, (chunked,))
+    sc, cams, dl = _setup()
+    P = _params(sc)
+    for cam in cams:                       # ONE process, two views: autograd accumulates into .grad
+        _render(P, cam, dl)
+    torch.cuda.synchronize()
+    for k in ORDER:
+        want = P[k].grad.cpu().numpy() / 2
+        scale = np.abs(want).max()
+        assert scale > 0
+        for rank, g in res:
+            # SURVEY 8a': <= 1e-5 relative (the gradient atomics of k_draw_bwd add in a different order per run)
+            assert np.abs(g[k] - want).max() <= 1e-5 * scale, (k, rank, np.abs(g[k] - want).max(), scale)
+    for k in ORDER:                        # both ranks hold the same reduced gradient
+        np.testing.assert_array_equal(res[0][1][k], res[1][1][k])
+
+
+def _trainer_worker(rank, world, port, q):
+    if world > 1:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from easygaussiansplatting_amd import scene as S
+        from easygaussiansplatting_amd.function import Camera, render
+        from easygaussiansplatting_amd.trainer import Trainer
+        torch.cuda.set_device(0)
+        sc = S.small_scene(4000, 128, 96, 48, seed=23)
+        cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 2, radius=5.0)]
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+        with torch.no_grad():
+            gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+        start = S.small_scene(4000, 128, 96, 48, seed=23)
+        start.shs[:, :3] += 0.4
+        tr = Trainer(start, cams, gts, max_steps=50, scene_size=4.0)
+        losses = [tr.step([0, 1]) for _ in range(3)]
+        with pytest.raises(ValueError):
+            tr.step([0]) if world > 1 else (_ for _ in ()).throw(ValueError())   # fewer views than ranks
+        q.put((rank, (losses, {k: v.detach().cpu().numpy() for k, v in tr.params.items()})))
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def test_trainer_two_ranks_equal_one_rank():
+    """train.py's loop, data-parallel: two ranks x one view per step move the parameters like one rank x two
+    views (Adam normalises the gradient: a strict check of the exchanged direction)."""
+    two = _spawn(_trainer_worker, ())
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_trainer_worker, args=(0, 1, 0, q))
+    p.start()
+    one = q.get(timeout=600)[1]
+    p.join(120)
+    assert p.exitcode == 0
+    for rank, (losses, params) in two:
+        np.testing.assert_allclose(losses, one[0], rtol=2e-4)
+        for k in params:
+            assert np.abs(params[k] - one[1][k]).max() < 2e-3 * max(1e-3, np.abs(one[1][k]).max()), (rank, k)

@@ -541,6 +541,116 @@ def test_full_size_policy_g_sampled_tiles_and_invariants(gsc, big):
         assert close(b[full], a[full], 2e-4)
 
 
+def _oracle_2d(sc, cam, rows=None, calc_J=False):
+    """The oracle's per-Gaussian stages (float64, policy G) for all Gaussians or for ``rows``."""
+    sel = slice(None) if rows is None else rows
+    P = O.POLICY_G
+    out = O.project(sc.pws[sel], cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P, calc_J)
+    us, pcs, depths = out[:3]
+    c3 = O.compute_cov3d(sc.rots[sel], sc.scales[sel], depths, P, calc_J)
+    c2 = O.compute_cov2d(c3[0] if calc_J else c3, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, P,
+                         calc_J)
+    col = O.sh2color(sc.shs[sel], sc.pws[sel], cam.twc, calc_J)
+    ci = O.inverse_cov2d((c2[0] if calc_J else c2), depths.copy(), P, calc_J)
+    if not calc_J:
+        return us, ci[0], col, depths
+    J = dict(du_dpcs=out[3], dcov3d_drots=c3[1], dcov3d_dscales=c3[2], dcov2d_dcov3ds=c2[1], dcov2d_dpcs=c2[2],
+             dcolor_dshs=col[1], dcolor_dpws=col[2], dcinv2d_dcov2ds=ci[2])
+    return us, ci[0], col[0], depths, J
+
+
+def test_full_size_fused_and_raw_paths(gsc, big):
+    """BASELINE configs[1]/[2] on the path bench.py times: ``GSFunction`` in mode "fused" (k_preprocess_fwd,
+    record-only draw, k_draw_bwd, k_preprocess_bwd) at 1 M Gaussians / 1920x1080 against the float64 oracle --
+    image on 24 sampled tiles (re-blended by O.draw from the oracle's OWN 2D Gaussians and the device's tile
+    lists), and all five parameter-gradient tensors for the Gaussians whose every patch lies inside six sampled
+    tiles (O.draw_backward + O.chain_rule).  Then ``GSRawFunction`` (activations inside the kernels) against the
+    fused path chained through torch's activations, over all 1 M rows."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import Camera, GSFunction, GSRawFunction
+    gsc.set_policy("gsplatcu")
+    sc = big
+    cam = Camera.from_scene(sc.cam)
+    W, H = sc.cam.width, sc.cam.height
+    GSFunction.mode = "fused"
+    P = dict(pws=dev(sc.pws), shs=dev(sc.shs), alphas=dev(sc.alphas).reshape(-1, 1), scales=dev(sc.scales),
+             rots=dev(sc.rots))
+    for p in P.values():
+        p.requires_grad_(True)
+    dl = S.normal(8, 1, (3, H, W)).astype(np.float32) / (H * W)
+    img_t, mask_t, st = fused.forward(P["pws"].detach(), P["shs"].detach(), P["alphas"].detach(), P["scales"].detach(),
+                                      P["rots"].detach(), cam)       # the state (tile lists) of the same render
+    rg, gs = host(st.ranges), host(st.gsid)
+    hcont, htau = host(st.contrib), host(st.final_tau)
+    us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+    image, mask = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+    image.backward(dev(dl))
+    assert torch.equal(image, img_t)
+    him = host(image)
+    T = rg.shape[0]
+    sel = (S.uniform01(4, 2, (24,)) * T).astype(np.int64)
+    o_us, o_ci, o_col, o_depths = _oracle_2d(sc, sc.cam)
+    assert np.array_equal(host(mask), o_depths > 0.2)
+    alphas64 = sc.alphas.astype(np.float64)
+    o_img, o_cont, o_tau = O.draw(W, H, rg, gs, o_us, o_ci, alphas64, o_col, None, O.POLICY_G, tiles=sel)
+    gx = (W + 15) // 16
+    nflip = 0
+    for t in sel:
+        ty, tx = divmod(int(t), gx)
+        ys = slice(ty * 16, min(ty * 16 + 16, H)); xs = slice(tx * 16, tx * 16 + 16)
+        d = np.abs(him[:, ys, xs] - o_img[:, ys, xs]).max(0)
+        flip = (hcont[ys, xs] != o_cont[ys, xs]) | (d >= 1e-4)
+        nflip += int(flip.sum())
+        assert d[~flip].max() < 1e-4 and d.max() < 5e-3
+    assert nflip <= 12, nflip                                          # threshold flips (fp32 vs fp64 2D Gaussians)
+    # gradients: Gaussians complete inside six sampled tiles
+    sub = sel[:6]
+    o_g2 = O.draw_backward(W, H, rg, gs, o_us, o_ci, alphas64, o_col, hcont, htau, dl.astype(np.float64), None,
+                           O.POLICY_G, tiles=sub)
+    allp = np.zeros(sc.n, np.int64); np.add.at(allp, gs, 1)
+    inp = np.zeros(sc.n, np.int64)
+    for t in sub:
+        np.add.at(inp, gs[rg[t, 0]:rg[t, 1]], 1)
+    full = np.nonzero((inp > 0) & (allp == inp))[0]
+    assert full.size > 20
+    _, _, _, _, J = _oracle_2d(sc, sc.cam, full, True)
+    g = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], sc.cam.Rcw, J)
+    want = dict(pws=g["dpws"], shs=g["dshs"], alphas=g["dalphas"][:, None], scales=g["dscales"], rots=g["drots"],
+                us=o_g2[0][full])
+    got = {k: host(v.grad)[full] for k, v in P.items()} | {"us": host(us0.grad)[full]}
+    for k in want:
+        assert got[k].shape == want[k].shape, k
+        assert close(got[k], want[k], 2e-4), (k, np.abs(got[k] - want[k]).max(), np.abs(want[k]).max())
+        assert np.abs(want[k]).max() > 0, k
+    # --- raw path at the same size: activations inside the kernels == torch activations around the fused path
+    a = torch.from_numpy(sc.alphas.astype(np.float32)).clamp(1e-4, 1 - 1e-4)
+    raw = dict(pws=dev(sc.pws), low_shs=dev(sc.shs[:, :3]), high_shs=dev(sc.shs[:, 3:]),
+               alphas_raw=torch.log(a / (1 - a)).reshape(-1, 1).cuda(), scales_raw=torch.log(dev(sc.scales)),
+               rots_raw=dev(sc.rots) * 1.7)
+    names = ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")
+
+    def run(use_raw):
+        p = {k: v.clone().requires_grad_(True) for k, v in raw.items()}
+        us = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+        if use_raw:
+            img, m = GSRawFunction.apply(*[p[k] for k in names], us, cam)
+        else:
+            img, m = GSFunction.apply(p["pws"], torch.cat((p["low_shs"], p["high_shs"]), 1),
+                                      torch.sigmoid(p["alphas_raw"]), torch.exp(p["scales_raw"]),
+                                      torch.nn.functional.normalize(p["rots_raw"]), us, cam)
+        img.backward(dev(dl))
+        return host(img), {k: host(p[k].grad) for k in names}
+    img_a, ga = run(False)
+    img_b, gb = run(True)
+    assert np.abs(img_a - img_b).max() < 2e-5
+    assert np.abs(img_a - him).max() < 2e-4          # (sigmoid(logit(alpha)) and q*1.7 normalised: the same scene)
+    for k in names:
+        scale = max(1.0, float(np.abs(ga[k]).max()))
+        assert np.abs(ga[k] - gb[k]).max() <= 2e-4 * scale, (k, np.abs(ga[k] - gb[k]).max(), scale)
+        bigm = np.abs(ga[k]) > 1e-3 * np.abs(ga[k]).max()
+        assert np.median(np.abs(ga[k][bigm] - gb[k][bigm]) / np.abs(ga[k][bigm])) < 1e-4, k
+
+
 def test_full_size_forward_cpu_reference_digest(gsc, big):
     """The REFERENCE's forward_cpu.py image at 1 M Gaussians / 1920x1080 (fixture G6: per-tile
     mean RGB + 64 full tiles) vs the HIP path under set_policy('forward_cpu')."""

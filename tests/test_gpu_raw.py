@@ -63,9 +63,10 @@ def test_raw_function_matches_torch_activations(K):
             assert np.median(np.abs(a[big] - b[big]) / np.abs(a[big])) < 1e-4, k
 
 
-def test_raw_function_full_size_step_and_trainer_equivalence():
-    """1 M Gaussians: same image as the torch-activation path; and one Trainer step with either path moves the
-    parameters identically (Adam normalises the gradient, so this is a strict check of its direction)."""
+def test_raw_function_trainer_equivalence_20k():
+    """20 k Gaussians, two views: three Trainer steps with the activations inside the kernels or in torch move
+    the parameters identically (Adam normalises the gradient, so this is a strict check of its direction).
+    (The 1 M / 1080p comparison of the two paths is tests/test_gpu_parity.py::test_full_size_fused_and_raw_paths.)"""
     from easygaussiansplatting_amd import scene as S
     from easygaussiansplatting_amd.function import Camera, render
     from easygaussiansplatting_amd.trainer import Trainer

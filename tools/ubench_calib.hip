@@ -12,7 +12,8 @@
 #define ITERS 4096
 
 namespace egs {
-enum { FMA, EXP, RCP, SWAP32, SWAP16, DPPADD, CNDMASK, READLANE, MOV64, MED3, CMPS, NOPS };
+enum { FMA, EXP, RCP, SWAP32, SWAP16, DPPADD, CNDMASK, READLANE, MOV64, MED3, CMPS, SWZ, BPERM, DPPMASK, VMIN, MOV32, CMPX,
+       SWZADD, FMAC, NOPS };
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
@@ -20,6 +21,7 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
 #pragma unroll
   for (int i = 0; i < CHAINS; ++i) { a[i] = seed + i + threadIdx.x * 1e-3f; b[i] = seed * 0.5f + i; }
   float c = seed * 1.0001f;
+  const int addr = ((threadIdx.x & 63) ^ 32) * 4;
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) {
@@ -34,6 +36,17 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
       if (OP == MOV64) asm volatile("v_mov_b64 %0, 0" : "=v"(*(double*)&a[i & ~1]));
       if (OP == MED3) asm volatile("v_med3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
       if (OP == CMPS) asm volatile("v_cmp_lt_f32 s[24:25], %0, %1" :: "v"(a[i]), "v"(c) : "s24", "s25");
+      // LDS crossbar exchanges (no VALU slot): lane ^ 16 by swizzle (immediate pattern), lane ^ 32 by bpermute
+      if (OP == SWZ) asm volatile("ds_swizzle_b32 %0, %0 offset:swizzle(BITMASK_PERM, \"0000p\")" : "+v"(a[i]));
+      if (OP == BPERM) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(a[i]) : "v"(addr));
+      if (OP == DPPMASK) asm volatile("v_add_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:0xc bank_mask:0xf" : "+v"(a[i]) : "v"(b[i]), "v"(c));
+      if (OP == VMIN) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
+      if (OP == MOV32) asm volatile("v_mov_b32 %0, 0" : "=v"(a[i]));
+      if (OP == CMPX) asm volatile("v_cmpx_lt_f32 vcc, %0, %1\n s_mov_b64 exec, -1" :: "v"(a[i]), "v"(c) : "vcc");
+      // the exchange + add pair of the reduction: swizzle, then a full-rate add of the returned value
+      if (OP == SWZADD) { float t; asm volatile("ds_swizzle_b32 %0, %1 offset:swizzle(BITMASK_PERM, \"0000p\")" : "=v"(t) : "v"(b[i]));
+                          asm volatile("s_waitcnt lgkmcnt(0)\n v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(t)); }
+      if (OP == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
     }
   }
   float s = 0;
@@ -66,5 +79,8 @@ int main() {
   run<egs::SWAP32>("swap32", d); run<egs::SWAP16>("swap16", d); run<egs::DPPADD>("add_dpp", d);
   run<egs::CNDMASK>("cndmask", d); run<egs::READLANE>("readlane", d); run<egs::MOV64>("mov_b64", d);
   run<egs::MED3>("med3", d); run<egs::CMPS>("cmp->sgpr", d);
+  run<egs::SWZ>("ds_swizzle", d); run<egs::BPERM>("ds_bpermute", d); run<egs::DPPMASK>("add_dpp_rowmask", d);
+  run<egs::VMIN>("v_min", d); run<egs::MOV32>("mov_b32", d); run<egs::CMPX>("cmpx+exec", d);
+  run<egs::SWZADD>("swizzle+wait+add", d); run<egs::FMAC>("v_fmac", d);
   return 0;
 }
