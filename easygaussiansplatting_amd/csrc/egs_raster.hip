@@ -871,59 +871,36 @@ __device__ __forceinline__ float rows_to_lanes9(const float (&q)[9], int c16) {
   return merge2<M1>(r, s8, h1);
 }
 
-// ---- the same reduction with the cross-row exchanges on the LDS crossbar ---------------------------------
-// Measured on gfx950 (tools/ubench_calib.hip, cycles per wave instruction): add / mul / fma 2.5 (full rate);
-// DPP, v_cndmask, v_med3, v_cmp, v_readlane, v_mov_b64 4.3 (half rate); v_permlane{32,16}_swap, v_exp, v_rcp
-// 8.6 (quarter rate).  The swap-based form above spends 27 quarter-rate swaps and 16 v_cndmask per group of four
-// entries.  Here lane ^ 32 and lane ^ 16 travel through ds_bpermute / ds_swizzle (LDS pipe, no VALU issue slot:
-// it idles otherwise) and every merge is one full-rate add plus one row-masked add; inside the rows the
-// first two levels pair lanes that differ in bit 0 / bit 1, where DPP's bank mask selects the lane class (no
-// v_cndmask), only the last two levels (three merges) still select.
-__device__ __forceinline__ float xchg32(float v, int addr32) {   // lane ^ 32; addr32 = 4 * (lane ^ 32)
-  return __int_as_float(__builtin_amdgcn_ds_bpermute(addr32, __float_as_int(v)));
-}
-__device__ __forceinline__ float xchg16(float v) {               // lane ^ 16: bit-mode swizzle, xor mask 0x10
-  return __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), (0x10 << 10) | 0x1f));
-}
-// acc = x + y on the rows (16 lanes each) of ROW_MASK, unchanged elsewhere
-template <int ROW_MASK>
-__device__ __forceinline__ void add_rows(float& acc, float x, float y) {
-  asm("v_add_f32_dpp %0, %1, %2 quad_perm:[0,1,2,3] row_mask:%3 bank_mask:0xf" : "+v"(acc) : "v"(x), "v"(y), "n"(ROW_MASK));
-}
-__device__ __forceinline__ float rows_of4_lds(float e0, float e1, float e2, float e3, int addr32) {
-  const float t0 = xchg32(e0, addr32), t1 = xchg32(e1, addr32), t2 = xchg32(e2, addr32), t3 = xchg32(e3, addr32);
-  float s01 = e0 + t0;            // rows 0,1: the two halves of e0 summed
-  add_rows<0xc>(s01, e1, t1);     // rows 2,3: e1
-  float s23 = e2 + t2;
-  add_rows<0xc>(s23, e3, t3);
-  const float u0 = xchg16(s01), u1 = xchg16(s23);
-  float r = s01 + u0;             // rows 0 / 2: e0 / e1
-  add_rows<0xa>(r, s23, u1);      // rows 1 / 3: e2 / e3  -> rows hold entries [0, 2, 1, 3] like rows_of4
-  return r;
-}
-// out = a + a[partner] everywhere, then b + b[partner] on the lanes of BANK_HI (banks = lane % 4)
-template <int QUAD_PERM, int BANK_HI>
-__device__ __forceinline__ float merge_bank(float a, float b) {
-  float out;
-  asm("v_add_f32_dpp %0, %1, %1 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:0xf"
-      : "=v"(out) : "v"(a), "n"(QUAD_PERM & 3), "n"((QUAD_PERM >> 2) & 3), "n"((QUAD_PERM >> 4) & 3), "n"((QUAD_PERM >> 6) & 3));
-  asm("v_add_f32_dpp %0, %1, %1 quad_perm:[%2,%3,%4,%5] row_mask:0xf bank_mask:%6"
-      : "+v"(out) : "v"(b), "n"(QUAD_PERM & 3), "n"((QUAD_PERM >> 2) & 3), "n"((QUAD_PERM >> 4) & 3), "n"((QUAD_PERM >> 6) & 3),
-        "n"(BANK_HI));
-  return out;
-}
-// the nine row-wise totals: q_c in lane c (c = 0..7) of every row, q_8 in lanes 8..15
+// ---- the in-row stage without selects ----------------------------------------------------------------------
+// Measured on gfx950 (tools/ubench_calib.hip, cycles per wave instruction per SIMD): add / mul / fma 2.5 (full
+// rate); DPP, v_cndmask, v_med3, v_min/max, v_cmp, v_readlane, v_mov_b64 4.3 (half rate); v_permlane{32,16}_swap,
+// v_exp, v_rcp 8.4 (quarter rate); ds_swizzle 8.2 and ds_bpermute 24 (the LDS crossbar is shared by the four SIMDs
+// of a CU: moving the cross-row exchanges there was measured 10 % SLOWER, so they stay v_permlane swaps).
+// merge2 above costs two v_cndmask and a DPP add.  The first two levels split the row by lane bits 3 and 2 --
+// exactly what DPP's bank mask addresses (a bank = four consecutive lanes of a row): one DPP add for everybody,
+// one bank-masked DPP add for the lanes that reduce the second register; no select.
+// out = a + a[mirror] everywhere, then b + b[mirror] on the banks of `bank_hi`
+#define EGS_MERGE_BANK(out, a, b, ctrl, bank_hi)                                                              \
+  do {                                                                                                        \
+    asm("v_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:0xf" : "=v"(out) : "v"(a));                  \
+    asm("v_add_f32_dpp %0, %1, %1 " ctrl " row_mask:0xf bank_mask:" bank_hi : "+v"(out) : "v"(b));            \
+  } while (0)
+// same result layout as rows_to_lanes9: totals in lanes {0, 8, 4, 12, 2, 10, 6, 14, odd} of every row
 __device__ __forceinline__ float rows_to_lanes9_bank(const float (&q)[9], int c16) {
-  const bool h8 = (c16 & 8) != 0, h4 = (c16 & 4) != 0;
-  constexpr int X1 = 0xB1, X2 = 0x4E, M4 = 0x141, M8 = 0x140;  // quad [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror
-  const float p01 = merge_bank<X1, 0xA>(q[0], q[1]), p23 = merge_bank<X1, 0xA>(q[2], q[3]);
-  const float p45 = merge_bank<X1, 0xA>(q[4], q[5]), p67 = merge_bank<X1, 0xA>(q[6], q[7]);
-  float s8 = q[8] + dpp_get<X1>(q[8]);
-  const float a = merge_bank<X2, 0xC>(p01, p23), b = merge_bank<X2, 0xC>(p45, p67);
-  s8 += dpp_get<X2>(s8);
-  const float r = merge2<M4>(a, b, h4);
+  const bool h2 = (c16 & 2) != 0, h1 = (c16 & 1) != 0;
+  constexpr int M8 = 0x140, M4 = 0x141, M2 = 0x4E, M1 = 0xB1;
+  float p01, p23, p45, p67, a, b;
+  EGS_MERGE_BANK(p01, q[0], q[1], "row_mirror", "0xc");        // lanes 8..15 (banks 2, 3) reduce the second one
+  EGS_MERGE_BANK(p23, q[2], q[3], "row_mirror", "0xc");
+  EGS_MERGE_BANK(p45, q[4], q[5], "row_mirror", "0xc");
+  EGS_MERGE_BANK(p67, q[6], q[7], "row_mirror", "0xc");
+  float s8 = q[8] + dpp_get<M8>(q[8]);
+  EGS_MERGE_BANK(a, p01, p23, "row_half_mirror", "0xa");       // lanes 4..7, 12..15 (banks 1, 3)
+  EGS_MERGE_BANK(b, p45, p67, "row_half_mirror", "0xa");
   s8 += dpp_get<M4>(s8);
-  return merge2<M8>(r, s8, h8);
+  const float r = merge2<M2>(a, b, h2);
+  s8 += dpp_get<M2>(s8);
+  return merge2<M1>(r, s8, h1);
 }
 
 // Per-tile back-to-front gradient pass.  One wave64 per 16x16 tile walked as four 8x8
@@ -993,27 +970,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
   const int c16 = lane & 15;
   int qoff = -1, kind = 0;
   float kscale = 1.f;
-  if (RED == 0) {   // swap-based reduction: totals in lanes {0, 8, 4, 12, 2, 10, 6, 14, 1}
-    if (c16 & 1) { if (c16 == 1) { qoff = 8; kscale = -0.5f; } }          // M2yy -> dcinv.z
-    else if (c16 == 0) { qoff = 4; kind = 1; }                            // M1x  -> du.x
-    else if (c16 == 2) { qoff = 5; kind = 2; }                            // M1y  -> du.y
-    else if (c16 == 4) qoff = 0;                                          // dalpha
-    else if (c16 == 6) qoff = 1;                                          // dcolor.r
-    else if (c16 == 8) qoff = 2;                                          // dcolor.g
-    else if (c16 == 10) qoff = 3;                                         // dcolor.b
-    else if (c16 == 12) { qoff = 6; kscale = -0.5f; }                     // M2xx -> dcinv.x
-    else { qoff = 7; kscale = -1.f; }                                     // M2xy -> dcinv.y  (lane 14)
-  } else {          // crossbar reduction: leaf q_c in lane c (c < 8), q_8 in lane 8
-    //   lane 0: M1x  1: dalpha  2: M1y  3,4,5: dcolor  6: M2xx  7: M2xy  8: M2yy
-    if (c16 == 0) { qoff = 4; kind = 1; }
-    else if (c16 == 1) qoff = 0;
-    else if (c16 == 2) { qoff = 5; kind = 2; }
-    else if (c16 <= 5) qoff = c16 - 2;
-    else if (c16 == 6) { qoff = 6; kscale = -0.5f; }
-    else if (c16 == 7) { qoff = 7; kscale = -1.f; }
-    else if (c16 == 8) { qoff = 8; kscale = -0.5f; }
-  }
-  const int addr32 = (lane ^ 32) << 2;   // ds_bpermute address of the lane in the other half (RED == 1)
+  if (c16 & 1) { if (c16 == 1) { qoff = 8; kscale = -0.5f; } }          // M2yy -> dcinv.z
+  else if (c16 == 0) { qoff = 4; kind = 1; }                            // M1x  -> du.x
+  else if (c16 == 2) { qoff = 5; kind = 2; }                            // M1y  -> du.y
+  else if (c16 == 4) qoff = 0;                                          // dalpha
+  else if (c16 == 6) qoff = 1;                                          // dcolor.r
+  else if (c16 == 8) qoff = 2;                                          // dcolor.g
+  else if (c16 == 10) qoff = 3;                                         // dcolor.b
+  else if (c16 == 12) { qoff = 6; kscale = -0.5f; }                     // M2xx -> dcinv.x
+  else { qoff = 7; kscale = -1.f; }                                     // M2xy -> dcinv.y  (lane 14)
 
   const int c_first = (maxcont - 1) >> 6;
   int gnext = (c_first * 64 + lane < n) ? gsid[r0 + c_first * 64 + lane] : 0;   // one chunk ahead, as in k_draw
@@ -1126,14 +1091,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         // quantity order chosen so that the two first moments meet in one quad (lanes 0 and 2):
         //   lane 0: M1x  2: M1y  4: dalpha  6,8,10: dcolor  12: M2xx  14: M2xy  odd: M2yy
         float rows[9];
-        // acc index feeding leaf q0..q8 (RED 0 / RED 1: see the lane tables above)
-        constexpr int ORDER0[9] = {4, 2, 0, 6, 5, 3, 1, 7, 8}, ORDER1[9] = {4, 0, 5, 1, 2, 3, 6, 7, 8};
+        constexpr int ORDER[9] = {4, 2, 0, 6, 5, 3, 1, 7, 8};   // acc index feeding leaf q0..q8
 #pragma unroll
-        for (int q = 0; q < 9; ++q) {
-          const int a = RED == 0 ? ORDER0[q] : ORDER1[q];
-          rows[q] = RED == 0 ? rows_of4(acc[0][a], acc[1][a], acc[2][a], acc[3][a])
-                             : rows_of4_lds(acc[0][a], acc[1][a], acc[2][a], acc[3][a], addr32);
-        }
+        for (int q = 0; q < 9; ++q)
+          rows[q] = rows_of4(acc[0][ORDER[q]], acc[1][ORDER[q]], acc[2][ORDER[q]], acc[3][ORDER[q]]);
         const float v = RED == 0 ? rows_to_lanes9(rows, c16) : rows_to_lanes9_bank(rows, c16);
         // row r of the wave holds the totals of slot e = {0,2,1,3}[r]
         const int row = lane >> 4;
@@ -1538,8 +1499,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s);
     if (rc) return rc;
   }
-  // reduction flavour of the backward kernel (0: permlane swaps, 1: LDS crossbar + bank-masked DPP); EGS_DRAWB_RED
-  // overrides (A/B knob)
+  // in-row stage of the backward kernel's wave reduction (0: select-based merges, 1: bank-masked DPP adds);
+  // EGS_DRAWB_RED overrides (A/B knob)
   static const int red = [] { const char* e = getenv("EGS_DRAWB_RED"); return e ? atoi(e) : EGS_DRAWB_RED_DEFAULT; }();
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   do {                                                                                                    \
