@@ -88,9 +88,13 @@ struct BinParams {
   int W, H, gx, gy;
   int footprint, far_cull, depth_key, mutate;
 };
+// tile rect of one Gaussian packed in 8 bytes: {x0 | y0 << 16, w | h << 16} (tiles; w * h = its patch count)
+__host__ __device__ inline uint2 pack_rect(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
+  return make_uint2(x0 | (y0 << 16), (x1 - x0) | ((y1 - y0) << 16));
+}
 struct BinCountOut {  // where k_bin_count's results live inside the bin workspace
-  uint4* rects;
-  uint32_t *counts, *dkeys, *ids, *maxkey;  // maxkey[1 + workgroup] = per-workgroup maximum of the depth keys
+  uint2* rc;                       // packed rect (+ implied count) per Gaussian
+  uint32_t *dkeys, *ids, *maxkey;  // maxkey[1 + workgroup] = per-workgroup maximum of the depth keys
 };
 BinParams make_bin_params(int width, int height, const EgsPolicy* pol);
 bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out);

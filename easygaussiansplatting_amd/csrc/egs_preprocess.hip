@@ -433,14 +433,13 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
         radius_f(c2.c, pp.radius_mode, rx, ry);
       }
     }
-    if (bo.rects) {  // getRects + depth key of the binning stage, straight from registers (no k_bin_count pass)
+    if (bo.rc) {  // getRects + depth key of the binning stage, straight from registers (no k_bin_count pass)
       uint4 rect;
       bool cull;
       const uint32_t cnt = bin_count_one(bp, u0, u1, (float)rx, (float)ry, depth, rect, dkey, cull);
       if (cull) { depth = EGS_BAD_MARKER; rx = 0; ry = 0; }  // in-place contract of splat (kernel.cu:114-119)
       bo.ids[i] = (uint32_t)i;
-      bo.rects[i] = rect;
-      bo.counts[i] = cnt;
+      bo.rc[i] = cnt ? pack_rect(rect.x, rect.y, rect.z, rect.w) : make_uint2(0u, 0u);
       bo.dkeys[i] = dkey;
     }
     // us / cinv2ds / colors / areas are only needed by callers that go on with the seven-op surface; the
@@ -455,7 +454,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
       make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alphas[i]) : alphas[i], col[0], col[1], col[2], rx, ry,
                   pp.W, pp.H, pp.footprint, pp.alpha_skip, r);
   }
-  if (bo.rects) block_max_key(dkey, bo.maxkey);
+  if (bo.rc) block_max_key(dkey, bo.maxkey);
   // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
   if (rec) stage_rows_out<12>(reinterpret_cast<const float*>(r), reinterpret_cast<float*>(rec), n, blockIdx.x * 256, stage);
 }

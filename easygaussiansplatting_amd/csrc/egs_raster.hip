@@ -322,7 +322,7 @@ static int exclusive_scan(int64_t n, const uint32_t* in, const uint32_t* gather,
 // kernel (egs_preprocess.hip) does the same through bin_count_one and skips this launch
 __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const float* __restrict__ us,
                                                    int32_t* __restrict__ areas, float* __restrict__ depths,
-                                                   uint4* __restrict__ rects, uint32_t* __restrict__ counts,
+                                                   uint2* __restrict__ rc,
                                                    uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
                                                    uint32_t* __restrict__ maxkey) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -338,8 +338,7 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
       areas[2 * (size_t)i + 1] = 0;
     }
     ids[i] = (uint32_t)i;
-    rects[i] = rect;
-    counts[i] = cnt;
+    rc[i] = cnt ? pack_rect(rect.x, rect.y, rect.z, rect.w) : make_uint2(0u, 0u);
     dkeys[i] = key;
   }
   block_max_key(key, maxkey);  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
@@ -361,6 +360,72 @@ __global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __rest
   }
 }
 
+// ---- offsets of the Gaussians' patch runs, in depth order -------------------------------------------------
+// The depth sort moves (key, id) pairs only; what the binning needs of a Gaussian afterwards is its packed
+// rect (8 bytes).  It is gathered ONCE, by the first scan kernel, into depth order (rc_sorted); the second scan
+// kernel and k_bin_emit then stream contiguous arrays.  (The first version gathered counts[ids[j]] in both scan
+// kernels and rects[ids[j]] in k_bin_emit: three dependent gathers through the sorted ids, 2.6-4x the
+// algorithmic traffic by the PMC counters.)
+__device__ __forceinline__ uint32_t rc_count(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
+
+__global__ __launch_bounds__(256) void k_bin_scan_partials(const uint32_t* __restrict__ ids,
+                                                           const uint2* __restrict__ rc, int64_t n,
+                                                           uint2* __restrict__ rc_sorted,
+                                                           uint32_t* __restrict__ partials) {
+  __shared__ uint32_t sm[4];
+  const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
+  uint32_t s = 0;
+  uint2 r[SC_IPT];
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {      // all gathers in flight before the first use
+    const int64_t i = base + k;
+    r[k] = (i < n) ? rc[ids[i]] : make_uint2(0u, 0u);
+  }
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {
+    const int64_t i = base + k;
+    if (i < n) rc_sorted[i] = r[k];
+    s += rc_count(r[k]);
+  }
+  s = wave_inclusive_scan(s);
+  if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__global__ __launch_bounds__(256) void k_bin_scan_apply(const uint2* __restrict__ rc_sorted, int64_t n,
+                                                        const uint32_t* __restrict__ partials,
+                                                        uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
+  __shared__ uint32_t sm[4];
+  __shared__ uint32_t s_prefix;
+  uint32_t pre = 0;
+  for (int i = threadIdx.x; i < (int)blockIdx.x; i += 256) pre += partials[i];
+  pre = wave_inclusive_scan(pre);
+  if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = pre;
+  __syncthreads();
+  if (threadIdx.x == 0) s_prefix = sm[0] + sm[1] + sm[2] + sm[3];
+  __syncthreads();
+  const uint32_t prefix = s_prefix;
+  const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
+  uint32_t v[SC_IPT];
+  uint32_t s = 0;
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {
+    const int64_t i = base + k;
+    v[k] = (i < n) ? rc_count(rc_sorted[i]) : 0u;
+    s += v[k];
+  }
+  uint32_t blocksum;
+  uint32_t ex = block256_exclusive_scan(s, sm, &blocksum) + prefix;
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prefix + blocksum;
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) {
+    const int64_t i = base + k;
+    if (i < n) out[i] = ex;
+    ex += v[k];
+  }
+}
+
 // createKeys (reference kernel.cu:46-80) in depth-sorted Gaussian order; the depth half of the key is
 // implicit in the emission order.  The reference (and the first version here) lets every thread loop over
 // its own rect: lanes idle while the largest rect of the wave finishes and every store instruction is 64
@@ -369,7 +434,7 @@ __global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __rest
 // search over the 256 offsets in LDS, so all lanes work and consecutive lanes write consecutive addresses.
 __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t* __restrict__ ids,
                                                   const uint32_t* __restrict__ offsets,
-                                                  const uint4* __restrict__ rects,
+                                                  const uint2* __restrict__ rc_sorted,
                                                   uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid,
                                                   uint32_t cap, int32_t* __restrict__ ranges, int n_ranges) {
   __shared__ uint32_t s_off[257];   // offsets relative to the workgroup's first one; [256] = span length
@@ -379,12 +444,13 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
   // tiles without patches keep (0, 0): k_tile_ranges, three sorts further down the stream, only writes the
   // tiles that have some -- zeroed here instead of by a separate 5-us fill in front of this kernel
   for (int i = j; i < n_ranges; i += gridDim.x * 256) ranges[i] = 0;
-  uint32_t off = 0, cnt = 0, g = 0, x0 = 0, y0 = 0, w = 1;
+  uint32_t off = 0, cnt = 0, g = 0, xy = 0, w = 1;
   if (j < n) {
     g = ids[j];
-    const uint4 r = rects[g];
+    const uint2 r = rc_sorted[j];
     off = offsets[j];
-    if (r.z > r.x && r.w > r.y) { x0 = r.x; y0 = r.y; w = r.z - r.x; cnt = w * (r.w - r.y); }
+    cnt = rc_count(r);
+    if (cnt) { xy = r.x; w = r.y & 0xFFFFu; }
   }
   // first offset of the workgroup (thread 0 always has a valid j) and the span length
   __shared__ uint32_t s_first, s_last;
@@ -395,7 +461,7 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
   const uint32_t first = s_first;
   s_off[tid] = (j < n) ? off - first : 0xFFFFFFFFu;   // lanes past the end never own a slot
   s_g[tid] = g;
-  s_xy[tid] = x0 | (y0 << 16);
+  s_xy[tid] = xy;
   s_w[tid] = w;
   const uint32_t span = s_last - first;
   __syncthreads();
@@ -407,10 +473,10 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
     for (int step = 128; step >= 1; step >>= 1)
       if (s_off[lo + step] <= s0) lo += step;     // s_off[lo + step] with lo + step <= 255
     const uint32_t r = s0 - s_off[lo];
-    const uint32_t ww = s_w[lo], xy = s_xy[lo];
+    const uint32_t ww = s_w[lo], xy0 = s_xy[lo];
     const uint32_t ry = r / ww, rx = r - ry * ww;
     if (first + s0 >= cap) break;   // (only when the buffers were sized from an earlier call: see egs_splat_draw_rec_dev)
-    tkeys[first + s0] = ((xy >> 16) + ry) * (uint32_t)gx + (xy & 0xFFFFu) + rx;
+    tkeys[first + s0] = ((xy0 >> 16) + ry) * (uint32_t)gx + (xy0 & 0xFFFFu) + rx;
     gsid[first + s0] = s_g[lo];
   }
 }
@@ -1134,20 +1200,20 @@ __global__ __launch_bounds__(256) void k_unpack_grads(int n, const float4* __res
 // host orchestration
 // ============================================================================
 struct BinLayout {
-  uint4* rects;
-  uint32_t *counts, *dkeys, *dkeys_alt, *ids, *ids_alt, *offsets, *scan_partials, *maxkey;
+  uint2 *rc, *rc_sorted;   // packed rects in Gaussian order / in depth order
+  uint32_t *dkeys, *dkeys_alt, *ids, *ids_alt, *offsets, *scan_partials, *maxkey;
   SortWs sort;
 };
 static size_t bin_ws_bytes(int n) {
   const size_t N = (size_t)(n > 0 ? n : 1);
-  return align_up(N * 16, 256) + 6 * align_up(N * 4, 256) + scan_ws_bytes(n) + sort_ws_bytes(n) +
+  return 2 * align_up(N * 8, 256) + 5 * align_up(N * 4, 256) + scan_ws_bytes(n) + sort_ws_bytes(n) +
          align_up((64 + N / 256 + 1) * 4, 256) + 4096;
 }
 static bool bin_carve(void* ws, size_t bytes, int n, BinLayout* L) {
   Carver cv(ws, bytes);
   const size_t N = (size_t)(n > 0 ? n : 1);
-  L->rects = cv.take<uint4>(N);
-  L->counts = cv.take<uint32_t>(N);
+  L->rc = cv.take<uint2>(N);
+  L->rc_sorted = cv.take<uint2>(N);
   L->dkeys = cv.take<uint32_t>(N);
   L->dkeys_alt = cv.take<uint32_t>(N);
   L->ids = cv.take<uint32_t>(N);
@@ -1296,8 +1362,8 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
     return EGS_ERR_WORKSPACE;
   }
   const BinParams p = make_bin_params(width, height, pol);
-  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rects,
-             L.counts, L.dkeys, L.ids, L.maxkey);
+  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rc,
+             L.dkeys, L.ids, L.maxkey);
   EGS_LAUNCH_OK();
   return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
 }
@@ -1315,7 +1381,7 @@ BinParams make_bin_params(int width, int height, const EgsPolicy* pol) {
 bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out) {
   BinLayout L;
   if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) return false;
-  out->rects = L.rects; out->counts = L.counts; out->dkeys = L.dkeys; out->ids = L.ids; out->maxkey = L.maxkey;
+  out->rc = L.rc; out->dkeys = L.dkeys; out->ids = L.ids; out->maxkey = L.maxkey;
   return true;
 }
 
@@ -1340,7 +1406,13 @@ int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_
     EGS_HIP(hipMemcpyAsync(L.dkeys, L.dkeys_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     EGS_HIP(hipMemcpyAsync(L.ids, L.ids_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   }
-  return exclusive_scan(n, L.counts, L.ids, L.offsets, total_patches, L.scan_partials, s);
+  const int nb = div_up(n, SC_TILE);
+  EGS_LAUNCH("k_bin_scan_partials", k_bin_scan_partials, dim3(nb), dim3(256), s, L.ids, L.rc, (int64_t)n, L.rc_sorted,
+             L.scan_partials);
+  EGS_LAUNCH("k_bin_scan_apply", k_bin_scan_apply, dim3(nb), dim3(256), s, L.rc_sorted, (int64_t)n, L.scan_partials,
+             L.offsets, total_patches);
+  EGS_LAUNCH_OK();
+  return 0;
 }
 }  // namespace egs
 
@@ -1383,7 +1455,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   uint32_t* k1 = (passes & 1) ? D.tkeys : D.tkeys_alt;
   uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
-  EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rects, k0,
+  EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rc_sorted, k0,
                      v0, (uint32_t)patches, patch_range_per_tile, 2 * dp.T);
   const float4* rec = rec_in ? rec_in : D.rec;
   if (!rec_in)

@@ -553,7 +553,7 @@ def _oracle_2d(sc, cam, rows=None, calc_J=False):
     col = O.sh2color(sc.shs[sel], sc.pws[sel], cam.twc, calc_J)
     ci = O.inverse_cov2d((c2[0] if calc_J else c2), depths.copy(), P, calc_J)
     if not calc_J:
-        return us, ci[0], col, depths
+        return us, ci[0], col, depths, ci[1]
     J = dict(du_dpcs=out[3], dcov3d_drots=c3[1], dcov3d_dscales=c3[2], dcov2d_dcov3ds=c2[1], dcov2d_dpcs=c2[2],
              dcolor_dshs=col[1], dcolor_dpws=col[2], dcinv2d_dcov2ds=ci[2])
     return us, ci[0], col[0], depths, J
@@ -589,8 +589,13 @@ def test_full_size_fused_and_raw_paths(gsc, big):
     him = host(image)
     T = rg.shape[0]
     sel = (S.uniform01(4, 2, (24,)) * T).astype(np.int64)
-    o_us, o_ci, o_col, o_depths = _oracle_2d(sc, sc.cam)
-    assert np.array_equal(host(mask), o_depths > 0.2)
+    o_us, o_ci, o_col, o_depths, o_areas = _oracle_2d(sc, sc.cam)
+    # the mask is depths > 0.2 AFTER getRects marked the Gaussians without a tile (kernel.cu:114-119, gsmodel.py:50);
+    # float32 (device) vs float64 (oracle) centres may disagree on a Gaussian that just touches the image border
+    d_marked = o_depths.astype(np.float32).copy()
+    O.get_rects(o_us.astype(np.float32), o_areas.copy(), d_marked, W, H, O.POLICY_G)
+    hmask = host(mask)
+    assert (hmask != (d_marked > 0.2)).sum() <= 4 and 0 < (~hmask).sum() < sc.n // 2
     alphas64 = sc.alphas.astype(np.float64)
     o_img, o_cont, o_tau = O.draw(W, H, rg, gs, o_us, o_ci, alphas64, o_col, None, O.POLICY_G, tiles=sel)
     gx = (W + 15) // 16
