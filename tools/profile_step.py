@@ -52,9 +52,12 @@ for _ in range(a.steps):
         with torch.no_grad():
             render(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam)
     else:
-        for p in P.values():
-            p.grad = None
-        img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
-        img.backward(dl)
+        from easygaussiansplatting_amd import fused
+        with fused.deferred() as d:          # the step bench.py times: validation at commit(), not inside forward
+            for p in P.values():
+                p.grad = None
+            img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+            img.backward(dl)
+            assert not d.commit()
 torch.cuda.synchronize()
 print("done")
