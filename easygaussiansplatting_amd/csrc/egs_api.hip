@@ -169,6 +169,18 @@ extern "C" int egs_mailbox_post(void* mb, int slot, const uint32_t* total_patche
   return 0;
 }
 
+extern "C" uint32_t* egs_mailbox_slot(void* mb, int slot) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  return (m && slot >= 0 && slot < m->slots) ? m->host + 4 * (size_t)slot : nullptr;
+}
+
+extern "C" int egs_mailbox_mark(void* mb, int slot, void* stream) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots);
+  EGS_HIP(hipEventRecord(m->ev[slot], (hipStream_t)stream));
+  return 0;
+}
+
 extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out) {
   egs::Mailbox* m = (egs::Mailbox*)mb;
   if (!m || slot < 0 || slot >= m->slots || !out) {

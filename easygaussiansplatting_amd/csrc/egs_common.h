@@ -99,8 +99,9 @@ struct BinCountOut {  // where k_bin_count's results live inside the bin workspa
 BinParams make_bin_params(int width, int height, const EgsPolicy* pol);
 bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out);
 // everything of egs_splat_bin after k_bin_count (max reduce, depth sort, offsets scan)
+// host_totals (nullable): page-locked host uint32[2] the kernels ALSO write {P, max depth key} into (mailbox slot)
 int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                          void* stream);
+                          void* stream, uint32_t* host_totals);
 
 // splatB's draw pass into the packed [N][12] gradient records (egs_raster.hip); *gpack
 // points into `ws`.  Shared by egs_splat_bwd (+unpack) and egs_fused_backward.
@@ -109,7 +110,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                      float** gpack, void* stream, const void* rec_in /* packed records or NULL */,
-                     const int32_t* tile_order /* dispatch order left by the forward pass, or NULL */);
+                     const int32_t* tile_order /* dispatch order left by the forward pass, or NULL */,
+                     float* grad_records /* [N][12] records ALREADY ZEROED (by the forward draw kernel), or NULL */);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

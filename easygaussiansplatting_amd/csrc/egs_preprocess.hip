@@ -711,13 +711,15 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
                               const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
                               int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds,
                               float* colors, int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint,
-                              void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+                              void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals,
+                              void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {
     EGS_HIP(hipMemsetAsync(total_patches, 0, 8, s));
+    if (host_totals) EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, s));
     return 0;
   }
   EGS_CHECK_ARG(pws && rots && scales && shs && Rcw && tcw && twc && depths);
@@ -751,7 +753,7 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
 #undef EGS_PRE
   EGS_LAUNCH_OK();
   // the kernel above already did getRects + depth keys (k_bin_count of egs_splat_bin)
-  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
+  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, host_totals);
 }
 
 extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
@@ -759,10 +761,10 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
                                  const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                                  const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
                                  int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                                 size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+                                 size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream) {
   return fused_forward_impl(false, n, sh_dim, pws, rots, scales, shs, nullptr, alphas, Rcw, tcw, twc, fx, fy, cx, cy,
                             width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible, key_bits_hint,
-                            ws_bin, ws_bin_bytes, total_patches, stream);
+                            ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
 }
 
 extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots_raw,
@@ -771,11 +773,12 @@ extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const 
                                      float fx, float fy, float cx, float cy, int width, int height,
                                      const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
                                      int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                                     size_t ws_bin_bytes, uint32_t* total_patches, void* stream) {
+                                     size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals,
+                                     void* stream) {
   EGS_CHECK_ARG(n == 0 || (rec && alphas_raw));  // the activated alpha only exists inside the records
   return fused_forward_impl(true, n, sh_dim, pws, rots_raw, scales_raw, low_shs, high_shs, alphas_raw, Rcw, tcw, twc,
                             fx, fy, cx, cy, width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible,
-                            key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
+                            key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
 }
 
 extern "C" size_t egs_fused_backward_ws_bytes(int n) { return egs_splat_bwd_ws_bytes(n); }
@@ -789,8 +792,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
                                const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                float* dloss_dshs, float* dloss_dshs_high, float* dloss_dalphas, float* dloss_dscales,
-                               float* dloss_drots, float* dloss_dus, const int32_t* tile_order, int phase,
-                               int row_begin, int row_count, void* stream) {
+                               float* dloss_drots, float* dloss_dus, const int32_t* tile_order,
+                               float* grad_records, int phase, int row_begin, int row_count, void* stream) {
   // phase 0: everything; 1: only the draw pass (-> packed gradient records in ws); 2: only the per-Gaussian
   // chain rule, for rows [row_begin, row_begin + row_count) -- a data-parallel caller launches the rows in a
   // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
@@ -807,11 +810,12 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
     set_error(EGS_ERR_WORKSPACE, "fused_backward workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
-  float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));   // where splat_bwd_packed puts the records
+  // where splat_bwd_packed puts the records
+  float* gpack = grad_records ? grad_records : (float*)((char*)ws + align_up((size_t)n * 48, 256));
   if (phase != 2) {
     int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
                               patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec,
-                              tile_order);
+                              tile_order, grad_records);
     if (rc) return rc;
     if (phase == 1) return 0;
   }
@@ -853,13 +857,13 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
                                   const int32_t* patch_range_per_tile, const int32_t* gsid_per_patch,
                                   const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                   float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                                  float* dloss_drots, float* dloss_dus, const int32_t* tile_order, int phase,
-                                  int row_begin, int row_count, void* stream) {
+                                  float* dloss_drots, float* dloss_dus, const int32_t* tile_order,
+                                  float* grad_records, int phase, int row_begin, int row_count, void* stream) {
   return fused_backward_impl(false, n, sh_dim, patches, width, height, pws, rots, scales, shs, nullptr, alphas, Rcw,
                              tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths, contrib,
                              final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, dloss_dpws,
-                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, tile_order, phase,
-                             row_begin, row_count, stream);
+                             dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, tile_order,
+                             grad_records, phase, row_begin, row_count, stream);
 }
 
 extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
@@ -873,11 +877,11 @@ extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int wi
                                       const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                       float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                                       float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
-                                      const int32_t* tile_order, int phase, int row_begin, int row_count,
-                                      void* stream) {
+                                      const int32_t* tile_order, float* grad_records, int phase, int row_begin,
+                                      int row_count, void* stream) {
   return fused_backward_impl(true, n, sh_dim, patches, width, height, pws, rots_raw, scales_raw, low_shs, high_shs,
                              alphas_raw, Rcw, tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths,
                              contrib, final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes,
                              dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
-                             dloss_drots_raw, dloss_dus, tile_order, phase, row_begin, row_count, stream);
+                             dloss_drots_raw, dloss_dus, tile_order, grad_records, phase, row_begin, row_count, stream);
 }

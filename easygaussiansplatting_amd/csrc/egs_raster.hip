@@ -73,11 +73,35 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
 
 // one workgroup per digit: exclusive scan of that digit's per-block counts (in
 // place) and the digit total.
+//
+// mk_parts != NULL (first pass of the depth sort): workgroup 0 also folds the per-workgroup maxima of the keys
+// (maxkey[1 + i], left by the kernel that produced them) into maxkey[0] -- the later passes test it -- and into
+// up to two more places (mk_out: next to P in device memory; mk_host: the page-locked mailbox slot).  The first
+// pass itself never consults maxkey: with shift 0 it could only detect "every key is 0", where the pass is the
+// identity anyway.  (A separate one-workgroup reduce kernel used to sit in front of the sort: 5 us of launch.)
 __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, int nblocks,
                                                        uint32_t* __restrict__ totals, int shift,
-                                                       const uint32_t* __restrict__ maxkey) {
+                                                       const uint32_t* __restrict__ maxkey,
+                                                       uint32_t* __restrict__ mk_parts, int nparts,
+                                                       uint32_t* __restrict__ mk_out,
+                                                       uint32_t* __restrict__ mk_host) {
   __shared__ uint32_t sm[4];
-  if (maxkey && ((*maxkey >> shift) == 0u)) return;
+  if (mk_parts && blockIdx.x == 0) {
+    uint32_t mk = 0u;
+    for (int i = threadIdx.x; i < nparts; i += 256) mk = max(mk, mk_parts[1 + i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mk;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const uint32_t m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+      mk_parts[0] = m;
+      if (mk_out) *mk_out = m;
+      if (mk_host) *mk_host = m;
+    }
+    __syncthreads();
+  }
+  if (!mk_parts && maxkey && ((*maxkey >> shift) == 0u)) return;
   uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
   uint32_t carry = 0;
   for (int base = 0; base < nblocks; base += 256) {
@@ -210,7 +234,9 @@ static int sort_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit
 // enqueue all passes; result ends in (keys,vals) if the pass count is even
 static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_alt, uint32_t* vals_alt,
                       int begin_bit, int end_bit, const SortWs& w, hipStream_t s,
-                      const uint32_t* maxkey = nullptr, const uint32_t* n_dev = nullptr) {
+                      const uint32_t* maxkey = nullptr, const uint32_t* n_dev = nullptr,
+                      uint32_t* mk_parts = nullptr, int nparts = 0, uint32_t* mk_out = nullptr,
+                      uint32_t* mk_host = nullptr) {
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
   // the bits are spread evenly over the passes (13 tile bits = 7 + 6, not 8 + 5): fewer buckets per pass
@@ -220,20 +246,22 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
   for (int shift = begin_bit; shift < end_bit; shift += width) {
     const int nb = end_bit - shift < width ? end_bit - shift : width;  // the last digit may be narrower
     const uint32_t dmask = (1u << nb) - 1u;
+    const bool first = shift == begin_bit && mk_parts != nullptr;      // this pass produces maxkey[0]
+    const uint32_t* mk = first ? nullptr : maxkey;
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
-                 w.nblocks, w.hist, maxkey, n_dev);
+                 w.nblocks, w.hist, mk, n_dev);
     else
       EGS_LAUNCH("k_radix_hist", k_radix_hist<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
-                 w.nblocks, w.hist, maxkey, n_dev);
+                 w.nblocks, w.hist, mk, n_dev);
     EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals, shift,
-               maxkey);
+               mk, first ? mk_parts : (uint32_t*)nullptr, nparts, mk_out, mk_host);
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
-                 dmask, w.nblocks, w.hist, w.totals, maxkey, n_dev);
+                 dmask, w.nblocks, w.hist, w.totals, mk, n_dev);
     else
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n,
-                 shift, dmask, w.nblocks, w.hist, w.totals, maxkey, n_dev);
+                 shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
@@ -344,22 +372,6 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
   block_max_key(key, maxkey);  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
 }
 
-__global__ __launch_bounds__(256) void k_max_reduce(int nparts, uint32_t* __restrict__ maxkey,
-                                                    uint32_t* __restrict__ maxkey_out) {
-  __shared__ uint32_t wm[4];
-  uint32_t mk = 0u;
-  for (int i = threadIdx.x; i < nparts; i += 256) mk = max(mk, maxkey[1 + i]);
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
-  if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const uint32_t m = max(max(wm[0], wm[1]), max(wm[2], wm[3]));
-    maxkey[0] = m;
-    maxkey_out[0] = m;  // returned to the host next to P: it sizes the next call's sort
-  }
-}
-
 // ---- offsets of the Gaussians' patch runs, in depth order -------------------------------------------------
 // The depth sort moves (key, id) pairs only; what the binning needs of a Gaussian afterwards is its packed
 // rect (8 bytes).  It is gathered ONCE, by the first scan kernel, into depth order (rc_sorted); the second scan
@@ -395,7 +407,8 @@ __global__ __launch_bounds__(256) void k_bin_scan_partials(const uint32_t* __res
 
 __global__ __launch_bounds__(256) void k_bin_scan_apply(const uint2* __restrict__ rc_sorted, int64_t n,
                                                         const uint32_t* __restrict__ partials,
-                                                        uint32_t* __restrict__ out, uint32_t* __restrict__ total) {
+                                                        uint32_t* __restrict__ out, uint32_t* __restrict__ total,
+                                                        uint32_t* __restrict__ total_host) {
   __shared__ uint32_t sm[4];
   __shared__ uint32_t s_prefix;
   uint32_t pre = 0;
@@ -417,7 +430,10 @@ __global__ __launch_bounds__(256) void k_bin_scan_apply(const uint2* __restrict_
   }
   uint32_t blocksum;
   uint32_t ex = block256_exclusive_scan(s, sm, &blocksum) + prefix;
-  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) *total = prefix + blocksum;
+  if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    *total = prefix + blocksum;
+    if (total_host) *total_host = prefix + blocksum;   // the mailbox slot (page-locked host memory), no copy
+  }
 #pragma unroll
   for (int k = 0; k < SC_IPT; ++k) {
     const int64_t i = base + k;
@@ -636,6 +652,10 @@ struct DrawParams {
   // longest-list-first dispatch (k_tile_order): workgroup b draws tile order[b] (-1: padding) when set
   const int32_t* order;
   int ngrid;     // entries of `order` (= workgroups launched)
+  // k_draw only: buffer its workgroups zero on the side (the packed gradient records of the coming backward
+  // pass: 48 N bytes; the kernel is VALU-bound and leaves the memory system idle, a separate fill costs 8 us)
+  float4* zero_buf;
+  uint32_t zero_n4;
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
@@ -724,11 +744,16 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
   __shared__ float4 sA[64], sB[64], sC[64];
+  const int lane = threadIdx.x;
+  if (p.zero_buf) {   // every workgroup of the grid (padding ones included) clears its slice
+    const uint32_t per = (p.zero_n4 + gridDim.x - 1) / gridDim.x;
+    const uint32_t z0 = blockIdx.x * per, z1 = min(p.zero_n4, z0 + per);
+    for (uint32_t i = z0 + lane; i < z1; i += 64) p.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
   const int n = r1 - r0;
-  const int lane = threadIdx.x;
   const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
   // pixel k = 2*by + bx of this lane: (tx0 + (lane&7) + 8 bx, ty0 + (lane>>3) + 8 by)
   const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
@@ -1268,6 +1293,8 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
   p.map_mode = forced >= 0 ? forced : (backward ? 0 : 2);
   p.order = nullptr;
   p.ngrid = 0;
+  p.zero_buf = nullptr;
+  p.zero_n4 = 0;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
@@ -1365,7 +1392,7 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
   EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rc,
              L.dkeys, L.ids, L.maxkey);
   EGS_LAUNCH_OK();
-  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream);
+  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, nullptr);
 }
 
 namespace egs {
@@ -1386,21 +1413,22 @@ bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* ou
 }
 
 int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                          void* stream) {
+                          void* stream, uint32_t* host_totals) {
   hipStream_t s = (hipStream_t)stream;
   BinLayout L;
   if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) {
     set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
-  EGS_LAUNCH("k_max_reduce", k_max_reduce, dim3(1), dim3(256), s, div_up(n, 256), L.maxkey, total_patches + 1);
-  EGS_LAUNCH_OK();
   // Only the depth-key bits the caller expects to be significant are sorted (hint from the previous
   // call's max key, which comes back in total_patches[1]); if the hint turns out too small the
   // caller re-runs the stage with hint = 32.  Within the launched passes, digits that are zero
   // in every key still degenerate to copies (maxkey check on the device).
   const int end_bit = (key_bits_hint <= 0 || key_bits_hint > 32) ? 32 : key_bits_hint;
-  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey);
+  // (the largest depth key -- total_patches[1], and the mailbox slot's second word -- comes out of the first
+  // pass's rowscan kernel)
+  int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey, nullptr, L.maxkey,
+                      div_up(n, 256), total_patches + 1, host_totals ? host_totals + 1 : nullptr);
   if (rc) return rc;
   if (sort_passes(0, end_bit) & 1) {  // odd pass count: bring the result back to the primary buffers
     EGS_HIP(hipMemcpyAsync(L.dkeys, L.dkeys_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
@@ -1410,7 +1438,7 @@ int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_
   EGS_LAUNCH("k_bin_scan_partials", k_bin_scan_partials, dim3(nb), dim3(256), s, L.ids, L.rc, (int64_t)n, L.rc_sorted,
              L.scan_partials);
   EGS_LAUNCH("k_bin_scan_apply", k_bin_scan_apply, dim3(nb), dim3(256), s, L.rc_sorted, (int64_t)n, L.scan_partials,
-             L.offsets, total_patches);
+             L.offsets, total_patches, host_totals);
   EGS_LAUNCH_OK();
   return 0;
 }
@@ -1421,7 +1449,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
                            size_t ws_draw_bytes, const float4* rec_in, float* image, int32_t* contrib,
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
-                           void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr) {
+                           void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
+                           float* grad_records = nullptr) {
+  // grad_records != NULL ([N][12] floats): zeroed on the side by the draw kernel for the coming backward pass
   // tile_order != NULL (egs_tile_order_len ints): the dispatch order of the tiles is written there, for the
   // backward pass to reuse (otherwise it lives in ws_draw and the backward pass computes its own)
   // patches_dev != NULL: `patches` is only the capacity of gsid_per_patch / ws_draw, the real count is read on
@@ -1430,6 +1460,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
   hipStream_t s = (hipStream_t)stream;
   DrawParams dp = make_draw_params(width, height, pol);
+  if (grad_records && n > 0 && (patches == 0)) EGS_HIP(hipMemsetAsync(grad_records, 0, (size_t)n * 48, s));
   if (n == 0 || patches == 0) {  // nothing to draw: all outputs are zero
     const size_t hw = (size_t)width * height;
     EGS_HIP(hipMemsetAsync(patch_range_per_tile, 0, (size_t)dp.T * 8, s));
@@ -1469,6 +1500,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
                           patch_range_per_tile, s);
   if (rc) return rc;
+  if (grad_records) { dp.zero_buf = (float4*)grad_records; dp.zero_n4 = (uint32_t)(3 * (size_t)n); }
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                         \
   do {                                                                                                      \
@@ -1512,11 +1544,11 @@ extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height,
                                   const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                   float* image, int32_t* contrib, float* final_tau,
                                   int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                  void* stream) {
+                                  float* grad_records, void* stream) {
   EGS_CHECK_ARG(rec || n == 0);
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
-                         patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order);
+                         patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order, grad_records);
 }
 
 // as egs_splat_draw_rec, enqueued BEFORE the host has read total_patches: patch_capacity sizes
@@ -1527,13 +1559,13 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                                       const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                       float* image, int32_t* contrib, float* final_tau,
                                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                      void* stream) {
+                                      float* grad_records, void* stream) {
   EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
   if (host_totals)
     EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
-                         patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order);
+                         patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]
@@ -1547,13 +1579,15 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                     float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order) {
+                     float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order,
+                     float* grad_records) {
   hipStream_t s = (hipStream_t)stream;
   const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
-  float* gpack = (float*)((char*)ws + align_up((size_t)n * 48, 256));  // [N][12] packed gradient records
+  // [N][12] packed gradient records: the caller's (already zeroed by the forward draw kernel) or a piece of ws
+  float* gpack = grad_records ? grad_records : (float*)((char*)ws + align_up((size_t)n * 48, 256));
   *gpack_out = gpack;
   (void)ws_bytes;
-  EGS_HIP(hipMemsetAsync(gpack, 0, (size_t)n * 48, s));
+  if (!grad_records) EGS_HIP(hipMemsetAsync(gpack, 0, (size_t)n * 48, s));
   if (patches == 0) return 0;
   EGS_CHECK_ARG(contrib && final_tau && patch_range_per_tile && gsid_per_patch && dloss_dgammas);
   EGS_CHECK_ARG(rec_in || (us && cinv2ds && alphas && colors && (areas || pol->footprint != 1)));
@@ -1619,7 +1653,7 @@ extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, cons
   float* gpack = nullptr;
   int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
                             patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, nullptr,
-                            nullptr);
+                            nullptr, nullptr);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,

@@ -9,9 +9,8 @@ Identical inputs ``(pws, shs, alphas[N,1], scales, rots, us, cam)``, outputs
   splat forward; splatB's draw pass + one Jacobian-free chain-rule kernel backward
   (three C-ABI calls per step, no Jacobians in HBM);
 * ``"ops"``  -- the reference's structure: six op calls with ``calc_J=True``, 17
-  tensors saved, ``splatB`` + the fused chain-rule kernel over the stored Jacobians;
-* ``"ops_bmm"`` -- as ``"ops"`` but the chain rule as the nine batched matmuls
-  exactly as the reference spells them (gsmodel.py:71-85).
+  tensors saved, ``splatB`` + the chain-rule kernel over the stored Jacobians
+  (``gsplatcu.chain_rule``; tests compare it with the batched-matmul spelling of gsmodel.py:71-85).
 """
 from __future__ import annotations
 
@@ -48,7 +47,7 @@ class GSFunction(torch.autograd.Function):
         # the mask output never carries a gradient: do not let autograd zero-fill one per step
         ctx.set_materialize_grads(False)
         if ctx.mode == "fused":
-            image, mask, state = _fused.forward(pws, shs, alphas, scales, rots, cam)
+            image, mask, state = _fused.forward(pws, shs, alphas, scales, rots, cam, need_grad=True)
             ctx.cam = cam
             ctx.state = state
             ctx.save_for_backward(pws, shs, alphas, scales, rots)
@@ -88,18 +87,9 @@ class GSFunction(torch.autograd.Function):
             cam.height, cam.width, us, cinv2ds, alphas, depths, colors, contrib, final_tau,
             patch_range_per_tile, gsid_per_patch, dloss_dgammas.contiguous())
         n = us.shape[0]
-        if ctx.mode == "ops":
-            dloss_dpws, dloss_dshs, dloss_dscales, dloss_drots = gsc.chain_rule(
-                dloss_dus, dloss_dcinv2ds, dloss_dcolors, cam.Rcw, dcinv2d_dcov2ds, dcov2d_dcov3ds,
-                dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws)
-        else:  # gsmodel.py:71-85 verbatim structure
-            dpc_dpws = cam.Rcw
-            dloss_dcov2ds = dloss_dcinv2ds @ dcinv2d_dcov2ds
-            dloss_drots = (dloss_dcov2ds @ dcov2d_dcov3ds @ dcov3d_drots).reshape(n, 4)
-            dloss_dscales = (dloss_dcov2ds @ dcov2d_dcov3ds @ dcov3d_dscales).reshape(n, 3)
-            dloss_dshs = (dloss_dcolors.permute(0, 2, 1) @ dcolor_dshs).permute(0, 2, 1).reshape(n, -1)
-            dloss_dpws = (dloss_dus @ du_dpcs @ dpc_dpws + dloss_dcolors @ dcolor_dpws +
-                          dloss_dcov2ds @ dcov2d_dpcs @ dpc_dpws).reshape(n, 3)
+        dloss_dpws, dloss_dshs, dloss_dscales, dloss_drots = gsc.chain_rule(
+            dloss_dus, dloss_dcinv2ds, dloss_dcolors, cam.Rcw, dcinv2d_dcov2ds, dcov2d_dcov3ds,
+            dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws)
         return (dloss_dpws, dloss_dshs, dloss_dalphas.reshape(n, 1), dloss_dscales, dloss_drots,
                 dloss_dus.reshape(n, 2), None)
 
@@ -113,7 +103,8 @@ class GSRawFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw, us, cam):
         ctx.set_materialize_grads(False)
-        image, mask, state = _fused.forward(pws, low_shs, alphas_raw, scales_raw, rots_raw, cam, high_shs=high_shs)
+        image, mask, state = _fused.forward(pws, low_shs, alphas_raw, scales_raw, rots_raw, cam, high_shs=high_shs,
+                                            need_grad=True)
         ctx.cam = cam
         ctx.state = state
         ctx.save_for_backward(pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw)

@@ -28,6 +28,7 @@ from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _
 
 
 ENQUEUE_AHEAD = os.environ.get("EGS_ENQUEUE_AHEAD", "1") != "0"   # knob for A/B measurements and tests
+MAILBOX_COPY = os.environ.get("EGS_MAILBOX_COPY", "0") == "1"     # A/B knob: read-back by copy instead of kernel stores
 MAILBOX_SLOTS = 64
 
 
@@ -35,7 +36,7 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "order", "width", "height", "ticket", "_patches")
+                 "order", "gpack", "width", "height", "ticket", "_patches")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
@@ -180,9 +181,10 @@ def _split_sh(low_shs, high_shs, n):
     return low, high, K
 
 
-def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
+def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False):
     """-> (image[3,H,W], mask[N] bool, state).  ``cam`` carries Rcw/tcw/twc device
     tensors and fx, fy, cx, cy, width, height (reference gausplat_dataset.py:14-26).
+    ``need_grad``: a backward pass will follow (the draw kernel then also zeroes its gradient records).
     With ``high_shs`` the inputs are the RAW training tensors (``shs`` = low_shs, ``alphas`` =
     alphas_raw, ``scales`` = scales_raw, ``rots`` = rots_raw) and the activations of
     gsplat/utils.py:121-150 run inside the kernel (egs_fused_forward_raw)."""
@@ -219,22 +221,25 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
     mask = torch.empty((n,), dtype=torch.bool, device=dev)        # depths > 0.2, written by the kernel
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
+    host_slot = [None]       # mailbox slot the binning kernels also write {P, max key} into (enqueue-ahead path)
     tail = lambda hint, total: (_ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc), float(cam.fx), float(cam.fy),
                                 float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
                                 _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin),
-                                ws_bin_bytes, _ptr(total), st)
+                                ws_bin_bytes, _ptr(total), host_slot[0], st)
     image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
     S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
     S.ranges = torch.empty((_tiles(W, H), 2), dtype=i32, device=dev)
     S.order = torch.empty(lib.egs_tile_order_len(W, H), dtype=i32, device=dev)   # tile dispatch order, reused by backward
+    # packed gradient records of the backward pass: zeroed on the side by the forward draw kernel (one use)
+    S.gpack = torch.empty((max(n, 1), 12), dtype=f32, device=dev) if (need_grad and n > 0) else None
 
     def draw_exact(patches):
         S.gsid = torch.empty(patches, dtype=i32, device=dev)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
-                                          _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), st))
+                                          _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -277,13 +282,20 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None):
             oldest = ctx.pending[0]
         _settle(oldest, True)                         # every slot in flight: wait for the oldest render
     total = torch.empty(2, dtype=i32, device=dev)
-    enqueue_bin(t.hint, total)
-    _lib.check(lib.egs_mailbox_post(ctx.mb, t.slot, _ptr(total), st))
+    if MAILBOX_COPY:          # {P, max key} by an 8-byte device-to-host copy behind the binning stage
+        enqueue_bin(t.hint, total)
+        _lib.check(lib.egs_mailbox_post(ctx.mb, t.slot, _ptr(total), st))
+    else:                     # the binning kernels store them into the page-locked slot themselves
+        host_slot[0] = C.c_void_p(lib.egs_mailbox_slot(ctx.mb, t.slot))
+        enqueue_bin(t.hint, total)
+        host_slot[0] = None   # (a later synchronous re-render must not write into a slot that was handed back)
+        _lib.check(lib.egs_mailbox_mark(ctx.mb, t.slot, st))
     gsid_full = torch.empty(cap, dtype=i32, device=dev)
     ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
     _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
                                           _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
-                                          _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order), st))
+                                          _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
+                                          _ptr(S.gpack), st))
     S.gsid = gsid_full                                # entries past P are unused (the kernels walk `ranges`)
     S._patches = None
     S.ticket = t
@@ -353,14 +365,16 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
            _ptr(S.depths), _ptr(S.contrib), _ptr(S.final_tau), _ptr(S.ranges), _ptr(S.gsid), _ptr(dl), _ptr(ws),
            ws_bytes, _ptr(dpws), _ptr(dshs))
     st = _stream()
+    gpack, S.gpack = S.gpack, None      # zeroed by the forward draw kernel: good for ONE backward pass
     if raw:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward_raw(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *mid,
-            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), phase, b, c, st))
+            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), phase, b, c,
+            st))
     else:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *mid, _ptr(dalphas),
-            _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), phase, b, c, st))
+            _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), phase, b, c, st))
     hook = _exchange_hook
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups

@@ -40,15 +40,18 @@ from .scene import gsdata_type
 SH_C0 = 0.28209479177387814
 
 
-def raw_params_from_scene(scene, device="cuda") -> Dict[str, torch.Tensor]:
-    """gsmodel.py:96-113: un-activated leaf tensors; SH split into degree 0 (low) and the rest (high)."""
+def raw_params_from_scene(scene, device="cuda", clamp_alpha: bool = True) -> Dict[str, torch.Tensor]:
+    """gsmodel.py:96-113: un-activated leaf tensors; SH split into degree 0 (low) and the rest (high).
+    ``clamp_alpha`` keeps the logit finite for opacities of exactly 0 or 1 (the reference does not clamp)."""
     t = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(device)
     shs = t(scene.shs)
     n = shs.shape[0]
     high = torch.full((n, 45), 0.001, device=device)
     if shs.shape[1] > 3:
         high[:, : shs.shape[1] - 3] = shs[:, 3:]
-    alphas = t(scene.alphas).reshape(-1, 1).clamp(1e-4, 1 - 1e-4)
+    alphas = t(scene.alphas).reshape(-1, 1)
+    if clamp_alpha:
+        alphas = alphas.clamp(1e-4, 1 - 1e-4)
     p = {"pws": t(scene.pws), "low_shs": shs[:, :3].contiguous(), "high_shs": high,
          "alphas_raw": torch.log(alphas / (1 - alphas)), "scales_raw": torch.log(t(scene.scales)),
          "rots_raw": t(scene.rots)}

@@ -9,32 +9,19 @@ import torch
 from easygaussiansplatting_amd.density import DensityControl
 from easygaussiansplatting_amd.function import GSFunction, GSRawFunction  # noqa: F401
 from gsplat.utils import *  # noqa: F401,F403
-from gsplat.utils import get_alphas_raw, get_scales_raw
 
 
 def get_training_params(gs):
-    """gsmodel.py:96-129: raw leaf tensors + the per-group Adam settings."""
-    dev = "cuda"
-    f = lambda a: torch.from_numpy(np.ascontiguousarray(a)).type(torch.float32).to(dev)
-    pws = f(gs["pw"]).requires_grad_()
-    rots_raw = f(gs["rot"]).requires_grad_()
-    scales_raw = get_scales_raw(f(gs["scale"])).requires_grad_()
-    alphas_raw = get_alphas_raw(f(gs["alpha"][:, np.newaxis])).requires_grad_()
-    shs = f(gs["sh"]).reshape(pws.shape[0], -1)
-    low_shs = shs[:, :3].contiguous()
-    high_shs = torch.ones_like(low_shs).repeat(1, 15) * 0.001
-    high_shs[:, :shs[:, 3:].shape[1]] = shs[:, 3:]
-    low_shs = low_shs.requires_grad_()
-    high_shs = high_shs.requires_grad_()
-    params = {"pws": pws, "low_shs": low_shs, "high_shs": high_shs, "alphas_raw": alphas_raw,
-              "scales_raw": scales_raw, "rots_raw": rots_raw}
-    adam_params = [{"params": [params["pws"]], "lr": 0.001, "name": "pws"},
-                   {"params": [params["low_shs"]], "lr": 0.001, "name": "low_shs"},
-                   {"params": [params["high_shs"]], "lr": 0.001 / 20, "name": "high_shs"},
-                   {"params": [params["alphas_raw"]], "lr": 0.05, "name": "alphas_raw"},
-                   {"params": [params["scales_raw"]], "lr": 0.005, "name": "scales_raw"},
-                   {"params": [params["rots_raw"]], "lr": 0.001, "name": "rots_raw"}]
-    return params, adam_params
+    """Leaf tensors + Adam groups for a Gaussian record array (the call reference train.py makes): the repo's own
+    ``trainer.raw_params_from_scene`` (raw parameterisation, SH split into degree 0 / rest) and
+    ``optim.adam_groups`` (the reference's per-group learning rates), exposed under the reference's name."""
+    from easygaussiansplatting_amd.optim import adam_groups
+    from easygaussiansplatting_amd.scene import Scene
+    from easygaussiansplatting_amd.trainer import raw_params_from_scene
+    n = gs["pw"].shape[0]
+    scene = Scene(gs["pw"], gs["rot"], gs["scale"], gs["alpha"].reshape(n), np.asarray(gs["sh"]).reshape(n, -1), None)
+    params = raw_params_from_scene(scene, "cuda", clamp_alpha=False)
+    return params, adam_groups(params)
 
 
 class GSModel(torch.nn.Module, DensityControl):

@@ -184,18 +184,24 @@ int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const float* dloss
  * us / cinv2ds / colors / areas may be NULL (they are only needed to continue on the seven-op surface)
  * and egs_fused_backward accepts NULL for them too.
  * visible (nullable): N bytes; receives depths[i] > 0.2 AFTER the in-place culling of splat, i.e. the
- * mask GSFunction.forward returns (gsmodel.py:50). */
+ * mask GSFunction.forward returns (gsmodel.py:50).
+ * host_totals (nullable): device-visible address of a page-locked host uint32[2] (egs_mailbox_slot) that the
+ * binning kernels write {P, max depth key} into as well -- the enqueue-ahead path then needs no copy. */
 int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, const float* scales,
                       const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                       const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                       const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
                       int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                      size_t ws_bin_bytes, uint32_t* total_patches, void* stream);
+                      size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream);
 int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
-                       int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/, void* stream);
-/* The draw kernels hand the tiles to the SIMDs longest list first (k_tile_order, one workgroup, after the
+                       int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
+                       float* grad_records /*nullable*/, void* stream);
+/* grad_records (nullable, [N][12] floats): the packed per-Gaussian gradient records of the COMING backward pass;
+ * the draw kernel zeroes them on the side (it is VALU-bound, the memory system idles) and egs_fused_backward,
+ * given the same pointer, skips its own 48 N-byte fill.  Valid for ONE backward pass.
+ * The draw kernels hand the tiles to the SIMDs longest list first (k_tile_order, one workgroup, after the
  * tile ranges are known).  tile_order (nullable, egs_tile_order_len(width, height) ints) receives that dispatch
  * order so that egs_fused_backward can reuse it instead of computing its own. */
 size_t egs_tile_order_len(int width, int height);
@@ -210,7 +216,7 @@ int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_
                            int width, int height, const void* rec, const EgsPolicy* pol, const void* ws_bin,
                            void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                            int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
-                           void* stream);
+                           float* grad_records /*nullable*/, void* stream);
 /* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
  * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
 int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
@@ -223,6 +229,11 @@ int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
 void* egs_mailbox_create(int slots);
 void egs_mailbox_destroy(void* mailbox);
 int egs_mailbox_post(void* mailbox, int slot, const uint32_t* total_patches, void* stream);
+/* The same without the copy: egs_mailbox_slot is the slot's address (valid on host and device: pass it as
+ * host_totals of egs_fused_forward, whose kernels store the two words there), egs_mailbox_mark records the
+ * slot's event on `stream` behind those kernels. */
+uint32_t* egs_mailbox_slot(void* mailbox, int slot);
+int egs_mailbox_mark(void* mailbox, int slot, void* stream);
 int egs_mailbox_fetch(void* mailbox, int slot, int blocking, uint32_t* out2);
 size_t egs_fused_backward_ws_bytes(int n);
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
@@ -238,8 +249,9 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                        const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
-                       float* dloss_drots, float* dloss_dus, const int32_t* tile_order /*nullable*/, int phase,
-                       int row_begin, int row_count, void* stream);
+                       float* dloss_drots, float* dloss_dus, const int32_t* tile_order /*nullable*/,
+                       float* grad_records /*nullable: zeroed by the forward draw*/, int phase, int row_begin,
+                       int row_count, void* stream);
 
 /* The same pair on the OPTIMIZER's tensors (gsplat/gsmodel.py:96-129: alphas_raw, scales_raw, rots_raw,
  * low_shs [N,3], high_shs [N,sh_dim-3]): the activations of gsplat/utils.py:121-150 (sigmoid, exp,
@@ -251,7 +263,7 @@ int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots
                           const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
                           int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
                           int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                          size_t ws_bin_bytes, uint32_t* total_patches, void* stream);
+                          size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream);
 int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
                            const float* rots_raw, const float* scales_raw, const float* low_shs,
                            const float* high_shs, const float* alphas_raw, const float* Rcw, const float* tcw,
@@ -262,8 +274,8 @@ int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int he
                            const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                            float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                            float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
-                           const int32_t* tile_order /*nullable*/, int phase, int row_begin, int row_count,
-                           void* stream);
+                           const int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/, int phase,
+                           int row_begin, int row_count, void* stream);
 
 /* ---- fused training loss -----------------------------------------
  * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the

@@ -87,7 +87,7 @@ def test_argument_errors_are_reported_not_crashed(lib):
     assert rc == 10001
     assert lib.egs_project(0, None, None, None, 1., 1., 0., 0., C.byref(p), None, None, None, None, None) == 0
     # workspace sizes are monotone and cover the documented layout
-    assert lib.egs_splat_bin_ws_bytes(1_000_000) >= 1_000_000 * (16 + 6 * 4)
+    assert lib.egs_splat_bin_ws_bytes(1_000_000) >= 1_000_000 * (2 * 8 + 5 * 4)   # 2 packed-rect + 5 u32 arrays
     assert lib.egs_splat_draw_ws_bytes(1_000_000, 4_100_000, 1920, 1080) >= 3 * 4 * 4_100_000 + 48 * 1_000_000
     assert lib.egs_splat_bin_ws_bytes(10) <= lib.egs_splat_bin_ws_bytes(1000)
 

@@ -434,12 +434,40 @@ def _oracle_param_grads(sc, cam, dl):
                                    rots=g["drots"], us=dus)
 
 
+def _bmm_chain(dloss_dus, dloss_dcinv2ds, dloss_dcolors, Rcw, J):
+    """backward.md eq (3)(4)(5)(7) as batched matmuls over the stored Jacobians -- the formulation of
+    GSFunction.backward in the reference (gsmodel.py:71-85); test comparator of the chain-rule kernel."""
+    n = dloss_dus.shape[0]
+    g2 = dloss_dcinv2ds @ J["dcinv2d_dcov2ds"]
+    g3 = g2 @ J["dcov2d_dcov3ds"]
+    drots = (g3 @ J["dcov3d_drots"]).reshape(n, 4)
+    dscales = (g3 @ J["dcov3d_dscales"]).reshape(n, 3)
+    dshs = (dloss_dcolors.permute(0, 2, 1) @ J["dcolor_dshs"]).permute(0, 2, 1).reshape(n, -1)
+    dpws = (dloss_dus @ J["du_dpcs"] @ Rcw + dloss_dcolors @ J["dcolor_dpws"] + g2 @ J["dcov2d_dpcs"] @ Rcw)
+    return dpws.reshape(n, 3), dshs, dscales, drots
+
+
+def test_chain_rule_kernel_equals_batched_matmuls(gsc):
+    """k_chain_rule over the stored Jacobians == the nine bmm of the reference's GSFunction.backward."""
+    gsc.set_policy("gsplatcu")
+    sc = S.small_scene(3000, 112, 80, 48, seed=14)
+    g = gpu_stages(gsc, sc, True, "gsplatcu")
+    n = sc.n
+    gus = dev(S.normal(1, 1, (n, 1, 2))); gci = dev(S.normal(1, 2, (n, 1, 3))); gco = dev(S.normal(1, 3, (n, 1, 3)))
+    Rcw = dev(sc.cam.Rcw)
+    names = ("dcinv2d_dcov2ds", "dcov2d_dcov3ds", "dcov3d_drots", "dcov3d_dscales", "dcolor_dshs", "du_dpcs",
+             "dcov2d_dpcs", "dcolor_dpws")
+    got = gsc.chain_rule(gus, gci, gco, Rcw, *[g[k] for k in names])
+    want = _bmm_chain(gus, gci, gco, Rcw, g)
+    for a, b, nm in zip(got, want, ("dpws", "dshs", "dscales", "drots")):
+        assert close(host(a), host(b), 2e-5), nm
+
+
 @pytest.mark.parametrize("K", [48, 3])
 def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
     """GSFunction counterpart (gsmodel.py:6-93): identical inputs/outputs/gradient
-    order; the fused path, the 7-op path (+HIP chain rule) and the 7-op path with the
-    reference's bmm chain agree, and match the oracle's parameter gradients
-    (backward_cpu.py:476-482) at 1e-4."""
+    order; the fused path and the 7-op path (+HIP chain rule) agree, and match the oracle's
+    parameter gradients (backward_cpu.py:476-482) at 1e-4."""
     from easygaussiansplatting_amd.function import Camera, GSFunction
     gsc.set_policy("gsplatcu")
     sc = S.small_scene(2500, 112, 80, K, seed=13)
@@ -448,7 +476,7 @@ def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
     dl = S.normal(3, 9, (3, sc.cam.height, sc.cam.width)).astype(np.float32) / (3 * sc.cam.height * sc.cam.width)
     o_img, o_mask, o_g = _oracle_param_grads(sc, sc.cam, dl.astype(np.float64))
     results = {}
-    for mode in ("fused", "ops", "ops_bmm"):
+    for mode in ("fused", "ops"):
         GSFunction.mode = mode
         P = dict(pws=dev(sc.pws), shs=dev(sc.shs), alphas=dev(sc.alphas).reshape(-1, 1), scales=dev(sc.scales),
                  rots=dev(sc.rots))
@@ -463,7 +491,7 @@ def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
     img_f, mask_f, g_f = results["fused"]
     assert np.array_equal(mask_f, o_mask)
     assert np.abs(img_f - o_img).max() < 1e-4
-    for mode in ("ops", "ops_bmm"):
+    for mode in ("ops",):
         img, mask, g = results[mode]
         # same device functions; only FMA contraction may differ between the fused and staged kernels
         assert np.abs(img - img_f).max() < 2e-6 and np.array_equal(mask, mask_f)

@@ -56,6 +56,7 @@ for _ in range(a.steps):
         with fused.deferred() as d:          # the step bench.py times: validation at commit(), not inside forward
             for p in P.values():
                 p.grad = None
+            us0.grad = None
             img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
             img.backward(dl)
             assert not d.commit()
