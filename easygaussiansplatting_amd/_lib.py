@@ -79,7 +79,7 @@ SIGNATURES = {
     "egs_mailbox_destroy": (None, [_P]),
     "egs_mailbox_post": (_i, [_P, _i, _P, _P]),
     "egs_mailbox_slot": (_P, [_P, _i]),
-    "egs_mailbox_mark": (_i, [_P, _i, _P]),
+    "egs_mailbox_arm": (_i, [_P, _i, _P]),
     "egs_mailbox_fetch": (_i, [_P, _i, _i, C.POINTER(C.c_uint32)]),
     "egs_fused_backward_ws_bytes": (_sz, [_i]),
     "egs_fused_backward": (_i, [_i, _i, _i64, _i, _i] + [_P] * 8 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -127,8 +128,10 @@ namespace egs {
 struct Mailbox {
   int slots;
   uint32_t* host;                 // slots x 4 words, page-locked
-  std::vector<hipEvent_t> ev;     // recorded behind the copy into the slot
+  std::vector<hipEvent_t> ev;     // recorded behind the copy into the slot (egs_mailbox_post)
+  std::vector<hipStream_t> armed; // non-null: the slot is filled by kernel stores and POLLED (egs_mailbox_arm)
 };
+constexpr uint32_t MAILBOX_EMPTY = 0xFFFFFFFFu;   // never a patch count (P < 2^31)
 }  // namespace egs
 
 extern "C" void* egs_mailbox_create(int slots) {
@@ -142,6 +145,7 @@ extern "C" void* egs_mailbox_create(int slots) {
   }
   memset(m->host, 0xFF, (size_t)slots * 16);
   m->ev.resize(slots, nullptr);
+  m->armed.resize(slots, nullptr);
   for (int i = 0; i < slots; ++i)
     if (hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) != hipSuccess) {
       for (int j = 0; j < i; ++j) (void)hipEventDestroy(m->ev[j]);
@@ -164,6 +168,7 @@ extern "C" int egs_mailbox_post(void* mb, int slot, const uint32_t* total_patche
   egs::Mailbox* m = (egs::Mailbox*)mb;
   EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots && total_patches);
   hipStream_t s = (hipStream_t)stream;
+  m->armed[slot] = nullptr;
   EGS_HIP(hipMemcpyAsync(m->host + 4 * (size_t)slot, total_patches, 8, hipMemcpyDeviceToHost, s));
   EGS_HIP(hipEventRecord(m->ev[slot], s));
   return 0;
@@ -174,10 +179,17 @@ extern "C" uint32_t* egs_mailbox_slot(void* mb, int slot) {
   return (m && slot >= 0 && slot < m->slots) ? m->host + 4 * (size_t)slot : nullptr;
 }
 
-extern "C" int egs_mailbox_mark(void* mb, int slot, void* stream) {
+// Arm a slot for kernel stores: word 0 (the patch count, stored LAST in stream order by the binning kernels)
+// is set to a value no patch count can take; egs_mailbox_fetch then polls it.  Nothing is enqueued -- an event
+// record behind the binning stage was measured to open a 6 us bubble in front of the next kernel.
+extern "C" int egs_mailbox_arm(void* mb, int slot, void* stream) {
   egs::Mailbox* m = (egs::Mailbox*)mb;
-  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots);
-  EGS_HIP(hipEventRecord(m->ev[slot], (hipStream_t)stream));
+  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots && stream != nullptr);
+  volatile uint32_t* h = m->host + 4 * (size_t)slot;
+  h[1] = 0u;
+  h[0] = egs::MAILBOX_EMPTY;
+  __sync_synchronize();
+  m->armed[slot] = (hipStream_t)stream;
   return 0;
 }
 
@@ -186,6 +198,29 @@ extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out
   if (!m || slot < 0 || slot >= m->slots || !out) {
     egs::set_error(EGS_ERR_BAD_ARG, "bad argument: mailbox / slot / out", __FILE__, __LINE__);
     return -EGS_ERR_BAD_ARG;
+  }
+  const volatile uint32_t* h = m->host + 4 * (size_t)slot;
+  if (m->armed[slot]) {   // filled by kernel stores: poll word 0 (the max key, word 1, was stored by an EARLIER kernel)
+    if (h[0] == egs::MAILBOX_EMPTY) {
+      if (!blocking) return 0;
+      const auto t0 = std::chrono::steady_clock::now();
+      uint64_t spins = 0;
+      while (h[0] == egs::MAILBOX_EMPTY) {
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFF) == 0 &&
+            std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {   // (never seen) ask the runtime
+          const hipError_t e = hipStreamSynchronize(m->armed[slot]);
+          if (e != hipSuccess || h[0] == egs::MAILBOX_EMPTY) {
+            egs::set_error((int)e, "mailbox slot was not written by the binning stage", __FILE__, __LINE__);
+            return -(e != hipSuccess ? (int)e : EGS_ERR_BAD_ARG);
+          }
+        }
+      }
+    }
+    __sync_synchronize();
+    out[0] = h[0];
+    out[1] = h[1];
+    return 1;
   }
   hipError_t e = hipEventQuery(m->ev[slot]);
   if (e == hipErrorNotReady) {
@@ -196,7 +231,6 @@ extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out
     egs::set_error((int)e, hipGetErrorString(e), __FILE__, __LINE__);
     return -(int)e;
   }
-  const volatile uint32_t* h = m->host + 4 * (size_t)slot;
   out[0] = h[0];
   out[1] = h[1];
   return 1;

@@ -655,7 +655,7 @@ struct DrawParams {
   // k_draw only: buffer its workgroups zero on the side (the packed gradient records of the coming backward
   // pass: 48 N bytes; the kernel is VALU-bound and leaves the memory system idle, a separate fill costs 8 us)
   float4* zero_buf;
-  uint32_t zero_n4;
+  uint32_t zero_n4, zero_per;   // float4s in all / per workgroup
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
@@ -746,9 +746,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   __shared__ float4 sA[64], sB[64], sC[64];
   const int lane = threadIdx.x;
   if (p.zero_buf) {   // every workgroup of the grid (padding ones included) clears its slice
-    const uint32_t per = (p.zero_n4 + gridDim.x - 1) / gridDim.x;
-    const uint32_t z0 = blockIdx.x * per, z1 = min(p.zero_n4, z0 + per);
-    for (uint32_t i = z0 + lane; i < z1; i += 64) p.zero_buf[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const uint32_t z0 = blockIdx.x * p.zero_per, z1 = min(p.zero_n4, z0 + p.zero_per);
+    float4* __restrict__ zb = p.zero_buf;
+    for (uint32_t i = z0 + lane; i < z1; i += 64) zb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
@@ -1295,6 +1295,7 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
   p.ngrid = 0;
   p.zero_buf = nullptr;
   p.zero_n4 = 0;
+  p.zero_per = 0;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
@@ -1500,7 +1501,11 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
                           patch_range_per_tile, s);
   if (rc) return rc;
-  if (grad_records) { dp.zero_buf = (float4*)grad_records; dp.zero_n4 = (uint32_t)(3 * (size_t)n); }
+  if (grad_records) {
+    dp.zero_buf = (float4*)grad_records;
+    dp.zero_n4 = (uint32_t)(3 * (size_t)n);
+    dp.zero_per = (dp.zero_n4 + (uint32_t)draw_grid(dp) - 1) / (uint32_t)draw_grid(dp);
+  }
   // policy -> template instance (compile-time footprint / floor / clamp)
 #define EGS_DRAW(BOX, FLOOR, CLAMP)                                                                         \
   do {                                                                                                      \

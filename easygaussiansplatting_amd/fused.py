@@ -286,10 +286,10 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         enqueue_bin(t.hint, total)
         _lib.check(lib.egs_mailbox_post(ctx.mb, t.slot, _ptr(total), st))
     else:                     # the binning kernels store them into the page-locked slot themselves
+        _lib.check(lib.egs_mailbox_arm(ctx.mb, t.slot, st))
         host_slot[0] = C.c_void_p(lib.egs_mailbox_slot(ctx.mb, t.slot))
         enqueue_bin(t.hint, total)
         host_slot[0] = None   # (a later synchronous re-render must not write into a slot that was handed back)
-        _lib.check(lib.egs_mailbox_mark(ctx.mb, t.slot, st))
     gsid_full = torch.empty(cap, dtype=i32, device=dev)
     ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
     _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),

@@ -229,11 +229,12 @@ int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
 void* egs_mailbox_create(int slots);
 void egs_mailbox_destroy(void* mailbox);
 int egs_mailbox_post(void* mailbox, int slot, const uint32_t* total_patches, void* stream);
-/* The same without the copy: egs_mailbox_slot is the slot's address (valid on host and device: pass it as
- * host_totals of egs_fused_forward, whose kernels store the two words there), egs_mailbox_mark records the
- * slot's event on `stream` behind those kernels. */
+/* The same without the copy and without an event: egs_mailbox_slot is the slot's address (valid on host and
+ * device: pass it as host_totals of egs_fused_forward, whose kernels store the two words there);
+ * egs_mailbox_arm -- called BEFORE that enqueue -- marks the slot empty, and egs_mailbox_fetch then polls the
+ * slot's first word (`stream` is only used to recover if nothing ever arrives). */
 uint32_t* egs_mailbox_slot(void* mailbox, int slot);
-int egs_mailbox_mark(void* mailbox, int slot, void* stream);
+int egs_mailbox_arm(void* mailbox, int slot, void* stream);
 int egs_mailbox_fetch(void* mailbox, int slot, int blocking, uint32_t* out2);
 size_t egs_fused_backward_ws_bytes(int n);
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
