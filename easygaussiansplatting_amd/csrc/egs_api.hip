@@ -129,7 +129,8 @@ struct Mailbox {
   int slots;
   uint32_t* host;                 // slots x 4 words, page-locked
   std::vector<hipEvent_t> ev;     // recorded behind the copy into the slot (egs_mailbox_post)
-  std::vector<hipStream_t> armed; // non-null: the slot is filled by kernel stores and POLLED (egs_mailbox_arm)
+  std::vector<char> armed;        // 1: the slot is filled by kernel stores and POLLED (egs_mailbox_arm)
+  std::vector<hipStream_t> stream;  // ... by kernels of this stream (0 = the default stream)
 };
 constexpr uint32_t MAILBOX_EMPTY = 0xFFFFFFFFu;   // never a patch count (P < 2^31)
 }  // namespace egs
@@ -145,7 +146,8 @@ extern "C" void* egs_mailbox_create(int slots) {
   }
   memset(m->host, 0xFF, (size_t)slots * 16);
   m->ev.resize(slots, nullptr);
-  m->armed.resize(slots, nullptr);
+  m->armed.resize(slots, 0);
+  m->stream.resize(slots, nullptr);
   for (int i = 0; i < slots; ++i)
     if (hipEventCreateWithFlags(&m->ev[i], hipEventDisableTiming) != hipSuccess) {
       for (int j = 0; j < i; ++j) (void)hipEventDestroy(m->ev[j]);
@@ -168,7 +170,7 @@ extern "C" int egs_mailbox_post(void* mb, int slot, const uint32_t* total_patche
   egs::Mailbox* m = (egs::Mailbox*)mb;
   EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots && total_patches);
   hipStream_t s = (hipStream_t)stream;
-  m->armed[slot] = nullptr;
+  m->armed[slot] = 0;
   EGS_HIP(hipMemcpyAsync(m->host + 4 * (size_t)slot, total_patches, 8, hipMemcpyDeviceToHost, s));
   EGS_HIP(hipEventRecord(m->ev[slot], s));
   return 0;
@@ -184,12 +186,13 @@ extern "C" uint32_t* egs_mailbox_slot(void* mb, int slot) {
 // record behind the binning stage was measured to open a 6 us bubble in front of the next kernel.
 extern "C" int egs_mailbox_arm(void* mb, int slot, void* stream) {
   egs::Mailbox* m = (egs::Mailbox*)mb;
-  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots && stream != nullptr);
+  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots);
   volatile uint32_t* h = m->host + 4 * (size_t)slot;
   h[1] = 0u;
   h[0] = egs::MAILBOX_EMPTY;
   __sync_synchronize();
-  m->armed[slot] = (hipStream_t)stream;
+  m->armed[slot] = 1;
+  m->stream[slot] = (hipStream_t)stream;
   return 0;
 }
 
@@ -209,7 +212,7 @@ extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out
         __builtin_ia32_pause();
         if ((++spins & 0xFFF) == 0 &&
             std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {   // (never seen) ask the runtime
-          const hipError_t e = hipStreamSynchronize(m->armed[slot]);
+          const hipError_t e = hipStreamSynchronize(m->stream[slot]);
           if (e != hipSuccess || h[0] == egs::MAILBOX_EMPTY) {
             egs::set_error((int)e, "mailbox slot was not written by the binning stage", __FILE__, __LINE__);
             return -(e != hipSuccess ? (int)e : EGS_ERR_BAD_ARG);
