@@ -25,3 +25,11 @@ print("fraction of pixels saturated (tau<1e-4): %.3f" % done.float().mean().item
 print("fwd work now  (sum tile_maxcont*4 blocks)  = %.3e" % (tilemax.sum().item() * 4))
 print("fwd work with per-block exit (sum blkmax)   = %.3e" % blkmax.sum().item())
 print("list total*4 = %.3e" % (lens.sum().item() * 4))
+# per-tile work estimates for the scheduling simulation (tools: /tmp/sim.py style): list length, largest contrib,
+# sum over the four blocks of their largest contrib (what k_draw_bwd actually walks per block)
+out = os.path.join(os.environ.get("GRAFT_REPO_ROOT", "."), "gpurun_out", "tile_work.npz")
+np.savez_compressed(out, lens=lens.cpu().numpy(), tilemax=tilemax.cpu().numpy(), blksum=blkmax.sum(-1).cpu().numpy())
+r = (tilemax / lens.clamp(min=1)).flatten()
+print("tile maxcont / len: mean %.3f  p10 %.3f  p50 %.3f  p90 %.3f" % (r.mean().item(), r.quantile(0.1).item(),
+      r.quantile(0.5).item(), r.quantile(0.9).item()))
+print("saved", out)
