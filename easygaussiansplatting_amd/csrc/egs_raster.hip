@@ -529,11 +529,14 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 // One workgroup: counting sort on (class, length / 4) in LDS -- 8160 tiles take a few microseconds.
 constexpr int TO_BINS = 1024;
 constexpr int TO_REGS = 16;    // list lengths a thread keeps in registers between the two passes (T <= 16384)
-__device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, int t) {
+// sort key of tile t: its list length, or -- `work` given -- the work the forward draw kernel measured for it
+__device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, const int32_t* __restrict__ work, int t) {
+  if (work) return work[t];
   const int2 r = reinterpret_cast<const int2*>(ranges)[t];
   return r.y - r.x;
 }
-__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges, int T, int gx, int mode,
+__global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges,
+                                                     const int32_t* __restrict__ work, int T, int gx, int mode,
                                                      int period, int32_t* __restrict__ order, int ngrid) {
   __shared__ uint32_t bins[8 * TO_BINS];
   __shared__ uint32_t wsum[16];
@@ -546,7 +549,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
 #pragma unroll
   for (int r = 0; r < TO_REGS; ++r) {
     const int t = tid + r * 1024;
-    lenr[r] = t < T ? tile_len(ranges, t) : 0;
+    lenr[r] = t < T ? tile_len(ranges, work, t) : 0;
   }
   for (int i = tid; i < ncls * TO_BINS; i += 1024) bins[i] = 0u;
   if (per_xcd)   // classes are padded to the largest one: slots without a tile stay -1
@@ -565,7 +568,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   }
   for (int t = tid + TO_REGS * 1024; t < T; t += 1024) {
     int cls;
-    atomicAdd(&bins[key_of(t, tile_len(ranges, t), cls)], 1u);
+    atomicAdd(&bins[key_of(t, tile_len(ranges, work, t), cls)], 1u);
   }
   __syncthreads();
   {  // exclusive scan of the ncls * 1024 bins: thread t owns bins [ncls t, ncls t + ncls)
@@ -604,7 +607,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     const int t = tid + r * 1024;
     if (t < T) place(t, lenr[r]);
   }
-  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) place(t, tile_len(ranges, t));
+  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) place(t, tile_len(ranges, work, t));
 }
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
@@ -656,6 +659,9 @@ struct DrawParams {
   // pass: 48 N bytes; the kernel is VALU-bound and leaves the memory system idle, a separate fill costs 8 us)
   float4* zero_buf;
   uint32_t zero_n4, zero_per;   // float4s in all / per workgroup
+  // k_draw only (nullable): per-tile work measure for the backward pass's dispatch order -- how far the tile
+  // actually walked its list (early termination makes that 0.6 .. 1.0 of the list length, tile by tile)
+  int32_t* work_out;
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
@@ -760,6 +766,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
   if (n <= 0) {  // empty tile: image = 0, contrib = 0 and final_tau = 0 (NOT 1), exactly what the
                  // reference's early return leaves in its zero-filled outputs (kernel.cu:182)
+    if (p.work_out && lane == 0) p.work_out[tile] = 0;
     const size_t HW0 = (size_t)p.W * p.H;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -891,6 +898,18 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
       if ((live & (1 << k)) && !__any(tau[k] >= stop)) live &= ~(1 << k);
     }
     }
+  }
+  if (p.work_out) {   // what k_draw_bwd will walk: the largest contributor index of the tile and of its blocks
+    int w = 0, wmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int mx = cont[k];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+      w += mx;
+      wmax = max(wmax, mx);
+    }
+    if (lane == 0) p.work_out[tile] = w + 2 * wmax;
   }
   const size_t HW = (size_t)p.W * p.H;
 #pragma unroll
@@ -1296,6 +1315,7 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
   p.zero_buf = nullptr;
   p.zero_n4 = 0;
   p.zero_per = 0;
+  p.work_out = nullptr;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
@@ -1312,7 +1332,7 @@ static int tile_order_mode(int which) {
   return mode[which];
 }
 static int tile_order_enqueue(DrawParams& p, int which, int32_t* buf, size_t buf_len,
-                              const int32_t* ranges, hipStream_t s) {
+                              const int32_t* ranges, hipStream_t s, const int32_t* work = nullptr) {
   const int mode = tile_order_mode(which);
   if (mode <= 0 || !buf) return 0;
   const bool per_xcd = mode >= 3;
@@ -1320,7 +1340,7 @@ static int tile_order_enqueue(DrawParams& p, int which, int32_t* buf, size_t buf
   if ((size_t)ngrid > buf_len) return 0;     // (images beyond the workspace bound keep the plain map)
   static const int serp = [] { const char* e = getenv("EGS_TILE_SERP"); return e ? atoi(e) : 0; }();
   const int period = serp > 0 ? serp : (per_xcd ? 128 : 1024);   // SIMDs per XCD / per chip
-  EGS_LAUNCH("k_tile_order", k_tile_order, dim3(1), dim3(1024), s, ranges, p.T, p.gx, mode, period, buf, ngrid);
+  EGS_LAUNCH("k_tile_order", k_tile_order, dim3(1), dim3(1024), s, ranges, work, p.T, p.gx, mode, period, buf, ngrid);
   EGS_LAUNCH_OK();
   p.order = buf;
   p.ngrid = ngrid;
@@ -1366,8 +1386,10 @@ extern "C" int egs_exclusive_scan_u32(int64_t n, const uint32_t* in, const uint3
 }
 
 extern "C" size_t egs_splat_bin_ws_bytes(int n) { return bin_ws_bytes(n); }
+// a caller-held tile_order buffer: [dispatch order of the forward draw | per-tile work it measured (T ints)]
 extern "C" size_t egs_tile_order_len(int width, int height) {
-  return (size_t)tile_order_len(div_up(width, EGS_TILE), div_up(height, EGS_TILE));
+  const int gx = div_up(width, EGS_TILE), gy = div_up(height, EGS_TILE);
+  return (size_t)tile_order_len(gx, gy) + (size_t)gx * gy;
 }
 extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height) {
   return draw_ws_bytes(n, patches, width, height);
@@ -1501,6 +1523,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
                           patch_range_per_tile, s);
   if (rc) return rc;
+  if (tile_order) dp.work_out = tile_order + tile_order_len(dp.gx, dp.gy);
   if (grad_records) {
     dp.zero_buf = (float4*)grad_records;
     dp.zero_n4 = (uint32_t)(3 * (size_t)n);
@@ -1601,7 +1624,16 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
-  if (tile_order && tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0) {
+  static const int by_work = [] { const char* e = getenv("EGS_DRAWB_BY_WORK"); return e ? atoi(e) : 1; }();
+  if (tile_order && by_work && tile_order_mode(1) > 0 && (size_t)tile_order_len(dp.gx, dp.gy) <= BWD_ORDER_CAP) {
+    // the forward draw kernel left behind how far every tile walked its list: order the tiles by THAT (the list
+    // length mis-ranks tiles whose pixels saturate early; simulated with the measured work of the 1 M scene:
+    // makespan 1.11 x ideal by length, 1.03 x by work)
+    int32_t* order = (int32_t*)((char*)ws + 2 * align_up((size_t)n * 48, 256));
+    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s,
+                                      tile_order + tile_order_len(dp.gx, dp.gy));
+    if (rc) return rc;
+  } else if (tile_order && tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0) {
     // the forward pass left its dispatch order behind (same mode): no second k_tile_order
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(1) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;

@@ -204,7 +204,7 @@ int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void
  * The draw kernels hand the tiles to the SIMDs longest list first (k_tile_order, one workgroup, after the
  * tile ranges are known).  tile_order (nullable, egs_tile_order_len(width, height) ints) receives that dispatch
  * order so that egs_fused_backward can reuse it instead of computing its own. */
-size_t egs_tile_order_len(int width, int height);
+size_t egs_tile_order_len(int width, int height);   /* ints: [forward dispatch order | per-tile work measured by the draw] */
 /* As egs_splat_draw_rec, for a host that enqueues the draw stage BEFORE it has read total_patches (no GPU
  * idle time around the read-back): patch_capacity sizes gsid_per_patch and ws_draw
  * (egs_splat_draw_ws_bytes(n, patch_capacity, ..)), the real patch count is taken from total_patches[0] on
