@@ -28,7 +28,7 @@
 #define EGS_TILE_ORDER_F_DEFAULT 1
 #endif
 #ifndef EGS_DRAWB_RED_DEFAULT
-#define EGS_DRAWB_RED_DEFAULT 1
+#define EGS_DRAWB_RED_DEFAULT 3
 #endif
 #ifndef EGS_TILE_ORDER_B_DEFAULT
 #define EGS_TILE_ORDER_B_DEFAULT 1
@@ -1033,6 +1033,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                                                  const float* __restrict__ dLdg,
                                                  float* __restrict__ gpack) {
   __shared__ float4 sA[64], sB[64], sC[64], sD[64];  // sD = {cinv.x, cinv.y, cinv.z, gsid}
+  __shared__ float4 szero[3];                        // a line of zeros (see the accumulator reset below)
+  constexpr bool ZLDS = (RED & 2) != 0;
+  if (ZLDS && threadIdx.x < 3) szero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
+  const uint32_t zaddr = (uint32_t)(uintptr_t)szero;   // LDS byte offset of the zero line
   const int tile = xcd_tile(blockIdx.x, p);
   if (tile < 0) return;
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -1127,8 +1131,22 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
       bool any = false;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        {  // nine zeros from five 64-bit moves (v_mov_b64 on gfx940+): the zeroing runs at full exec once per
-           // slot and this kernel is VALU-issue bound
+        if (ZLDS) {
+          // The nine zeros come out of LDS: broadcast reads of a zero line cost the VALU nothing (nine v_mov_b32 or
+          // five v_mov_b64 are 21 issue cycles per slot in a kernel that is VALU-issue bound; the LDS pipe idles).
+          // Inline asm, because the compiler would hoist a plain load and hand out register copies again; it
+          // cannot see these loads in its lgkmcnt bookkeeping, so every hit body -- the only place the
+          // accumulators are touched before the reduction -- starts with an explicit wait (LDS returns in order
+          // and the hit test has already waited for the entry's own, LATER, record loads: the wait never stalls).
+          typedef float f4v __attribute__((ext_vector_type(4)));
+          f4v z0, z1;
+          float z2;
+          asm volatile("ds_read_b128 %0, %3\n ds_read_b128 %1, %3 offset:16\n ds_read_b32 %2, %3 offset:32"
+                       : "=v"(z0), "=v"(z1), "=v"(z2) : "v"(zaddr));
+          acc[e][0] = z0.x; acc[e][1] = z0.y; acc[e][2] = z0.z; acc[e][3] = z0.w;
+          acc[e][4] = z1.x; acc[e][5] = z1.y; acc[e][6] = z1.z; acc[e][7] = z1.w;
+          acc[e][8] = z2;
+        } else {  // nine zeros from five 64-bit moves (v_mov_b64 on gfx940+)
 #pragma unroll
           for (int q = 0; q < 8; q += 2) {
             unsigned long long z = 0ull;
@@ -1172,6 +1190,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
           bool hit = (i < cont[k]) && (pw >= C.w);  // kernel.cu:899,913
           if (BOX) hit = hit && inx[bx] && iny[by];
           if (hit) {
+            if (ZLDS)   // the slot's zeros have landed (see above); the operands pin every accumulator use behind it
+              asm volatile("s_waitcnt lgkmcnt(0)"
+                           : "+v"(acc[e][0]), "+v"(acc[e][1]), "+v"(acc[e][2]), "+v"(acc[e][3]), "+v"(acc[e][4]),
+                             "+v"(acc[e][5]), "+v"(acc[e][6]), "+v"(acc[e][7]), "+v"(acc[e][8]));
             const float g = __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
             float ap = B.y * g;
             if (CLAMP) ap = min_hi(ap, 0.99f);
@@ -1205,7 +1227,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
 #pragma unroll
         for (int q = 0; q < 9; ++q)
           rows[q] = rows_of4(acc[0][ORDER[q]], acc[1][ORDER[q]], acc[2][ORDER[q]], acc[3][ORDER[q]]);
-        const float v = RED == 0 ? rows_to_lanes9(rows, c16) : rows_to_lanes9_bank(rows, c16);
+        const float v = (RED & 1) == 0 ? rows_to_lanes9(rows, c16) : rows_to_lanes9_bank(rows, c16);
         // row r of the wave holds the totals of slot e = {0,2,1,3}[r]
         const int row = lane >> 4;
         const int e = ((row & 1) << 1) | (row >> 1);
@@ -1642,8 +1664,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s);
     if (rc) return rc;
   }
-  // in-row stage of the backward kernel's wave reduction (0: select-based merges, 1: bank-masked DPP adds);
-  // EGS_DRAWB_RED overrides (A/B knob)
+  // variants of the backward kernel (bit 0: in-row merges of the wave reduction with bank-masked DPP adds instead
+  // of selects; bit 1: accumulator zeros loaded from LDS instead of moved); EGS_DRAWB_RED = 0 | 1 | 3 overrides
   static const int red = [] { const char* e = getenv("EGS_DRAWB_RED"); return e ? atoi(e) : EGS_DRAWB_RED_DEFAULT; }();
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   do {                                                                                                    \
@@ -1651,8 +1673,12 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
       EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 0>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
                      dloss_dgammas, gpack);                                                               \
-    else                                                                                                  \
+    else if (red == 1)                                                                                    \
       EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 1>), dim3(draw_grid(dp)), dim3(64),     \
+                     draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
+                     dloss_dgammas, gpack);                                                               \
+    else                                                                                                  \
+      EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 3>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
                      dloss_dgammas, gpack);                                                               \
   } while (0)
