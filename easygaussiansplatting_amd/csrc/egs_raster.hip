@@ -1134,14 +1134,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         if (ZLDS) {
           // The nine zeros come out of LDS: broadcast reads of a zero line cost the VALU nothing (nine v_mov_b32 or
           // five v_mov_b64 are 21 issue cycles per slot in a kernel that is VALU-issue bound; the LDS pipe idles).
-          // Inline asm, because the compiler would hoist a plain load and hand out register copies again; it
-          // cannot see these loads in its lgkmcnt bookkeeping, so every hit body -- the only place the
-          // accumulators are touched before the reduction -- starts with an explicit wait (LDS returns in order
-          // and the hit test has already waited for the entry's own, LATER, record loads: the wait never stalls).
+          // Inline asm, because the compiler would hoist a plain load and hand out register copies again.  The
+          // wait is part of the statement: the compiler does not see these loads in its lgkmcnt bookkeeping and
+          // may copy the results anywhere afterwards.  (The wave parks for one LDS latency; its four neighbours
+          // on the SIMD issue meanwhile.)
           typedef float f4v __attribute__((ext_vector_type(4)));
           f4v z0, z1;
           float z2;
-          asm volatile("ds_read_b128 %0, %3\n ds_read_b128 %1, %3 offset:16\n ds_read_b32 %2, %3 offset:32"
+          asm volatile("ds_read_b128 %0, %3\n ds_read_b128 %1, %3 offset:16\n ds_read_b32 %2, %3 offset:32\n"
+                       " s_waitcnt lgkmcnt(0)"
                        : "=v"(z0), "=v"(z1), "=v"(z2) : "v"(zaddr));
           acc[e][0] = z0.x; acc[e][1] = z0.y; acc[e][2] = z0.z; acc[e][3] = z0.w;
           acc[e][4] = z1.x; acc[e][5] = z1.y; acc[e][6] = z1.z; acc[e][7] = z1.w;
@@ -1190,10 +1191,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
           bool hit = (i < cont[k]) && (pw >= C.w);  // kernel.cu:899,913
           if (BOX) hit = hit && inx[bx] && iny[by];
           if (hit) {
-            if (ZLDS)   // the slot's zeros have landed (see above); the operands pin every accumulator use behind it
-              asm volatile("s_waitcnt lgkmcnt(0)"
-                           : "+v"(acc[e][0]), "+v"(acc[e][1]), "+v"(acc[e][2]), "+v"(acc[e][3]), "+v"(acc[e][4]),
-                             "+v"(acc[e][5]), "+v"(acc[e][6]), "+v"(acc[e][7]), "+v"(acc[e][8]));
             const float g = __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
             float ap = B.y * g;
             if (CLAMP) ap = min_hi(ap, 0.99f);
