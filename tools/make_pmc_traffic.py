@@ -1,17 +1,31 @@
 #!/usr/bin/env python3
-"""profiles/pmc_traffic.json from a tools/pmc_summary.py JSON (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes).
-   python tools/make_pmc_traffic.py gpurun_out/prof/pmc_fetch_write.json profiles/pmc_traffic.json"""
+"""profiles/pmc_traffic.json from tools/pmc_summary.py JSONs:
+   python tools/make_pmc_traffic.py <fetch_write.json> <sq_counters.json or -> <ubench_counters.json or -> <out.json>
+
+* HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes);
+* VALU issue utilisation per kernel from the SQ passes, CALIBRATED on single-instruction kernels
+  (tools/ubench_calib.hip): SQ_ACTIVE_INST_VALU counts 4 cycles for an instruction that really occupies the
+  SIMD for 2.5 (add / mul / fma), 4.3 (DPP, cndmask, med3, min/max, cmp, readlane) and 8 for one that takes 8.5
+  (exp, rcp, permlane swaps) -- "busy = counter x 4 / cycles" therefore reads 1.59 for a pure-FMA kernel at 100 %
+  issue and cannot be quoted as a utilisation.  What is stored instead is the range the counters allow:
+  (INSTS - Q) x c + Q x 8.5 cycles with Q = ACTIVE - INSTS quarter-rate instructions and c = 2.5 (every other
+  instruction full rate) .. 4.3 (every other one half rate), over the SIMD cycles of the launch;
+* `source_hash`: fingerprint of the kernel sources the passes ran on -- bench.py quotes these numbers only when it
+  runs the same sources."""
 import json
+import os
 import sys
 
-src, dst = sys.argv[1], sys.argv[2]
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_hash  # noqa: E402
+
+src, sq, ub, dst = sys.argv[1:5]
 d = json.load(open(src))
-out = {"gaussians": 1000000, "width": 1920, "height": 1080,
-       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes), tools/profile_step.py, "
-                 "MI355X; tools/collect_profiles.sh",
+out = {"gaussians": 1000000, "width": 1920, "height": 1080, "source_hash": kernel_source_hash(),
+       "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and SQ passes, "
+                 "tools/profile_step.py, MI355X; tools/collect_profiles.sh",
        "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane loads, MI355X_MICROARCH.md "
-                     "section HBM; calibrated on k_preprocess_fwd: 240 MB algorithmic reads -> FETCH_SIZE 119 MB, "
-                     "WRITE_SIZE exact), WRITE_SIZE x1; counters are in KB",
+                     "section HBM; calibrated on k_preprocess_fwd), WRITE_SIZE x1; counters are in KB",
        "kernels": {}}
 for k, v in d.items():
     name = k.replace("egs::", "").split("<")[0]
@@ -27,5 +41,24 @@ for name, e in out["kernels"].items():
     e["FETCH_SIZE_KB"] /= n
     e["WRITE_SIZE_KB"] /= n
     e["hbm_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024)
+if sq != "-":
+    for k, c in json.load(open(sq)).items():
+        name = k.replace("egs::", "").split("<")[0]
+        if name not in out["kernels"] or "SQ_ACTIVE_INST_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
+            continue
+        insts, active = c["SQ_INSTS_VALU"], c["SQ_ACTIVE_INST_VALU"]
+        q = max(0.0, active - insts)
+        simd_cycles = 1024 * c["GRBM_GUI_ACTIVE"] / 8
+        out["kernels"][name]["valu_insts_per_launch"] = int(insts)
+        out["kernels"][name]["valu_busy_counter"] = round(active * 4 / simd_cycles, 3)
+        out["kernels"][name]["valu_issue_util"] = [round(((insts - q) * 2.5 + q * 8.5) / simd_cycles, 3),
+                                                   round(min(1.0, ((insts - q) * 4.3 + q * 8.5) / simd_cycles), 3)]
+if ub != "-":
+    cal = {}
+    for k, c in json.load(open(ub)).items():
+        cal[k.split("<")[-1].rstrip(">")] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
+    out["valu_busy_counter_at_full_issue"] = {"by_ubench_op_index": cal,
+                                              "note": "tools/ubench_calib.hip kernels k_ub<OP>: 0 v_fma, 1 v_exp, 2 v_rcp, "
+                                                      "3/4 permlane swaps, 5 dpp add, 6 cndmask, 7 readlane, 8 mov_b64, 9 med3"}
 json.dump(out, open(dst, "w"), indent=1)
-print({k: v["hbm_bytes_per_launch"] for k, v in out["kernels"].items()})
+print({k: (v["hbm_bytes_per_launch"], v.get("valu_issue_util")) for k, v in out["kernels"].items()})
