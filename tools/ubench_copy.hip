@@ -3,12 +3,13 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 
+typedef float f4v __attribute__((ext_vector_type(4)));
 template <int U>
-__global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+__global__ __launch_bounds__(256) void k_copy(const f4v* __restrict__ src, f4v* __restrict__ dst, size_t n4) {
   const size_t stride = (size_t)gridDim.x * 256;
   size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
   for (; i + (U - 1) * stride < n4; i += U * stride) {
-    float4 v[U];
+    f4v v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load(&src[i + u * stride]);
 #pragma unroll
@@ -18,7 +19,7 @@ __global__ __launch_bounds__(256) void k_copy(const float4* __restrict__ src, fl
 }
 
 template <int U>
-void run(int wg_per_cu, float4* a, float4* b, size_t n4) {
+void run(int wg_per_cu, f4v* a, f4v* b, size_t n4) {
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   for (int r = 0; r < 2; ++r) hipLaunchKernelGGL(k_copy<U>, dim3(256 * wg_per_cu), dim3(256), 0, 0, a, b, n4);
   hipEventRecord(e0);
@@ -30,7 +31,7 @@ void run(int wg_per_cu, float4* a, float4* b, size_t n4) {
 
 int main() {
   const size_t n4 = (size_t)1 << 26;   // 1 GiB
-  float4 *a, *b; hipMalloc(&a, n4 * 16); hipMalloc(&b, n4 * 16); hipMemset(a, 1, n4 * 16);
+  f4v *a, *b; (void)hipMalloc(&a, n4 * 16); (void)hipMalloc(&b, n4 * 16); (void)hipMemset(a, 1, n4 * 16);
   for (int w : {4, 8, 16, 32}) { run<1>(w, a, b, n4); run<2>(w, a, b, n4); run<4>(w, a, b, n4); run<8>(w, a, b, n4); }
   float ms; hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   hipEventRecord(e0);
