@@ -372,14 +372,18 @@ def main():
         st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
         for _ in range(2):
             _lib.check(lib.egs_hbm_copy_probe(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nb, st))
-        c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
-        c0.record()
-        reps = 10
-        for _ in range(reps):
-            _lib.check(lib.egs_hbm_copy_probe(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nb, st))
-        c1.record()
-        torch.cuda.synchronize()
-        peak_measured = round(2.0 * nb * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9, 1)   # read + write
+        best = 0.0
+        for _ in range(3):      # best of three batches (the clock settles during the first)
+            c0 = torch.cuda.Event(enable_timing=True); c1 = torch.cuda.Event(enable_timing=True)
+            c0.record()
+            reps = 8
+            for _ in range(reps):
+                _lib.check(lib.egs_hbm_copy_probe(ctypes.c_void_p(dst.data_ptr()), ctypes.c_void_p(src.data_ptr()), nb,
+                                                  st))
+            c1.record()
+            torch.cuda.synchronize()
+            best = max(best, 2.0 * nb * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9)   # read + write
+        peak_measured = round(best, 1)
         del src, dst
 
     # informative extra (outside the timed region): render + fused L1/SSIM loss + backward, i.e. a

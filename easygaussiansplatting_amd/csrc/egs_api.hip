@@ -106,19 +106,22 @@ extern "C" int egs_prof_report(char* buf, size_t cap) {
 
 // ---- HBM bandwidth probe: the device-to-device copy bench.py calibrates its roofline peak with --------
 namespace egs {
-__global__ __launch_bounds__(256) void k_hbm_copy(const float4* __restrict__ src, float4* __restrict__ dst, size_t n4) {
+typedef float f4v __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_hbm_copy(const f4v* __restrict__ src, f4v* __restrict__ dst, size_t n4) {
   const size_t stride = (size_t)gridDim.x * 256;
-  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) dst[i] = src[i];
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride)
+    __builtin_nontemporal_store(__builtin_nontemporal_load(&src[i]), &dst[i]);
 }
 }  // namespace egs
 
 extern "C" int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream) {
   EGS_CHECK_ARG(dst && src && bytes >= 16 && (((uintptr_t)dst | (uintptr_t)src) & 15) == 0);
   const size_t n4 = bytes / 16;
-  // 16 workgroups per CU, each lane streaming float4s with a grid stride: the copy shape MI355X_MICROARCH.md
-  // quotes 6.29 TB/s for
-  hipLaunchKernelGGL(egs::k_hbm_copy, dim3(256 * 16), dim3(256), 0, (hipStream_t)stream, (const float4*)src,
-                     (float4*)dst, n4);
+  // 4 workgroups per CU, one float4 per lane and iteration, streaming (nt) loads and stores: the best of the
+  // shapes tried on this pool (tools/ubench_copy.hip: 4.7-5.8 TB/s read + write; hipMemcpyAsync D2D 5.0;
+  // MI355X_MICROARCH.md quotes 6.29 TB/s for its float4 copy)
+  hipLaunchKernelGGL(egs::k_hbm_copy, dim3(256 * 4), dim3(256), 0, (hipStream_t)stream, (const egs::f4v*)src,
+                     (egs::f4v*)dst, n4);
   EGS_LAUNCH_OK();
   return 0;
 }
