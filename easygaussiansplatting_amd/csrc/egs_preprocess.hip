@@ -405,11 +405,6 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
   float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
-    // every load of the Gaussian is issued before the first use: loaded inside the depth-test branch below, the
-    // rotation and the scale cost the wave a second trip to memory behind the SH evaluation
-    float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-    f3 sc = ld3(scales + 3 * (size_t)i);
-    const float alpha_in = rec ? alphas[i] : 0.f;
     float col[3];
     {  // colour has no depth test in the reference (kernel.cu:619-725)
       if constexpr (RAW) {
@@ -426,6 +421,8 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
     int rx = 0, ry = 0;
     if (!(pp.near_cull && P.pc.z < EGS_MIN_DEPTH)) {
       u0 = P.u0; u1 = P.u1; depth = P.pc.z;
+      float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+      f3 sc = ld3(scales + 3 * (size_t)i);
       if constexpr (RAW) { float nrm; q = act_rot(q, nrm); sc = act_scale(sc); }
       const Cov3 c3 = cov3d_f(q, sc);
       const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
@@ -454,7 +451,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
     if (areas) { areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry; }
     // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
     if (rec)
-      make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alpha_in) : alpha_in, col[0], col[1], col[2], rx, ry,
+      make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alphas[i]) : alphas[i], col[0], col[1], col[2], rx, ry,
                   pp.W, pp.H, pp.footprint, pp.alpha_skip, r);
   }
   if (bo.rc) block_max_key(dkey, bo.maxkey);
@@ -496,12 +493,6 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   for (int k = 0; k < K; ++k) gsh[k] = 0.f;
   if (i < n) {
     const float4 ga = gpack[3 * (size_t)i], gb = gpack[3 * (size_t)i + 1], gc = gpack[3 * (size_t)i + 2];
-    // every load of the Gaussian is issued before the first use (inside the depth-test branch the position,
-    // rotation and scale would cost the wave a third trip to memory, behind the one for `depths`)
-    const float depth_i = depths[i];
-    const f3 pw = ld3(pws + 3 * (size_t)i);
-    float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-    f3 s = ld3(scales + 3 * (size_t)i);
     const f3 gcol = {ga.y, ga.z, ga.w};
     const float gu0 = gb.x, gu1 = gb.y;
     const f3 gci = {gb.z, gb.w, gc.x};
@@ -512,11 +503,14 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       dL_dalpha[i] = ga.x;
     }
     dL_du[2 * (size_t)i] = gu0; dL_du[2 * (size_t)i + 1] = gu1;
-    if (pp.near_cull && depth_i < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
+    if (pp.near_cull && depths[i] < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
       st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
       st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
       st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
     } else {
+      const f3 pw = ld3(pws + 3 * (size_t)i);
+      float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+      f3 s = ld3(scales + 3 * (size_t)i);
       float qnorm = 1.f;
       if constexpr (RAW) { q = act_rot(q, qnorm); s = act_scale(s); }
       const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
