@@ -68,9 +68,11 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         "k_cov2d": N * (24 + 12 + 4 + 12 + 72 + 36),
         "k_sh2color": N * (4 * K + 12 + 12 + 4 * nc + 36),
         "k_inv_cov2d": N * (12 + 4 + 12 + 8 + 36),
-        "k_bin_count": N * (8 + 8 + 4 + 16 + 4 + 4 + 4),
+        "k_bin_count": N * (8 + 8 + 4 + 8 + 4 + 4),
+        "k_bin_scan_partials": N * (4 + 8 + 8),      # sorted ids in, packed rects gathered once -> depth order
+        "k_bin_scan_apply": N * (8 + 4),
         "k_pack_records": N * (36 + 8 + 48),
-        "k_bin_emit": N * (4 + 4 + 16) + P * 8,
+        "k_bin_emit": N * (4 + 4 + 8) + P * 8,
         "k_radix_hist": None, "k_radix_rowscan": None, "k_radix_scatter": None,  # size depends on the pass
         "k_tile_ranges": P * 4 + T * 8,
         "k_tile_order": T * 12,
@@ -81,8 +83,8 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         "k_draw_bwd": 112 * P + 8 * T + 20 * HW,
         "k_chain_rule": N * (436 - 24 + 24 + 36 + 4 * (3 + 3 * nc + 3 + 4)),
         # fused path: parameters in (pw 12, rot 16, scale 12, sh 4K, alpha 4); out: depth 4, mask 1, the packed
-        # 48-B record, and the binning's rect 16 + count 4 + depth key 4 + id 4      (= 317 N at K = 48)
-        "k_preprocess_fwd": N * (44 + 4 * K + 4 + 1 + 48 + 28),
+        # 48-B record, and the binning's packed rect 8 + depth key 4 + id 4          (= 305 N at K = 48)
+        "k_preprocess_fwd": N * (44 + 4 * K + 4 + 1 + 48 + 16),
         # parameters + depth + packed gradient record in, 59 gradient floats + du out (= 528 N at K = 48)
         "k_preprocess_bwd": N * (40 + 4 * K + 4 + 48 + 4 * (3 + K + 1 + 3 + 4 + 2)),
         "k_unpack_grads": N * (48 + 36),
