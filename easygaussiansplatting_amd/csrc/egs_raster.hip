@@ -1492,7 +1492,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            size_t ws_draw_bytes, const float4* rec_in, float* image, int32_t* contrib,
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
                            void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
-                           float* grad_records = nullptr) {
+                           float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr) {
+  // prev_tile_work != NULL (T ints): the work the draw kernel measured per tile the LAST time this camera was
+  // rendered -- a much better sort key for the dispatch order than the list length (pixels saturate)
   // grad_records != NULL ([N][12] floats): zeroed on the side by the draw kernel for the coming backward pass
   // tile_order != NULL (egs_tile_order_len ints): the dispatch order of the tiles is written there, for the
   // backward pass to reuse (otherwise it lives in ws_draw and the backward pass computes its own)
@@ -1540,7 +1542,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile, patches_dev);
   rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
-                          patch_range_per_tile, s);
+                          patch_range_per_tile, s, prev_tile_work);
   if (rc) return rc;
   if (tile_order) dp.work_out = tile_order + tile_order_len(dp.gx, dp.gy);
   if (grad_records) {
@@ -1591,11 +1593,12 @@ extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height,
                                   const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                   float* image, int32_t* contrib, float* final_tau,
                                   int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                  float* grad_records, void* stream) {
+                                  float* grad_records, const int32_t* prev_tile_work, void* stream) {
   EGS_CHECK_ARG(rec || n == 0);
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
-                         patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order, grad_records);
+                         patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order, grad_records,
+                         prev_tile_work);
 }
 
 // as egs_splat_draw_rec, enqueued BEFORE the host has read total_patches: patch_capacity sizes
@@ -1606,13 +1609,14 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                                       const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                       float* image, int32_t* contrib, float* final_tau,
                                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                      float* grad_records, void* stream) {
+                                      float* grad_records, const int32_t* prev_tile_work, void* stream) {
   EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
   if (host_totals)
     EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
-                         patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records);
+                         patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records,
+                         prev_tile_work);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]

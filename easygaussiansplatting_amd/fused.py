@@ -18,6 +18,7 @@ import collections
 import ctypes as C
 import os
 import threading
+import weakref
 
 import torch
 
@@ -29,6 +30,7 @@ from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _
 
 ENQUEUE_AHEAD = os.environ.get("EGS_ENQUEUE_AHEAD", "1") != "0"   # knob for A/B measurements and tests
 MAILBOX_COPY = os.environ.get("EGS_MAILBOX_COPY", "0") == "1"     # A/B knob: read-back by copy instead of kernel stores
+TILE_WORK_CACHE = os.environ.get("EGS_TILE_WORK_CACHE", "1") != "0"  # A/B knob: forward dispatch order by remembered work
 MAILBOX_SLOTS = 64
 
 
@@ -36,7 +38,7 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "order", "gpack", "width", "height", "ticket", "_patches")
+                 "order", "gpack", "width", "height", "ticket", "_patches", "_keep")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
@@ -66,6 +68,9 @@ class _DeviceCtx:
         self.pending = collections.deque()
         self.failed = []
         self.capacity = {}      # (N, W, H) -> patch-list allocation size learnt from earlier renders
+        # camera -> (weakref, order buffer of its last render): the per-tile work the draw kernel measured then is
+        # the sort key of this render's dispatch order (a trainer meets every view again each epoch)
+        self.tile_work = {}
         self.lock = threading.RLock()
 
 
@@ -212,7 +217,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     f32, i32 = torch.float32, torch.int32
     S = FusedState()
     S.width, S.height = W, H
-    S.ticket, S._patches = None, None
+    S.ticket, S._patches, S._keep = None, None, None
     # the draw kernels (forward and backward) work from the packed records alone: us / cinv2ds / colors /
     # areas are not materialised
     S.us = S.cinv2ds = S.colors = S.areas = None
@@ -239,7 +244,8 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
-                                          _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), st))
+                                          _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
+                                          st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -251,6 +257,22 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     ctx = _ctx(dev)
     key = (n, W, H)
     S.ticket = None
+    # dispatch order of the tiles: sorted by the work the draw kernel measured the LAST time this camera was
+    # rendered, when there is such a record (list lengths otherwise, inside the library)
+    prev_work = None
+    if TILE_WORK_CACHE and n > 0:
+        ck = (id(cam), n, W, H)
+        with ctx.lock:
+            hit = ctx.tile_work.get(ck)
+            if hit is not None and hit[0]() is cam and hit[1].numel() == S.order.numel():
+                prev_work = C.c_void_p(hit[1].data_ptr() + 4 * (hit[1].numel() - _tiles(W, H)))
+                S._keep = hit[1]                        # alive until this render's kernels have consumed it
+            if len(ctx.tile_work) > 4096:               # (cameras that no longer exist)
+                ctx.tile_work = {k: v for k, v in ctx.tile_work.items() if v[0]() is not None}
+            try:
+                ctx.tile_work[ck] = (weakref.ref(cam), S.order)
+            except TypeError:                           # a camera object that cannot be weakly referenced
+                pass
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
     def render_exact():
@@ -295,7 +317,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
                                           _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
                                           _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
-                                          _ptr(S.gpack), st))
+                                          _ptr(S.gpack), prev_work, st))
     S.gsid = gsid_full                                # entries past P are unused (the kernels walk `ranges`)
     S._patches = None
     S.ticket = t
