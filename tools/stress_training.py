@@ -26,6 +26,7 @@ hist = tr.fit(epochs=24, views_per_step=1, densify_every=4, reset_alpha_every=12
 torch.cuda.synchronize()
 print("epochs %d, %.1f s, loss %.4f -> %.4f, gaussians %d -> %d, densifications %d" % (
     len(hist), time.time() - t0, hist[0], hist[-1], n, tr.params["pws"].shape[0], tr.density.round))
+print("steps rendered twice (a view outgrew the enqueue-ahead buffers):", tr.redone_steps, "of", tr.iteration)
 print("patch capacities learnt:", {k: v for k, v in list(fused._ctx(torch.device("cuda", 0)).capacity.items())[:6]},
       "hints", dict(list(gsc._key_bits.items())[:6]))
 assert all(np.isfinite(hist)), hist
