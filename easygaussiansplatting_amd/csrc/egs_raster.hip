@@ -28,7 +28,7 @@
 #define EGS_TILE_ORDER_F_DEFAULT 1
 #endif
 #ifndef EGS_DRAWB_RED_DEFAULT
-#define EGS_DRAWB_RED_DEFAULT 15
+#define EGS_DRAWB_RED_DEFAULT 7
 #endif
 #ifndef EGS_TILE_ORDER_B_DEFAULT
 #define EGS_TILE_ORDER_B_DEFAULT 1
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                                                  float* __restrict__ gpack) {
   __shared__ float4 sA[64], sB[64], sC[64], sD[64];  // sD = {cinv.x, cinv.y, cinv.z, gsid}
   __shared__ float4 szero[3];                        // a line of zeros (see the accumulator reset below)
-  constexpr bool ZLDS = (RED & 2) != 0, LAZY = (RED & 4) != 0, FAST = (RED & 8) != 0;
+  constexpr bool ZLDS = (RED & 2) != 0, LAZY = (RED & 4) != 0;
   if (ZLDS && threadIdx.x < 3) szero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t zaddr = (uint32_t)(uintptr_t)szero;   // LDS byte offset of the zero line
   const int tile = xcd_tile(blockIdx.x, p);
@@ -1120,15 +1120,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     // Groups of four: each of the four accumulator slots takes entries until one of them HITS (a quarter
     // of the entries that reach a live block hit no pixel: they leave the slot zero and cost neither a
     // re-zeroing nor a share of a wave reduction).
-    unsigned long long slowmask = ~0ull;
-    if (FAST) {
-      bool slow_lane = true;
-      if (idx < n) {
-        const float4 A0 = sA[lane], B0 = sB[lane];   // own entry (just staged by this lane)
-        slow_lane = !(A0.z < 0.f && B0.x < 0.f && 4.f * A0.z * B0.x > 1.001f * A0.w * A0.w && B0.y <= 0.989f);
-      }
-      slowmask = __ballot(slow_lane);
-    }
     int rl = mymask;
 #pragma unroll
     for (int k = 0; k < 4; ++k)
@@ -1185,10 +1176,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
         }
         // LAZY: the exponent from scratch per evaluated block (7 full-rate instructions) instead of the separable
         // form (14 per entry up front + 2 per block): most entries reach one or two of the four blocks.
-        // FAST: an entry with a positive-definite conic and alpha <= 0.989 can neither need the floor (its
-        // exponent is <= 0 up to rounding) nor the 0.99 clamp: the two half-rate v_med3 are skipped for it
-        // (wave-uniform flag from the staging lanes' ballot).
-        const bool slow = !FAST || ((slowmask >> j) & 1ull) != 0ull;
+        // (Measured and dropped: skipping the floor / clamp v_med3 for entries with a positive-definite conic and
+        // alpha <= 0.989 behind a wave-uniform flag -- the two scalar branches cost more than the two half-rate
+        // instructions they save: +1.5 %.)
         float dx[2], dy[2], cxx[2], cxy[2], cyy[2];
         if (!LAZY) {
 #pragma unroll
@@ -1218,11 +1208,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
           bool hit = (i < cont[k]) && (pw >= C.w);  // kernel.cu:899,913
           if (BOX) hit = hit && inx[bx] && iny[by];
           if (hit) {
-            float pwf = pw;
-            if (FLOOR) { if (slow) pwf = min_hi(pw, 0.f); }
-            const float g = __builtin_amdgcn_exp2f(pwf);
+            const float g = __builtin_amdgcn_exp2f(FLOOR ? min_hi(pw, 0.f) : pw);
             float ap = B.y * g;
-            if (CLAMP) { if (slow) ap = min_hi(ap, 0.99f); }
+            if (CLAMP) ap = min_hi(ap, 0.99f);
             const float tk = tau[k] * __builtin_amdgcn_rcpf(1.f - ap);  // undo F.5.2
             tau[k] = tk;
             const float dq = (lr[k] * B.z + lg[k] * B.w + lb[k] * C.x) - lq[k];  // dL/dgamma . (color - gamma_cur2last)
@@ -1695,8 +1683,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     if (rc) return rc;
   }
   // variants of the backward kernel (bit 0: in-row merges of the wave reduction with bank-masked DPP adds instead
-  // of selects; bit 1: accumulator zeros loaded from LDS instead of moved; bit 2: exponent per evaluated block;
-  // bit 3: no floor / clamp instructions for well-conditioned entries); EGS_DRAWB_RED = 0 | 3 | 7 | 15 overrides
+  // of selects; bit 1: accumulator zeros loaded from LDS instead of moved; bit 2: exponent per evaluated block);
+  // EGS_DRAWB_RED = 0 | 3 | 7 overrides
   static const int red = [] { const char* e = getenv("EGS_DRAWB_RED"); return e ? atoi(e) : EGS_DRAWB_RED_DEFAULT; }();
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   do {                                                                                                    \
@@ -1708,12 +1696,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
       EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 3>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
                      dloss_dgammas, gpack);                                                               \
-    else if (red == 7)                                                                                    \
-      EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 7>), dim3(draw_grid(dp)), dim3(64),     \
-                     draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
-                     dloss_dgammas, gpack);                                                               \
     else                                                                                                  \
-      EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 15>), dim3(draw_grid(dp)), dim3(64),    \
+      EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 7>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
                      dloss_dgammas, gpack);                                                               \
   } while (0)
