@@ -304,45 +304,6 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int
   }
 }
 
-// The same idea per WAVE and in rounds of 16 rows (K = 48 floats): the wave's 64 rows are one contiguous 12-KB
-// span, fetched with fully coalesced dwordx4 loads (three per lane and round), parked in a 3.3-KB LDS region
-// of the wave's own (16 rows, stride 13 float4: conflict-free), from where the 16 lanes that own those rows pick
-// them up.  No workgroup barrier (a wave's LDS operations execute in order) and no occupancy cost -- the
-// workgroup-wide staging above needs 53 KB per workgroup.
-__device__ __forceinline__ void wave_rows_in48(const float* __restrict__ src, int n, int wave_row0, float* lds_wave,
-                                               float* row) {
-  constexpr int Q = 12, STRIDE = 52, R = 16;
-  const int lane = threadIdx.x & 63;
-  const int valid = n - wave_row0;     // rows of this wave that exist (<= 0: none)
-  const float4* __restrict__ s4 = reinterpret_cast<const float4*>(src + (size_t)48 * wave_row0);
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    float4 v[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int p = lane + 64 * j;       // piece (float4) of this round: row p / 12, column p % 12
-      v[j] = (R * r + p / Q < valid) ? s4[(size_t)r * (R * Q) + p] : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int p = lane + 64 * j, rr = p / Q, c = p - rr * Q;
-      *reinterpret_cast<float4*>(lds_wave + rr * STRIDE + 4 * c) = v[j];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if ((lane >> 4) == r) {
-#pragma unroll
-      for (int j = 0; j < Q; ++j) {
-        const float4 t = *reinterpret_cast<const float4*>(lds_wave + (lane & 15) * STRIDE + 4 * j);
-        row[4 * j] = t.x; row[4 * j + 1] = t.y; row[4 * j + 2] = t.z; row[4 * j + 3] = t.w;
-      }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-  }
-}
-
 // the inverse: every lane deposits its row, the workgroup stores the span coalesced
 template <int K>
 __device__ __forceinline__ void stage_rows_out(const float* row, float* __restrict__ dst, int n, int base, float* lds) {
@@ -441,13 +402,6 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
       else stage_rows_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
     }
   }
-  bool sh_staged = false;
-  if constexpr (!RAW && K == 48) {
-    if (pp.stage_in == 2) {   // (experiment knob) SH rows through the wave's own LDS region, coalesced global reads
-      wave_rows_in48(shs, n, blockIdx.x * 256 + (threadIdx.x & ~63), stage + (threadIdx.x >> 6) * (16 * 52), sh);
-      sh_staged = true;
-    }
-  }
   float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
@@ -455,7 +409,7 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
     {  // colour has no depth test in the reference (kernel.cu:619-725)
       if constexpr (RAW) {
         sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2];
-      } else if (!sh_staged) {  // direct dwordx4 row loads: staging them through LDS measured 10 % slower here
+      } else {  // direct dwordx4 row loads: staging them through LDS measured 10 % slower here
         load_sh_row<K>(shs + (size_t)K * i, sh);
       }
       const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
@@ -532,15 +486,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     }
     if (i < n) { sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2]; }
   } else {
-    bool staged2 = false;
-    if constexpr (K == 48) {
-      if (pp.stage_in == 2) {
-        wave_rows_in48(shs, n, blockIdx.x * 256 + (threadIdx.x & ~63), stage + (threadIdx.x >> 6) * (16 * 52), sh);
-        staged2 = true;
-      }
-    }
-    if (staged2) {}
-    else if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
+    if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
     else if (i < n) load_sh_row<K>(shs + (size_t)K * i, sh);
   }
 #pragma unroll
