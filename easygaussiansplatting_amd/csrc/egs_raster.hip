@@ -526,7 +526,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 //   mode 1: one global order           mode 2: global, serpentine
 //   mode 3: per XCD (tile row % 8 stays on XCD b % 8: horizontal neighbours share one L2), sorted
 //   mode 4: per XCD, serpentine
-// One workgroup: counting sort on (class, length / 4) in LDS -- 8160 tiles take a few microseconds.
+// One workgroup: counting sort on (class, length) in LDS -- 8160 tiles take a few microseconds.
 constexpr int TO_BINS = 1024;
 constexpr int TO_REGS = 16;    // list lengths a thread keeps in registers between the two passes (T <= 16384)
 // sort key of tile t: its list length, or -- `work` given -- the work the forward draw kernel measured for it
@@ -538,12 +538,18 @@ __device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, cons
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges,
                                                      const int32_t* __restrict__ work, int T, int gx, int mode,
                                                      int period, int32_t* __restrict__ order, int ngrid) {
-  __shared__ uint32_t bins[8 * TO_BINS];
+  // 8192 bins in all: one class of 8192 (global modes) or eight of 1024 (per-XCD modes).  Fine bins matter: the
+  // two passes are LDS atomics on the bins, and tiles of similar length pile up on few of them (a 4K image has
+  // 32400 tiles within ~200 distinct lengths: with bins of four the kernel took 45 us, most of it conflicts).
+  constexpr int NB = 8 * TO_BINS;
+  __shared__ uint32_t bins[NB];
   __shared__ uint32_t wsum[16];
   __shared__ uint32_t cbase[9];
   const int tid = threadIdx.x;
   const bool per_xcd = mode >= 3;
-  const int ncls = per_xcd ? 8 : 1;
+  const int cbins = per_xcd ? TO_BINS : NB;                       // bins per class
+  // key -> bin: list lengths 1:1 (1:4 per XCD); the forward kernel's work measure is ~6x a length
+  const int shift = (per_xcd ? 2 : 0) + (work ? 2 : 0);
   // all loads in flight at once: the kernel is a chain of latencies, not of bytes
   int lenr[TO_REGS];
 #pragma unroll
@@ -551,14 +557,14 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     const int t = tid + r * 1024;
     lenr[r] = t < T ? tile_len(ranges, work, t) : 0;
   }
-  for (int i = tid; i < ncls * TO_BINS; i += 1024) bins[i] = 0u;
+  for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
   if (per_xcd)   // classes are padded to the largest one: slots without a tile stay -1
     for (int i = tid; i < ngrid; i += 1024) order[i] = -1;
   __syncthreads();
   auto key_of = [&](int t, int len, int& cls) {
-    const int q = min(max(len, 0), 4 * TO_BINS - 1) >> 2;
+    const int q = min(max(len, 0) >> shift, cbins - 1);
     cls = per_xcd ? ((t / gx) & 7) : 0;
-    return cls * TO_BINS + (TO_BINS - 1 - q);
+    return cls * cbins + (cbins - 1 - q);
   };
 #pragma unroll
   for (int r = 0; r < TO_REGS; ++r) {
@@ -571,10 +577,10 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     atomicAdd(&bins[key_of(t, tile_len(ranges, work, t), cls)], 1u);
   }
   __syncthreads();
-  {  // exclusive scan of the ncls * 1024 bins: thread t owns bins [ncls t, ncls t + ncls)
+  {  // exclusive scan of the 8192 bins: thread t owns bins [8 t, 8 t + 8)
     uint32_t v[8], s = 0u;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { v[k] = k < ncls ? bins[ncls * tid + k] : 0u; s += v[k]; }
+    for (int k = 0; k < 8; ++k) { v[k] = bins[8 * tid + k]; s += v[k]; }
     const uint32_t inc = wave_inclusive_scan(s);
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
@@ -582,11 +588,10 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
     uint32_t ex = pre + inc - s;
 #pragma unroll
-    for (int k = 0; k < 8; ++k)
-      if (k < ncls) { bins[ncls * tid + k] = ex; ex += v[k]; }
+    for (int k = 0; k < 8; ++k) { bins[8 * tid + k] = ex; ex += v[k]; }
   }
   __syncthreads();
-  if (tid < 8) cbase[tid] = tid < ncls ? bins[tid * TO_BINS] : (uint32_t)T;
+  if (tid < 8) cbase[tid] = per_xcd ? bins[tid * TO_BINS] : (tid == 0 ? 0u : (uint32_t)T);
   if (tid == 8) cbase[8] = (uint32_t)T;
   __syncthreads();
   const bool serp = (mode == 2 || mode == 4) && period > 0;
