@@ -528,7 +528,8 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 //   mode 4: per XCD, serpentine
 // One workgroup: counting sort on (class, length) in LDS -- 8160 tiles take a few microseconds.
 constexpr int TO_BINS = 1024;
-constexpr int TO_REGS = 16;    // list lengths a thread keeps in registers between the two passes (T <= 16384)
+constexpr int TO_REGS = 32;    // sort keys a thread keeps in registers between the two passes (T <= 32768: a 4K image);
+                               // beyond that the loops below re-read them, eight loads in flight at a time
 // sort key of tile t: its list length, or -- `work` given -- the work the forward draw kernel measured for it
 __device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, const int32_t* __restrict__ work, int t) {
   if (work) return work[t];
@@ -572,9 +573,15 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     int cls;
     if (t < T) atomicAdd(&bins[key_of(t, lenr[r], cls)], 1u);
   }
-  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) {
-    int cls;
-    atomicAdd(&bins[key_of(t, tile_len(ranges, work, t), cls)], 1u);
+  for (int t0 = tid + TO_REGS * 1024; t0 < T; t0 += 8 * 1024) {
+    int l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l8[u] = (t0 + u * 1024 < T) ? tile_len(ranges, work, t0 + u * 1024) : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      int cls;
+      if (t0 + u * 1024 < T) atomicAdd(&bins[key_of(t0 + u * 1024, l8[u], cls)], 1u);
+    }
   }
   __syncthreads();
   {  // exclusive scan of the 8192 bins: thread t owns bins [8 t, 8 t + 8)
@@ -612,7 +619,14 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
     const int t = tid + r * 1024;
     if (t < T) place(t, lenr[r]);
   }
-  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) place(t, tile_len(ranges, work, t));
+  for (int t0 = tid + TO_REGS * 1024; t0 < T; t0 += 8 * 1024) {
+    int l8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) l8[u] = (t0 + u * 1024 < T) ? tile_len(ranges, work, t0 + u * 1024) : 0;
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (t0 + u * 1024 < T) place(t0 + u * 1024, l8[u]);
+  }
 }
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
