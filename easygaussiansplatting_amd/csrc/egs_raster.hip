@@ -528,8 +528,7 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
 //   mode 4: per XCD, serpentine
 // One workgroup: counting sort on (class, length) in LDS -- 8160 tiles take a few microseconds.
 constexpr int TO_BINS = 1024;
-constexpr int TO_REGS = 32;    // sort keys a thread keeps in registers between the two passes (T <= 32768: a 4K image);
-                               // beyond that the loops below re-read them, eight loads in flight at a time
+constexpr int TO_REGS = 16;    // tiles per thread whose (bin, rank) stay in registers between the two passes
 // sort key of tile t: its list length, or -- `work` given -- the work the forward draw kernel measured for it
 __device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, const int32_t* __restrict__ work, int t) {
   if (work) return work[t];
@@ -539,9 +538,11 @@ __device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, cons
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges,
                                                      const int32_t* __restrict__ work, int T, int gx, int mode,
                                                      int period, int32_t* __restrict__ order, int ngrid) {
-  // 8192 bins in all: one class of 8192 (global modes) or eight of 1024 (per-XCD modes).  Fine bins matter: the
-  // two passes are LDS atomics on the bins, and tiles of similar length pile up on few of them (a 4K image has
-  // 32400 tiles within ~200 distinct lengths: with bins of four the kernel took 45 us, most of it conflicts).
+  // 8192 bins in all: one class of 8192 (global modes) or eight of 1024 (per-XCD modes).
+  // ONE LDS atomic per tile: the returning add that counts a bin also hands the tile its rank inside the bin
+  // (arrival order -- any order inside a bin will do); after the scan of the bins its slot is start + rank.
+  // LDS atomics retire about one lane per clock whatever the conflicts, so the kernel costs ~T cycles per pass:
+  // the first version's two passes took 9 us at 1080p and 45 us at 4K (32400 tiles).
   constexpr int NB = 8 * TO_BINS;
   __shared__ uint32_t bins[NB];
   __shared__ uint32_t wsum[16];
@@ -551,8 +552,7 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   const int cbins = per_xcd ? TO_BINS : NB;                       // bins per class
   // key -> bin: list lengths 1:1 (1:4 per XCD); the forward kernel's work measure is ~6x a length
   const int shift = (per_xcd ? 2 : 0) + (work ? 2 : 0);
-  // all loads in flight at once: the kernel is a chain of latencies, not of bytes
-  int lenr[TO_REGS];
+  int lenr[TO_REGS];     // all loads in flight at once: the kernel is a chain of latencies, not of bytes
 #pragma unroll
   for (int r = 0; r < TO_REGS; ++r) {
     const int t = tid + r * 1024;
@@ -562,26 +562,26 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   if (per_xcd)   // classes are padded to the largest one: slots without a tile stay -1
     for (int i = tid; i < ngrid; i += 1024) order[i] = -1;
   __syncthreads();
-  auto key_of = [&](int t, int len, int& cls) {
+  auto key_of = [&](int t, int len) {
     const int q = min(max(len, 0) >> shift, cbins - 1);
-    cls = per_xcd ? ((t / gx) & 7) : 0;
+    const int cls = per_xcd ? ((t / gx) & 7) : 0;
     return cls * cbins + (cbins - 1 - q);
   };
+  // pass 1: (bin, rank) per tile, packed 13 + 19 bits (T < 2^19: checked by the host)
+  uint32_t kr[TO_REGS];
 #pragma unroll
   for (int r = 0; r < TO_REGS; ++r) {
     const int t = tid + r * 1024;
-    int cls;
-    if (t < T) atomicAdd(&bins[key_of(t, lenr[r], cls)], 1u);
-  }
-  for (int t0 = tid + TO_REGS * 1024; t0 < T; t0 += 8 * 1024) {
-    int l8[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) l8[u] = (t0 + u * 1024 < T) ? tile_len(ranges, work, t0 + u * 1024) : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      int cls;
-      if (t0 + u * 1024 < T) atomicAdd(&bins[key_of(t0 + u * 1024, l8[u], cls)], 1u);
+    kr[r] = 0u;
+    if (t < T) {
+      const int key = key_of(t, lenr[r]);
+      kr[r] = ((uint32_t)key << 19) | atomicAdd(&bins[key], 1u);
     }
+  }
+  // (tiles beyond TO_REGS * 1024 keep their (bin, rank) in the order buffer itself until pass 2)
+  for (int t = tid + TO_REGS * 1024; t < T; t += 1024) {
+    const int key = key_of(t, tile_len(ranges, work, t));
+    order[t] = (int32_t)(((uint32_t)key << 19) | atomicAdd(&bins[key], 1u));
   }
   __syncthreads();
   {  // exclusive scan of the 8192 bins: thread t owns bins [8 t, 8 t + 8)
@@ -602,32 +602,47 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   if (tid == 8) cbase[8] = (uint32_t)T;
   __syncthreads();
   const bool serp = (mode == 2 || mode == 4) && period > 0;
-  auto place = [&](int t, int len) {
-    int cls;
-    const uint32_t pos = atomicAdd(&bins[key_of(t, len, cls)], 1u);
-    int r = (int)(pos - cbase[cls]);
+  auto slot_of = [&](uint32_t packed) {
+    const int key = (int)(packed >> 19);
+    const int cls = key / cbins;
+    int r = (int)(bins[key] + (packed & 0x7FFFFu) - cbase[cls]);
     if (serp) {
       const int cnt = (int)(cbase[cls + 1] - cbase[cls]);
       const int st = r / period, ps = r - st * period;
       if (st & 1) r = st * period + (min(period, cnt - st * period) - 1 - ps);
     }
-    const int slot = per_xcd ? 8 * r + cls : r;
-    if (slot < ngrid) order[slot] = t;
+    return per_xcd ? 8 * r + cls : r;
   };
+  // pass 2 for the tiles parked in the order buffer: read them ALL before any slot is written (a slot may be
+  // another tile's parking place)
+  constexpr int TO_TAIL = 24;      // up to (TO_REGS + TO_TAIL) * 1024 = 40960 tiles (a 4K image has 32400)
+  uint32_t tail[TO_TAIL];
+#pragma unroll
+  for (int u = 0; u < TO_TAIL; ++u) {
+    const int t = tid + (TO_REGS + u) * 1024;
+    tail[u] = t < T ? (uint32_t)order[t] : 0u;
+  }
+  __syncthreads();
+  if (per_xcd) {   // the parking places go back to "no tile" before the real slots are written
+#pragma unroll
+    for (int u = 0; u < TO_TAIL; ++u) {
+      const int t = tid + (TO_REGS + u) * 1024;
+      if (t < T) order[t] = -1;
+    }
+    __syncthreads();
+  }
 #pragma unroll
   for (int r = 0; r < TO_REGS; ++r) {
     const int t = tid + r * 1024;
-    if (t < T) place(t, lenr[r]);
+    if (t < T) { const int slot = slot_of(kr[r]); if (slot < ngrid) order[slot] = t; }
   }
-  for (int t0 = tid + TO_REGS * 1024; t0 < T; t0 += 8 * 1024) {
-    int l8[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) l8[u] = (t0 + u * 1024 < T) ? tile_len(ranges, work, t0 + u * 1024) : 0;
-#pragma unroll
-    for (int u = 0; u < 8; ++u)
-      if (t0 + u * 1024 < T) place(t0 + u * 1024, l8[u]);
+  for (int u = 0; u < TO_TAIL; ++u) {
+    const int t = tid + (TO_REGS + u) * 1024;
+    if (t < T) { const int slot = slot_of(tail[u]); if (slot < ngrid) order[slot] = t; }
   }
 }
+constexpr int TILE_ORDER_MAX_T = (TO_REGS + 24) * 1024;   // what k_tile_order handles
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
 
@@ -1392,7 +1407,7 @@ static int tile_order_enqueue(DrawParams& p, int which, int32_t* buf, size_t buf
   if (mode <= 0 || !buf) return 0;
   const bool per_xcd = mode >= 3;
   const int ngrid = per_xcd ? tile_order_len(p.gx, p.gy) : p.T;
-  if ((size_t)ngrid > buf_len) return 0;     // (images beyond the workspace bound keep the plain map)
+  if ((size_t)ngrid > buf_len || p.T > TILE_ORDER_MAX_T) return 0;   // (larger images keep the plain map)
   static const int serp = [] { const char* e = getenv("EGS_TILE_SERP"); return e ? atoi(e) : 0; }();
   const int period = serp > 0 ? serp : (per_xcd ? 128 : 1024);   // SIMDs per XCD / per chip
   EGS_LAUNCH("k_tile_order", k_tile_order, dim3(1), dim3(1024), s, ranges, work, p.T, p.gx, mode, period, buf, ngrid);
