@@ -149,3 +149,25 @@ def test_second_backward_with_retain_graph():
     torch.cuda.synchronize()
     np.testing.assert_allclose(ps[0].grad.cpu().numpy(), g1.cpu().numpy(), rtol=0,
                                atol=2e-6 * max(1.0, float(g1.abs().max())))
+
+
+def test_tile_dispatch_order_is_a_sorted_permutation():
+    """``k_tile_order``: the dispatch order the draw kernels use is a permutation of the tiles, longest list first
+    on a camera's first render, most measured work first on its next one (``state.order`` = [order | work])."""
+    from easygaussiansplatting_amd import fused
+    args, cam = _scene(20000, 640, 368, 4)
+    T = (640 // 16) * (368 // 16)
+    with torch.no_grad():
+        _, _, st1 = fused.forward(*args, cam)
+        _, _, st2 = fused.forward(*args, cam)
+    torch.cuda.synchronize()
+    lens = (st1.ranges[:, 1] - st1.ranges[:, 0]).cpu().numpy()
+    for st, key in ((st1, lens), (st2, None)):
+        buf = st.order.cpu().numpy()
+        order, work = buf[:T], buf[-T:]
+        assert np.array_equal(np.sort(order), np.arange(T))
+        k = key if key is not None else work_prev // 4      # second render: sorted by the first one's work, bins of 4
+        assert (np.diff(k[order]) <= 0).all()
+        assert (work >= 0).all() and (work[lens == 0] == 0).all() and work.max() <= 6 * lens.max()
+        work_prev = work
+    np.testing.assert_array_equal(st1.order.cpu().numpy()[-T:], st2.order.cpu().numpy()[-T:])   # same image, same work
