@@ -385,11 +385,12 @@ __device__ __forceinline__ uint32_t bin_count_one(const BinParams& p, float ux, 
 
 // per-workgroup (256 threads) maximum of the depth keys -> maxkey[1 + workgroup]; no atomics (a
 // same-address atomicMax per wave measured +170 us); k_max_reduce folds the <= 4 K partial maxima
-__device__ __forceinline__ void block_max_key(uint32_t key, uint32_t* __restrict__ maxkey) {
+// `wm`: four words of LDS (the caller's: k_preprocess_fwd lends its staging buffer -- 16 bytes of its own would
+// be the 128 bytes too many that keep an eighth workgroup off the CU)
+__device__ __forceinline__ void block_max_key(uint32_t key, uint32_t* __restrict__ maxkey, uint32_t* wm) {
   uint32_t mk = key;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
-  __shared__ uint32_t wm[4];
   if ((threadIdx.x & 63) == 0) wm[threadIdx.x >> 6] = mk;
   __syncthreads();
   if (threadIdx.x == 0) maxkey[1 + blockIdx.x] = max(max(wm[0], wm[1]), max(wm[2], wm[3]));

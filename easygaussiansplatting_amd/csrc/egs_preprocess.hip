@@ -369,11 +369,14 @@ __device__ __forceinline__ void stage_span_out(const float* row, float* __restri
   for (int f = 4 * nq + tid; f < total; f += 256) dst[(size_t)K * base + f] = lds[f];
 }
 
+// Occupancy: 20 KB of LDS per workgroup = exactly 8 workgroups per CU (8 waves per SIMD, which needs <= 64 VGPRs).
+// With 7 -- one VGPR or 16 bytes of LDS too many -- the 3906 workgroups of 1 M Gaussians run as 2.2 "rounds" of
+// 1792, i.e. the launch ends with a third round that is 20 % full.
 // forward.md steps 1-5 for one Gaussian in one pass (== gsmodel.py:21-35 minus splat):
 // writes exactly what splat / splatB / the backward pass consume.
 // RAW: rots/scales/alphas are the un-activated tensors, shs = low_shs [N,3], shs_high = high_shs [N,K-3]
 template <int NC, bool RAW>
-__global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8, 8))) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
                                                         const float* __restrict__ rots,
                                                         const float* __restrict__ scales,
                                                         const float* __restrict__ shs,
@@ -454,7 +457,10 @@ __global__ __launch_bounds__(256) void k_preprocess_fwd(int n, PreParams pp, con
       make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alphas[i]) : alphas[i], col[0], col[1], col[2], rx, ry,
                   pp.W, pp.H, pp.footprint, pp.alpha_skip, r);
   }
-  if (bo.rc) block_max_key(dkey, bo.maxkey);
+  if (bo.rc) {
+    __syncthreads();   // (RAW: every wave is done with the rows staged in)
+    block_max_key(dkey, bo.maxkey, reinterpret_cast<uint32_t*>(stage));
+  }
   // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
   if (rec) stage_rows_out<12>(reinterpret_cast<const float*>(r), reinterpret_cast<float*>(rec), n, blockIdx.x * 256, stage);
 }

@@ -369,7 +369,8 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
     rc[i] = cnt ? pack_rect(rect.x, rect.y, rect.z, rect.w) : make_uint2(0u, 0u);
     dkeys[i] = key;
   }
-  block_max_key(key, maxkey);  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
+  __shared__ uint32_t wm[4];
+  block_max_key(key, maxkey, wm);  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
 }
 
 // ---- offsets of the Gaussians' patch runs, in depth order -------------------------------------------------
