@@ -497,6 +497,10 @@ def main():
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
                        "views_per_step": world, "policy": "gsplatcu", "mode": a.mode,
                        "validation": "deferred (commit per step)" if deferred else "immediate",
+                       "tile_dispatch": "forward: by the work measured at this camera's previous render (list "
+                                        "length at first sight); backward: by the work this render measured"
+                                        if fused_path.TILE_WORK_CACHE else "forward: by list length; backward: by "
+                                        "the work this render measured",
                        "patches": P, "tiles": T, "max_list_len": max_len, "pixel_gaussian_pairs": pairs},
             "gpu_busy_ms_per_step": None if gpu_busy_ms is None else round(gpu_busy_ms, 4),
             "wall_over_gpu_busy": None if not gpu_busy_ms else round(ms / gpu_busy_ms, 4),
