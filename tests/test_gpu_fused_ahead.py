@@ -171,3 +171,35 @@ def test_tile_dispatch_order_is_a_sorted_permutation():
         assert (work >= 0).all() and (work[lens == 0] == 0).all() and work.max() <= 6 * lens.max()
         work_prev = work
     np.testing.assert_array_equal(st1.order.cpu().numpy()[-T:], st2.order.cpu().numpy()[-T:])   # same image, same work
+
+
+def test_trainer_redoes_a_step_whose_view_outgrew_the_buffers():
+    """``Trainer.step`` renders with deferred validation; when ``commit()`` reports an incomplete render (here:
+    the learnt patch capacity is knocked down before the step) the step is redone and ends exactly where an
+    undisturbed trainer ends."""
+    from easygaussiansplatting_amd import fused, scene as S
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer
+    sc = S.small_scene(4000, 160, 96, 48, seed=6)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 2, radius=5.0)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    with torch.no_grad():
+        gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+    outs = []
+    for disturb in (False, True):
+        start = S.small_scene(4000, 160, 96, 48, seed=6)
+        start.shs[:, :3] += 0.3
+        tr = Trainer(start, cams, gts, max_steps=50, scene_size=4.0)
+        losses = [tr.step([0, 1])]
+        if disturb:
+            cap = fused._ctx(torch.device("cuda", 0)).capacity
+            for k in list(cap):
+                if k[0] == 4000:
+                    cap[k] = 100                       # far too small for the next renders
+        losses += [tr.step([0, 1]) for _ in range(2)]
+        assert tr.redone_steps == (1 if disturb else 0)
+        outs.append((losses, {k: v.detach().cpu().numpy() for k, v in tr.params.items()}))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=1e-5)
+    for k in outs[0][1]:
+        a, b = outs[0][1][k], outs[1][1][k]
+        assert np.abs(a - b).max() < 1e-4 * max(1e-3, np.abs(a).max()), k
