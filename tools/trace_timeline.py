@@ -15,7 +15,8 @@ for f in files:
             rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
 rows.sort()
 # the last step = from the last k_preprocess_fwd on
-starts = [i for i, r in enumerate(rows) if "k_preprocess_fwd" in r[2]]
+# (with the two-stream forward the side-stream part is k_preprocess_fwd<.., 2>: not a step boundary)
+starts = [i for i, r in enumerate(rows) if "k_preprocess_fwd" in r[2] and ", 2>(" not in r[2]]
 i0, i1 = starts[-2], starts[-1]
 step = rows[i0:i1]
 t0 = step[0][0]
@@ -25,7 +26,7 @@ print("%-46s %9s %9s %9s" % ("kernel", "start_us", "dur_us", "gap_us"))
 for s, e, name in step:
     gap = 0 if prev_end is None else (s - prev_end) / 1e3
     print("%-46s %9.1f %9.1f %9.1f" % (name[:46], (s - t0) / 1e3, (e - s) / 1e3, gap))
-    busy += e - s
-    prev_end = e
+    busy += e - max(s, prev_end or s) if e > (prev_end or 0) else 0   # concurrent launches count once
+    prev_end = max(e, prev_end or e)
 span = (rows[i1][0] - t0) / 1e3
 print("step span %.1f us, kernel busy %.1f us, idle %.1f us, launches %d" % (span, busy / 1e3, span - busy / 1e3, len(step)))
