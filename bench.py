@@ -69,7 +69,7 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         "k_sh2color": N * (4 * K + 12 + 12 + 4 * nc + 36),
         "k_inv_cov2d": N * (12 + 4 + 12 + 8 + 36),
         "k_bin_count": N * (8 + 8 + 4 + 8 + 4 + 4),
-        "k_bin_scan_partials": N * (4 + 8 + 8),      # sorted ids in, packed rects gathered once -> depth order
+        "k_bin_scan_partials": N * 8,                # depth-ordered packed rects (gathered by the depth sort's last scatter)
         "k_bin_scan_apply": N * (8 + 4),
         "k_pack_records": N * (36 + 8 + 48),
         "k_bin_emit": N * (4 + 4 + 8) + P * 8,

@@ -124,7 +124,11 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
     int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
-    const uint32_t* __restrict__ maxkey, const uint32_t* __restrict__ n_dev) {
+    const uint32_t* __restrict__ maxkey, const uint32_t* __restrict__ n_dev,
+    const uint2* __restrict__ gsrc, uint2* __restrict__ gdst) {
+  // gsrc != NULL (last pass of the depth sort): the 8-byte record gsrc[value] of every item is gathered into
+  // sorted order on the way out (gdst[pos]) -- the random reads hide behind this kernel's stores instead of
+  // heading the dependent scan kernel that follows
   if (n_dev) n = min(n, (int64_t)*n_dev);
   constexpr int RS_TILE = RS_THREADS * RS_IPT;       // items per workgroup
   constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // contiguous items per wave
@@ -134,7 +138,12 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
       const int64_t idx = blockbase + r * RS_THREADS + tid;
-      if (idx < n) { keys_out[idx] = keys_in[idx]; vals_out[idx] = vals_in[idx]; }
+      if (idx < n) {
+        const uint32_t v = vals_in[idx];
+        keys_out[idx] = keys_in[idx];
+        vals_out[idx] = v;
+        if (gsrc) gdst[idx] = gsrc[v];
+      }
     }
     return;
   }
@@ -208,8 +217,10 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     if (slot < nvalid) {
       const uint32_t k = skey[slot];
       const uint32_t pos = gadj[(k >> shift) & dmask] + (uint32_t)slot;
+      const uint32_t v = sval[slot];
       keys_out[pos] = k;
-      vals_out[pos] = sval[slot];
+      vals_out[pos] = v;
+      if (gsrc) gdst[pos] = gsrc[v];
     }
   }
 }
@@ -236,7 +247,8 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
                       int begin_bit, int end_bit, const SortWs& w, hipStream_t s,
                       const uint32_t* maxkey = nullptr, const uint32_t* n_dev = nullptr,
                       uint32_t* mk_parts = nullptr, int nparts = 0, uint32_t* mk_out = nullptr,
-                      uint32_t* mk_host = nullptr) {
+                      uint32_t* mk_host = nullptr, const uint2* gsrc = nullptr, uint2* gdst = nullptr) {
+  // gsrc/gdst: gdst[j] = gsrc[value of the j-th item of the sorted sequence], written by the last pass
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
   // the bits are spread evenly over the passes (13 tile bits = 7 + 6, not 8 + 5): fewer buckets per pass
@@ -248,6 +260,8 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
     const uint32_t dmask = (1u << nb) - 1u;
     const bool first = shift == begin_bit && mk_parts != nullptr;      // this pass produces maxkey[0]
     const uint32_t* mk = first ? nullptr : maxkey;
+    const bool last = shift + width >= end_bit;
+    const uint2* gs = last ? gsrc : nullptr;
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
                  w.nblocks, w.hist, mk, n_dev);
@@ -258,10 +272,10 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
                mk, first ? mk_parts : (uint32_t*)nullptr, nparts, mk_out, mk_host);
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
-                 dmask, w.nblocks, w.hist, w.totals, mk, n_dev);
+                 dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst);
     else
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n,
-                 shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev);
+                 shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
@@ -375,8 +389,9 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
 
 // ---- offsets of the Gaussians' patch runs, in depth order -------------------------------------------------
 // The depth sort moves (key, id) pairs only; what the binning needs of a Gaussian afterwards is its packed
-// rect (8 bytes).  It is gathered ONCE, by the first scan kernel, into depth order (rc_sorted); the second scan
-// kernel and k_bin_emit then stream contiguous arrays.  (The first version gathered counts[ids[j]] in both scan
+// rect (8 bytes).  It is gathered ONCE into depth order (rc_sorted) -- by the last scatter pass of the depth
+// sort, next to its stores (k_bin_scan_partials with ids == NULL then streams rc_sorted; with ids it does the
+// gather itself: 18.8 us instead of 7) -- and the scan kernels and k_bin_emit stream contiguous arrays.  (The first version gathered counts[ids[j]] in both scan
 // kernels and rects[ids[j]] in k_bin_emit: three dependent gathers through the sorted ids, 2.6-4x the
 // algorithmic traffic by the PMC counters.)
 __device__ __forceinline__ uint32_t rc_count(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
@@ -392,12 +407,12 @@ __global__ __launch_bounds__(256) void k_bin_scan_partials(const uint32_t* __res
 #pragma unroll
   for (int k = 0; k < SC_IPT; ++k) {      // all gathers in flight before the first use
     const int64_t i = base + k;
-    r[k] = (i < n) ? rc[ids[i]] : make_uint2(0u, 0u);
+    r[k] = (i < n) ? (ids ? rc[ids[i]] : rc_sorted[i]) : make_uint2(0u, 0u);
   }
 #pragma unroll
   for (int k = 0; k < SC_IPT; ++k) {
     const int64_t i = base + k;
-    if (i < n) rc_sorted[i] = r[k];
+    if (ids && i < n) rc_sorted[i] = r[k];
     s += rc_count(r[k]);
   }
   s = wave_inclusive_scan(s);
@@ -1522,15 +1537,15 @@ int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_
   // (the largest depth key -- total_patches[1], and the mailbox slot's second word -- comes out of the first
   // pass's rowscan kernel)
   int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey, nullptr, L.maxkey,
-                      div_up(n, 256), total_patches + 1, host_totals ? host_totals + 1 : nullptr);
+                      div_up(n, 256), total_patches + 1, host_totals ? host_totals + 1 : nullptr, L.rc, L.rc_sorted);
   if (rc) return rc;
   if (sort_passes(0, end_bit) & 1) {  // odd pass count: bring the result back to the primary buffers
     EGS_HIP(hipMemcpyAsync(L.dkeys, L.dkeys_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     EGS_HIP(hipMemcpyAsync(L.ids, L.ids_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   }
   const int nb = div_up(n, SC_TILE);
-  EGS_LAUNCH("k_bin_scan_partials", k_bin_scan_partials, dim3(nb), dim3(256), s, L.ids, L.rc, (int64_t)n, L.rc_sorted,
-             L.scan_partials);
+  EGS_LAUNCH("k_bin_scan_partials", k_bin_scan_partials, dim3(nb), dim3(256), s, (const uint32_t*)nullptr, L.rc,
+             (int64_t)n, L.rc_sorted, L.scan_partials);
   EGS_LAUNCH("k_bin_scan_apply", k_bin_scan_apply, dim3(nb), dim3(256), s, L.rc_sorted, (int64_t)n, L.scan_partials,
              L.offsets, total_patches, host_totals);
   EGS_LAUNCH_OK();
