@@ -111,7 +111,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                      float** gpack, void* stream, const void* rec_in /* packed records or NULL */,
                      const int32_t* tile_order /* dispatch order left by the forward pass, or NULL */,
-                     float* grad_records /* [N][12] records ALREADY ZEROED (by the forward draw kernel), or NULL */);
+                     float* grad_records /* [N][12] records ALREADY ZEROED (by the forward draw kernel), or NULL */,
+                     bool keep_forward_order = false /* dispatch the tiles exactly as tile_order says */);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

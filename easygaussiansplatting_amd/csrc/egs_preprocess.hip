@@ -804,6 +804,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   // chain rule, for rows [row_begin, row_begin + row_count) -- a data-parallel caller launches the rows in a
   // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && patches >= 0);
+  const bool keep_order = (phase & EGS_BWD_KEEP_FORWARD_ORDER) != 0;
+  phase &= ~EGS_BWD_KEEP_FORWARD_ORDER;
   EGS_CHECK_ARG(phase >= 0 && phase <= 2);
   if (phase != 2) { row_begin = 0; row_count = n; }
   EGS_CHECK_ARG(row_begin >= 0 && row_count >= 0 && row_begin + (int64_t)row_count <= n && row_begin % 256 == 0);
@@ -821,7 +823,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   if (phase != 2) {
     int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
                               patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec,
-                              tile_order, grad_records);
+                              tile_order, grad_records, keep_order);
     if (rc) return rc;
     if (phase == 1) return 0;
   }

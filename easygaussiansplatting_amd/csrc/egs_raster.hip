@@ -1698,7 +1698,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                      float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order,
-                     float* grad_records) {
+                     float* grad_records, bool keep_forward_order) {
   hipStream_t s = (hipStream_t)stream;
   const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
   // [N][12] packed gradient records: the caller's (already zeroed by the forward draw kernel) or a piece of ws
@@ -1715,7 +1715,13 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
   static const int by_work = [] { const char* e = getenv("EGS_DRAWB_BY_WORK"); return e ? atoi(e) : 1; }();
-  if (tile_order && by_work && tile_order_mode(1) > 0 && (size_t)tile_order_len(dp.gx, dp.gy) <= BWD_ORDER_CAP) {
+  const bool same_mode = tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0;
+  if (tile_order && keep_forward_order && same_mode) {
+    // the forward pass already dispatched by measured work (that of the camera's previous render, one step or
+    // one epoch old -- as good a key for this pass as for that one): no second k_tile_order (8 us)
+    dp.order = tile_order;
+    dp.ngrid = tile_order_mode(1) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
+  } else if (tile_order && by_work && tile_order_mode(1) > 0 && (size_t)tile_order_len(dp.gx, dp.gy) <= BWD_ORDER_CAP) {
     // the forward draw kernel left behind how far every tile walked its list: order the tiles by THAT (the list
     // length mis-ranks tiles whose pixels saturate early; simulated with the measured work of the 1 M scene:
     // makespan 1.11 x ideal by length, 1.03 x by work)
@@ -1723,7 +1729,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s,
                                       tile_order + tile_order_len(dp.gx, dp.gy));
     if (rc) return rc;
-  } else if (tile_order && tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0) {
+  } else if (tile_order && same_mode) {
     // the forward pass left its dispatch order behind (same mode): no second k_tile_order
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(1) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;

@@ -30,6 +30,8 @@ from .gsplatcu import _alphas, _bin_stage, _chk, _lib_on, _pol, _ptr, _stream, _
 
 ENQUEUE_AHEAD = os.environ.get("EGS_ENQUEUE_AHEAD", "1") != "0"   # knob for A/B measurements and tests
 MAILBOX_COPY = os.environ.get("EGS_MAILBOX_COPY", "0") == "1"     # A/B knob: read-back by copy instead of kernel stores
+REUSE_ORDER = os.environ.get("EGS_BWD_REUSE_ORDER", "1") != "0"   # A/B knob: see KEEP_FORWARD_ORDER
+KEEP_FORWARD_ORDER = 16   # include/egs_hip.h EGS_BWD_KEEP_FORWARD_ORDER
 TILE_WORK_CACHE = os.environ.get("EGS_TILE_WORK_CACHE", "1") != "0"  # A/B knob: forward dispatch order by remembered work
 MAILBOX_SLOTS = 64
 
@@ -38,7 +40,7 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "order", "gpack", "width", "height", "ticket", "_patches", "_keep")
+                 "order", "order_by_work", "gpack", "width", "height", "ticket", "_patches", "_keep")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
@@ -273,6 +275,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                 ctx.tile_work[ck] = (weakref.ref(cam), S.order)
             except TypeError:                           # a camera object that cannot be weakly referenced
                 pass
+    S.order_by_work = prev_work is not None
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
     def render_exact():
@@ -397,17 +400,19 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *mid, _ptr(dalphas),
             _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), phase, b, c, st))
+    # the forward pass was dispatched by remembered work: the backward pass keeps its order (no second order kernel)
+    keep = KEEP_FORWARD_ORDER if (REUSE_ORDER and getattr(S, "order_by_work", False)) else 0
     hook = _exchange_hook
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups
     if hook is None or chunks <= 1 or rows >= n:
-        launch(0, 0, n)
+        launch(0 | keep, 0, n)
         if hook is not None:
             hook.on_chunk(parts)
     else:
         # The chain rule runs in a few row chunks; each chunk's gradient slices go to the exchange as soon as
         # its kernel is enqueued, so the all-reduce of chunk k overlaps the computation of chunk k + 1
-        launch(1, 0, 0)
+        launch(1 | keep, 0, 0)
         for b in range(0, n, rows):
             c = min(rows, n - b)
             launch(2, b, c)

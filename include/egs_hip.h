@@ -241,6 +241,10 @@ uint32_t* egs_mailbox_slot(void* mailbox, int slot);
 int egs_mailbox_arm(void* mailbox, int slot, void* stream);
 int egs_mailbox_fetch(void* mailbox, int slot, int blocking, uint32_t* out2);
 size_t egs_fused_backward_ws_bytes(int n);
+/* OR-ed into `phase`: the forward pass that filled tile_order was itself dispatched by measured work
+ * (prev_tile_work != NULL), so the backward pass keeps that order instead of sorting the tiles again by the
+ * work this render measured (one k_tile_order launch, 8 us, less; without the flag it sorts). */
+#define EGS_BWD_KEEP_FORWARD_ORDER 16
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
  * phase 2: only the per-Gaussian chain rule for rows [row_begin, row_begin + row_count), row_begin a multiple
  * of 256, reading the records phase 1 left in the SAME ws: a data-parallel caller launches the rows in a few

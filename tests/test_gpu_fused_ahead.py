@@ -203,3 +203,29 @@ def test_trainer_redoes_a_step_whose_view_outgrew_the_buffers():
     for k in outs[0][1]:
         a, b = outs[0][1][k], outs[1][1][k]
         assert np.abs(a - b).max() < 1e-4 * max(1e-3, np.abs(a).max()), k
+
+
+def test_backward_in_the_forward_dispatch_order(monkeypatch):
+    """A camera rendered before is dispatched by its remembered work, and the backward pass then keeps that order
+    (EGS_BWD_KEEP_FORWARD_ORDER) instead of sorting the tiles again: same gradients either way."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import GSFunction
+    args, cam = _scene(20000, 640, 368, 13)
+    dl = torch.randn((3, 368, 640), device="cuda") / (3 * 368 * 640)
+
+    def grads():
+        ps = [a.clone().requires_grad_(True) for a in args]
+        ps[2] = ps[2].detach().reshape(-1, 1).clone().requires_grad_(True)
+        us = torch.zeros((20000, 2), device="cuda", requires_grad=True)
+        img, _ = GSFunction.apply(ps[0], ps[1], ps[2], ps[3], ps[4], us, cam)
+        img.backward(dl)
+        torch.cuda.synchronize()
+        return [p.grad.cpu().numpy() for p in ps] + [us.grad.cpu().numpy()]
+    grads()                                   # first render of this camera: leaves its per-tile work behind
+    monkeypatch.setattr(fused, "REUSE_ORDER", False)
+    a = grads()
+    monkeypatch.setattr(fused, "REUSE_ORDER", True)
+    b = grads()
+    for x, y in zip(a, b):
+        assert np.abs(x).max() > 0
+        np.testing.assert_allclose(x, y, rtol=0, atol=2e-6 * max(1.0, np.abs(x).max()))
