@@ -16,7 +16,7 @@ With N > 1 every rank renders its own camera view of the same scene (one view pe
 step ends with an RCCL all-reduce of the parameter gradients (236 MB at 1 M Gaussians); `value` is the
 whole-job rate: N * W*H / t_step.
 
-Order of a run: ``--ramp-ms`` (default 150) of untimed steps that take the GPU off its idle clocks, the W warm-up
+Order of a run: ``--ramp-steps`` (default 150) untimed steps that take the GPU off its idle clocks, the W warm-up
 steps, an untimed pre-pass with every launch bracketed by HIP events (per-kernel table), then EXACTLY K timed
 steps between barrier + synchronize pairs -- back to back, the garbage collector parked, so that the timed
 region sees the steady state of a training run and not the clock ramp (measured: 20 steps timed cold 1.03-1.04
@@ -140,9 +140,10 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-dim", type=int, default=48)
-    ap.add_argument("--ramp-ms", type=float, default=150.0,
-                    help="untimed render steps for this long BEFORE the warm-up steps: the GPU leaves its idle clocks "
-                         "(20 steps measured cold are ~7 %% slower than the steady state a training run sees)")
+    ap.add_argument("--ramp-steps", type=int, default=150,
+                    help="untimed render steps BEFORE the warm-up steps (~0.15 s): the GPU leaves its idle clocks "
+                         "(20 steps measured cold are ~7 %% slower than the steady state a training run sees); "
+                         "a count, not a duration, so that all ranks issue the same collectives")
     ap.add_argument("--cpu-sample", type=int, default=250_000, help="Gaussians in the cpu_baseline sample (0 = skip)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
@@ -272,11 +273,8 @@ def main():
     # lets the GPU fall back to its idle clocks right before the clock starts
     gc.collect()
     gc.disable()
-    t_ramp = time.perf_counter()
-    ramp_steps = 0
-    while (time.perf_counter() - t_ramp) * 1e3 < a.ramp_ms:   # clock ramp (no effect on what a step computes)
+    for _ in range(max(0, a.ramp_steps)):   # clock ramp (no effect on what a step computes)
         step()
-        ramp_steps += 1
     for _ in range(a.warmup):
         step()
     sync()
@@ -514,7 +512,7 @@ def main():
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
                        "views_per_step": world, "policy": "gsplatcu", "mode": a.mode,
                        "validation": "deferred (commit per step)" if deferred else "immediate",
-                       "preconditioning": "%d untimed steps (%.0f ms) before the warm-up steps" % (ramp_steps, a.ramp_ms),
+                       "preconditioning": "%d untimed steps before the warm-up steps (clock ramp)" % max(0, a.ramp_steps),
                        "tile_dispatch": "forward: by the work measured at this camera's previous render (list "
                                         "length at first sight); backward: by the work this render measured"
                                         if fused_path.TILE_WORK_CACHE else "forward: by list length; backward: by "

@@ -1,5 +1,5 @@
 #!/bin/bash
-# how the timed step depends on what precedes it (idle clocks, the collector): bench.py at several --steps / --warmup / --ramp-ms
+# how the timed step depends on what precedes it (idle clocks, the collector): bench.py at several --steps / --warmup / --ramp-steps
 cd $GRAFT_REPO_ROOT; O=gpurun_out/ramp; mkdir -p $O; export PYTHONDONTWRITEBYTECODE=1
 B="python bench.py --cpu-sample 0 --no-ops"
 for spec in "$@"; do

@@ -13,7 +13,7 @@
 
 namespace egs {
 enum { FMA, EXP, RCP, SWAP32, SWAP16, DPPADD, CNDMASK, READLANE, MOV64, MED3, CMPS, SWZ, BPERM, DPPMASK, VMIN, MOV32, CMPX,
-       SWZADD, FMAC, NOPS };
+       SWZADD, FMAC, PKFMA, PKMUL, PKADD, VADD, VMUL, NOPS };
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
@@ -21,6 +21,10 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
 #pragma unroll
   for (int i = 0; i < CHAINS; ++i) { a[i] = seed + i + threadIdx.x * 1e-3f; b[i] = seed * 0.5f + i; }
   float c = seed * 1.0001f;
+  typedef float f2 __attribute__((ext_vector_type(2)));
+  f2 pa[CHAINS / 2], pb[CHAINS / 2], pc = {c, c * 0.999f};
+#pragma unroll
+  for (int i = 0; i < CHAINS / 2; ++i) { pa[i] = f2{a[2 * i], a[2 * i + 1]}; pb[i] = f2{b[2 * i], b[2 * i + 1]}; }
   const int addr = ((threadIdx.x & 63) ^ 32) * 4;
   for (int it = 0; it < ITERS; ++it) {
 #pragma unroll
@@ -47,17 +51,25 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
       if (OP == SWZADD) { float t; asm volatile("ds_swizzle_b32 %0, %1 offset:swizzle(BITMASK_PERM, \"0000p\")" : "=v"(t) : "v"(b[i]));
                           asm volatile("s_waitcnt lgkmcnt(0)\n v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(t)); }
       if (OP == FMAC) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
+      // packed f32: two lanes' worth of work per instruction on an aligned register pair (4 pairs = 8 values)
+      if (OP == PKFMA && i < CHAINS / 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[i]) : "v"(pc), "v"(pb[i]));
+      if (OP == PKMUL && i < CHAINS / 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pa[i]) : "v"(pc));
+      if (OP == PKADD && i < CHAINS / 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pa[i]) : "v"(pb[i]));
+      if (OP == VADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
+      if (OP == VMUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
     }
   }
   float s = 0;
 #pragma unroll
   for (int i = 0; i < CHAINS; ++i) s += a[i] + b[i];
+#pragma unroll
+  for (int i = 0; i < CHAINS / 2; ++i) s += pa[i].x + pa[i].y;
   if (s == 12345.678f) out[0] = s;
 }
 }  // namespace egs
 
 template <int OP>
-static void run(const char* name, float* d) {
+static void run(const char* name, float* d, int per_iter = CHAINS) {
   const int blocks = 2048;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -68,7 +80,7 @@ static void run(const char* name, float* d) {
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms; hipEventElapsedTime(&ms, e0, e1);
-  const double winst = (double)blocks * 4 * ITERS * CHAINS / 1024.0;   // wave-instructions per SIMD
+  const double winst = (double)blocks * 4 * ITERS * per_iter / 1024.0;   // wave-instructions per SIMD
   printf("%-10s %8.3f ms  %6.3f ns per wave-instr per SIMD (= %.2f cycles @2.4 GHz nominal)\n", name, ms,
          ms * 1e6 / winst, ms * 1e6 / winst * 2.4);
 }
@@ -82,5 +94,9 @@ int main() {
   run<egs::SWZ>("ds_swizzle", d); run<egs::BPERM>("ds_bpermute", d); run<egs::DPPMASK>("add_dpp_rowmask", d);
   run<egs::VMIN>("v_min", d); run<egs::MOV32>("mov_b32", d); run<egs::CMPX>("cmpx+exec", d);
   run<egs::SWZADD>("swizzle+wait+add", d); run<egs::FMAC>("v_fmac", d);
+  // packed f32 (CHAINS/2 instructions per iteration, each doing two values per lane)
+  run<egs::PKFMA>("v_pk_fma", d, CHAINS / 2); run<egs::PKMUL>("v_pk_mul", d, CHAINS / 2);
+  run<egs::PKADD>("v_pk_add", d, CHAINS / 2);
+  run<egs::VADD>("v_add", d); run<egs::VMUL>("v_mul", d);
   return 0;
 }
