@@ -1559,7 +1559,10 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            size_t ws_draw_bytes, const float4* rec_in, float* image, int32_t* contrib,
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
                            void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
-                           float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr) {
+                           float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr,
+                           int order_ready = 0) {
+  // order_ready != 0: tile_order already holds a dispatch order (an earlier render through the SAME buffer left
+  // it there): it is used as it stands, no k_tile_order launch; the work part is still rewritten by the draw
   // prev_tile_work != NULL (T ints): the work the draw kernel measured per tile the LAST time this camera was
   // rendered -- a much better sort key for the dispatch order than the list length (pixels saturate)
   // grad_records != NULL ([N][12] floats): zeroed on the side by the draw kernel for the coming backward pass
@@ -1608,9 +1611,14 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   if (rc) return rc;
   EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
                      patch_range_per_tile, patches_dev);
-  rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
-                          patch_range_per_tile, s, prev_tile_work);
-  if (rc) return rc;
+  if (order_ready && tile_order && tile_order_mode(0) > 0 && dp.T <= TILE_ORDER_MAX_T) {
+    dp.order = tile_order;
+    dp.ngrid = tile_order_mode(0) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
+  } else {
+    rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
+                            patch_range_per_tile, s, prev_tile_work);
+    if (rc) return rc;
+  }
   if (tile_order) dp.work_out = tile_order + tile_order_len(dp.gx, dp.gy);
   if (grad_records) {
     dp.zero_buf = (float4*)grad_records;
@@ -1660,12 +1668,13 @@ extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height,
                                   const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                   float* image, int32_t* contrib, float* final_tau,
                                   int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                  float* grad_records, const int32_t* prev_tile_work, void* stream) {
+                                  float* grad_records, const int32_t* prev_tile_work, int order_ready,
+                                  void* stream) {
   EGS_CHECK_ARG(rec || n == 0);
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
                          patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order, grad_records,
-                         prev_tile_work);
+                         prev_tile_work, order_ready);
 }
 
 // as egs_splat_draw_rec, enqueued BEFORE the host has read total_patches: patch_capacity sizes
@@ -1676,14 +1685,15 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                                       const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                       float* image, int32_t* contrib, float* final_tau,
                                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                      float* grad_records, const int32_t* prev_tile_work, void* stream) {
+                                      float* grad_records, const int32_t* prev_tile_work, int order_ready,
+                                      void* stream) {
   EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
   if (host_totals)
     EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, (hipStream_t)stream));
   return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
                          patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records,
-                         prev_tile_work);
+                         prev_tile_work, order_ready);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]

@@ -32,7 +32,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 2
+#define EGS_ABI_VERSION 3
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -197,10 +197,15 @@ int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
                        int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
-                       float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/, void* stream);
+                       float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/,
+                       int order_ready, void* stream);
 /* prev_tile_work (nullable, T ints): the work part of the tile_order buffer an EARLIER render of the same camera
  * left behind; the forward dispatch order then sorts by it instead of by the list lengths.  Any values are
- * legal (every permutation of the tiles gives the same image), good ones balance the launch. */
+ * legal (every permutation of the tiles gives the same image), good ones balance the launch.  It may be the work
+ * part of tile_order itself (a caller that keeps ONE buffer per camera: the order is refreshed in place).
+ * order_ready != 0: tile_order already holds a dispatch order from an earlier render through the same buffer;
+ * the draw uses it as it stands (no k_tile_order launch, 10 us) and only rewrites the work part.  The work
+ * pattern of a camera drifts slowly, so a caller refreshes every few renders, not every time. */
 /* grad_records (nullable, [N][12] floats): the packed per-Gaussian gradient records of the COMING backward pass;
  * the draw kernel zeroes them on the side (it is VALU-bound, the memory system idles) and egs_fused_backward,
  * given the same pointer, skips its own 48 N-byte fill.  Valid for ONE backward pass.
@@ -220,7 +225,7 @@ int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_
                            void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                            int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
                            float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/,
-                           void* stream);
+                           int order_ready, void* stream);
 /* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
  * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
 int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);

@@ -152,25 +152,43 @@ def test_second_backward_with_retain_graph():
 
 
 def test_tile_dispatch_order_is_a_sorted_permutation():
-    """``k_tile_order``: the dispatch order the draw kernels use is a permutation of the tiles, longest list first
-    on a camera's first render, most measured work first on its next one (``state.order`` = [order | work])."""
+    """``k_tile_order``: the dispatch order the draw kernels use is a permutation of the tiles -- longest list first
+    on a camera's first render, most measured work first on its second one, then kept as it stands (no order
+    kernel) and refreshed from the latest work every ``ORDER_REFRESH``-th render.  A camera keeps ONE
+    ``[order | work]`` buffer (``state.order``); the image never depends on the order."""
     from easygaussiansplatting_amd import fused
     args, cam = _scene(20000, 640, 368, 4)
     T = (640 // 16) * (368 // 16)
+    snaps, imgs = [], []
     with torch.no_grad():
-        _, _, st1 = fused.forward(*args, cam)
-        _, _, st2 = fused.forward(*args, cam)
-    torch.cuda.synchronize()
-    lens = (st1.ranges[:, 1] - st1.ranges[:, 0]).cpu().numpy()
-    for st, key in ((st1, lens), (st2, None)):
-        buf = st.order.cpu().numpy()
+        for rep in range(fused.ORDER_REFRESH + 1):
+            img, _, st = fused.forward(*args, cam)
+            torch.cuda.synchronize()
+            snaps.append(st.order.cpu().numpy().copy())
+            imgs.append(img.cpu().numpy())
+            assert rep == 0 or st.order is prev              # one buffer per camera
+            assert st.order_by_work == (rep > 0)
+            prev = st.order
+    lens = (st.ranges[:, 1] - st.ranges[:, 0]).cpu().numpy()
+    for rep, buf in enumerate(snaps):
         order, work = buf[:T], buf[-T:]
         assert np.array_equal(np.sort(order), np.arange(T))
-        k = key if key is not None else work_prev // 4      # second render: sorted by the first one's work, bins of 4
-        assert (np.diff(k[order]) <= 0).all()
         assert (work >= 0).all() and (work[lens == 0] == 0).all() and work.max() <= 6 * lens.max()
-        work_prev = work
-    np.testing.assert_array_equal(st1.order.cpu().numpy()[-T:], st2.order.cpu().numpy()[-T:])   # same image, same work
+        np.testing.assert_array_equal(work, snaps[0][-T:])   # same image, same work
+        np.testing.assert_array_equal(imgs[rep], imgs[0])
+    assert (np.diff(lens[snaps[0][:T]]) <= 0).all()          # first render: by list length
+    by_work = snaps[1][:T]                                   # second render: by the first one's work, bins of 4
+    assert (np.diff((snaps[0][-T:] // 4)[by_work]) <= 0).all()
+    for rep in range(2, fused.ORDER_REFRESH + 1):
+        if (rep + 1) % fused.ORDER_REFRESH == 0:             # refreshed (ties may land in another sequence)
+            assert (np.diff((snaps[0][-T:] // 4)[snaps[rep][:T]]) <= 0).all()
+        else:                                                # kept as it stands
+            np.testing.assert_array_equal(snaps[rep][:T], snaps[rep - 1][:T])
+    other = torch.cuda.Stream()                              # another stream: its own buffer
+    with torch.cuda.stream(other), torch.no_grad():
+        _, _, st2 = fused.forward(*args, cam)
+    torch.cuda.synchronize()
+    assert st2.order is not prev and not st2.order_by_work
 
 
 def test_trainer_redoes_a_step_whose_view_outgrew_the_buffers():
