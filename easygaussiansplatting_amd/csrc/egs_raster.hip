@@ -861,6 +861,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   // the list value of the NEXT chunk is fetched one chunk ahead: the staging of a chunk then pays one global
   // latency (the record gather), not two dependent ones
   int gnext = (lane < n) ? gsid[r0 + lane] : 0;
+#ifdef EGS_DRAW_DUMMY_SALU
+  uint32_t dummy_s = 0;
+#endif
+#ifdef EGS_DRAW_DUMMY_VALU
+  float dummy_v = 1.f;
+#endif
   for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     int mymask = 0;   // reach mask of the entry THIS lane staged (lane j <-> entry base + j)
@@ -904,7 +910,19 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
       const int reach = (int)((act >> (4 * t)) & 0xFu);
       if (reach != 0) {  // scalar branch: some live block is within reach of this entry
         const int j = j0 + t;
+#ifdef EGS_DRAW_PROBE_NOK    // LDS probe: two broadcast reads per entry instead of three (WRONG colours)
+        const float4 Q = sA[j], P = sB[j], K = make_float4(0.5f, 0.25f, 0.125f, 0.f);
+#else
         const float4 Q = sA[j], P = sB[j], K = sC[j];  // wave-uniform address: LDS broadcast
+#endif
+#ifdef EGS_DRAW_DUMMY_SALU   // issue-limit probe (tools/lab_issue_probe.sh): N extra scalar instructions per entry
+#pragma unroll
+        for (int q = 0; q < EGS_DRAW_DUMMY_SALU; ++q) asm volatile("s_add_u32 %0, %0, 1" : "+s"(dummy_s) : : "scc");
+#endif
+#ifdef EGS_DRAW_DUMMY_VALU   // ... or N extra full-rate vector instructions
+#pragma unroll
+        for (int q = 0; q < EGS_DRAW_DUMMY_VALU; ++q) asm volatile("v_add_f32 %0, %0, %0" : "+v"(dummy_v));
+#endif
         bool inx[2] = {true, true}, iny[2] = {true, true};
         if (BOX) {
           const uint32_t bx = __float_as_uint(P.w), by = __float_as_uint(K.w);
@@ -949,6 +967,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
     }
     }
   }
+#ifdef EGS_DRAW_DUMMY_SALU
+  if (dummy_s == 0xFFFFFFFFu) cr[0] += 1.f;   // (keeps the probe's chain alive)
+#endif
+#ifdef EGS_DRAW_DUMMY_VALU
+  if (dummy_v == 12345.f) cr[0] += 1.f;
+#endif
   if (p.work_out) {   // what k_draw_bwd will walk: the largest contributor index of the tile and of its blocks
     int w = 0, wmax = 0;
 #pragma unroll

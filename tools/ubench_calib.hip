@@ -13,7 +13,7 @@
 
 namespace egs {
 enum { FMA, EXP, RCP, SWAP32, SWAP16, DPPADD, CNDMASK, READLANE, MOV64, MED3, CMPS, SWZ, BPERM, DPPMASK, VMIN, MOV32, CMPX,
-       SWZADD, FMAC, PKFMA, PKMUL, PKADD, VADD, VMUL, NOPS };
+       SWZADD, FMAC, PKFMA, PKMUL, PKADD, VADD, VMUL, DSR128B, DSR128, DSR64B, DSR32B, NOPS };
 
 template <int OP>
 __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
@@ -26,7 +26,16 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
 #pragma unroll
   for (int i = 0; i < CHAINS / 2; ++i) { pa[i] = f2{a[2 * i], a[2 * i + 1]}; pb[i] = f2{b[2 * i], b[2 * i + 1]}; }
   const int addr = ((threadIdx.x & 63) ^ 32) * 4;
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  f4 q4[2] = {f4{0, 0, 0, 0}, f4{0, 0, 0, 0}};
+  __shared__ float lds_buf[4096];
+  if (OP >= DSR128B && OP <= DSR32B) {
+    for (int i = threadIdx.x; i < 4096; i += 256) lds_buf[i] = seed + i;
+    __syncthreads();
+  }
+  const int zero = (int)(seed > 1e30f), lane16 = (threadIdx.x & 63) * 16;
   for (int it = 0; it < ITERS; ++it) {
+    if (OP >= DSR128B && OP <= DSR32B) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
     for (int i = 0; i < CHAINS; ++i) {
       if (OP == FMA) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(c), "v"(b[i]));
@@ -55,6 +64,12 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
       if (OP == PKFMA && i < CHAINS / 2) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(pa[i]) : "v"(pc), "v"(pb[i]));
       if (OP == PKMUL && i < CHAINS / 2) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(pa[i]) : "v"(pc));
       if (OP == PKADD && i < CHAINS / 2) asm volatile("v_pk_add_f32 %0, %0, %1" : "+v"(pa[i]) : "v"(pb[i]));
+      // LDS reads: every lane the SAME address (broadcast: how the draw kernels fetch an entry's record) vs one
+      // 16-B piece per lane; the LDS pipe is shared by the four SIMDs of a CU
+      if (OP == DSR128B) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q4[i & 1]) : "v"(zero), "n"(16 * i));
+      if (OP == DSR128) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(q4[i & 1]) : "v"(lane16), "n"(1024 * i));
+      if (OP == DSR64B) asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(pa[i & 3]) : "v"(zero), "n"(16 * i));
+      if (OP == DSR32B) asm volatile("ds_read_b32 %0, %1 offset:%2" : "=v"(a[i]) : "v"(zero), "n"(16 * i));
       if (OP == VADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b[i]));
       if (OP == VMUL) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(c));
     }
@@ -64,6 +79,8 @@ __global__ __launch_bounds__(256) void k_ub(float* out, float seed) {
   for (int i = 0; i < CHAINS; ++i) s += a[i] + b[i];
 #pragma unroll
   for (int i = 0; i < CHAINS / 2; ++i) s += pa[i].x + pa[i].y;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  s += q4[0].x + q4[1].y + lds_buf[threadIdx.x];
   if (s == 12345.678f) out[0] = s;
 }
 }  // namespace egs
@@ -98,5 +115,7 @@ int main() {
   run<egs::PKFMA>("v_pk_fma", d, CHAINS / 2); run<egs::PKMUL>("v_pk_mul", d, CHAINS / 2);
   run<egs::PKADD>("v_pk_add", d, CHAINS / 2);
   run<egs::VADD>("v_add", d); run<egs::VMUL>("v_mul", d);
+  run<egs::DSR128B>("ds_read_b128 bcast", d); run<egs::DSR128>("ds_read_b128 lanes", d);
+  run<egs::DSR64B>("ds_read_b64 bcast", d); run<egs::DSR32B>("ds_read_b32 bcast", d);
   return 0;
 }
