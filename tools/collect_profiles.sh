@@ -11,8 +11,8 @@ python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/bench_20_5.json 2>>
 # the same command under rocprofv3 kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --cpu-sample 0 --no-ops > $O/bench_under_rocprof.json 2>/tmp/ks.err
 find /tmp/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
-# one step as a timeline (no event brackets)
-rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $R/tools/profile_step.py --steps 8 > /tmp/tr.log 2>&1
+# one step as a timeline (no event brackets), after 150+ steps: steady-state clocks
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $R/tools/profile_step.py --steps 160 > /tmp/tr.log 2>&1
 python $R/tools/trace_timeline.py /tmp/tr > $O/step_timeline.txt
 # HBM traffic counters (separate passes, no tracing besides kernel-trace)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p1 -- python $R/tools/profile_step.py --steps 3 > /tmp/p1.log 2>&1
