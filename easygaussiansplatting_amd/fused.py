@@ -71,9 +71,10 @@ class _DeviceCtx:
         self.pending = collections.deque()
         self.failed = []
         self.capacity = {}      # (N, W, H) -> patch-list allocation size learnt from earlier renders
-        # camera -> (weakref, order buffer of its last render): the per-tile work the draw kernel measured then is
-        # the sort key of this render's dispatch order (a trainer meets every view again each epoch)
+        # (camera, stream) -> (weakref, its [order | work] buffer, renders so far, problem size): the dispatch order
+        # of the tiles is kept between the renders of a camera (a trainer meets every view again each epoch)
         self.tile_work = {}
+        self.tile_work_limit = 4096
         self.lock = threading.RLock()
 
 
@@ -269,11 +270,11 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     # no order kernel at all on most renders (10 us forward, 8 us backward at 1080p).
     prev_work, order_ready = None, 0
     if TILE_WORK_CACHE and n > 0:
-        ck = (id(cam), n, W, H, int(st.value or 0))
+        ck = (id(cam), int(st.value or 0))              # one entry per camera and stream, whatever the scene size
         olen = lib.egs_tile_order_len(W, H)
         with ctx.lock:
             hit = ctx.tile_work.get(ck)
-            if hit is not None and hit[0]() is cam and hit[1].numel() == olen:
+            if hit is not None and hit[0]() is cam and hit[1].numel() == olen and hit[3] == (n, W, H):
                 S.order = hit[1]
                 renders = hit[2] + 1
                 if renders == 2 or renders % ORDER_REFRESH == 0:
@@ -283,10 +284,11 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             else:
                 S.order = torch.empty(olen, dtype=i32, device=dev)
                 renders = 1
-            if len(ctx.tile_work) > 4096:               # (cameras that no longer exist)
+            if len(ctx.tile_work) > ctx.tile_work_limit:    # (cameras that no longer exist)
                 ctx.tile_work = {k: v for k, v in ctx.tile_work.items() if v[0]() is not None}
+                ctx.tile_work_limit = max(4096, 2 * len(ctx.tile_work))
             try:
-                ctx.tile_work[ck] = (weakref.ref(cam), S.order, renders)
+                ctx.tile_work[ck] = (weakref.ref(cam), S.order, renders, (n, W, H))
             except TypeError:                           # a camera object that cannot be weakly referenced
                 pass
     if S.order is None:
