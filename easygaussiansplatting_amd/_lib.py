@@ -58,6 +58,8 @@ SIGNATURES = {
     "egs_splat_draw_ws_bytes": (_sz, [_i, _i64, _i, _i]),
     "egs_splat_bin": (_i, [_i, _i, _i, _P, _P, _P, _PP, _i, _P, _sz, _P, _P]),
     "egs_splat_draw": (_i, [_i, _i64, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P]),
+    "egs_splat_bin_mb": (_i, [_i, _i, _i, _P, _P, _P, _PP, _i, _P, _sz, _P, _P, _P]),
+    "egs_splat_draw_dev": (_i, [_i, _i64, _P, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P]),
     "egs_splat_bwd_ws_bytes": (_sz, [_i]),
     "egs_splat_bwd": (_i, [_i, _i64, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P, _P, _P, _P, _P, _sz,
                            _P, _P, _P, _P, _P]),

@@ -1505,14 +1505,34 @@ extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int
   return draw_ws_bytes(n, patches, width, height);
 }
 
+static int splat_bin_impl(int n, int width, int height, const float* us, int32_t* areas, float* depths,
+                          const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                          uint32_t* total_patches, uint32_t* host_totals, void* stream);
+
 extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int32_t* areas, float* depths,
                              const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
                              uint32_t* total_patches, void* stream) {
+  return splat_bin_impl(n, width, height, us, areas, depths, pol, key_bits_hint, ws_bin, ws_bin_bytes, total_patches,
+                        nullptr, stream);
+}
+
+// the same, the kernels also storing {P, max depth key} into a page-locked mailbox slot (egs_mailbox_slot)
+extern "C" int egs_splat_bin_mb(int n, int width, int height, const float* us, int32_t* areas, float* depths,
+                                const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                                uint32_t* total_patches, uint32_t* host_totals, void* stream) {
+  return splat_bin_impl(n, width, height, us, areas, depths, pol, key_bits_hint, ws_bin, ws_bin_bytes, total_patches,
+                        host_totals, stream);
+}
+
+static int splat_bin_impl(int n, int width, int height, const float* us, int32_t* areas, float* depths,
+                          const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                          uint32_t* total_patches, uint32_t* host_totals, void* stream) {
   EGS_CHECK_ARG(n >= 0 && width > 0 && height > 0 && pol && total_patches);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   hipStream_t s = (hipStream_t)stream;
   if (n == 0) {  // the reference dereferences patch_offset_per_gs[-1] here (gausplat.cu:67)
     EGS_HIP(hipMemsetAsync(total_patches, 0, 8, s));
+    if (host_totals) EGS_HIP(hipMemcpyAsync(host_totals, total_patches, 8, hipMemcpyDeviceToHost, s));
     return 0;
   }
   EGS_CHECK_ARG(us && areas && depths && ws_bin);
@@ -1525,7 +1545,7 @@ extern "C" int egs_splat_bin(int n, int width, int height, const float* us, int3
   EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rc,
              L.dkeys, L.ids, L.maxkey);
   EGS_LAUNCH_OK();
-  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, nullptr);
+  return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, host_totals);
 }
 
 namespace egs {
@@ -1685,6 +1705,18 @@ extern "C" int egs_splat_draw(int n, int64_t patches, int width, int height, con
   return splat_draw_impl(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, ws_bin, ws_draw,
                          ws_draw_bytes, nullptr, image, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
                          stream);
+}
+
+// as egs_splat_draw, enqueued BEFORE the host has read total_patches (see egs_splat_draw_rec_dev)
+extern "C" int egs_splat_draw_dev(int n, int64_t patch_capacity, const uint32_t* total_patches, int width, int height,
+                                  const float* us, const float* cinv2ds, const float* alphas, const float* colors,
+                                  const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                                  size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                                  int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream) {
+  EGS_CHECK_ARG(total_patches && patch_capacity > 0);
+  return splat_draw_impl(n, patch_capacity, width, height, us, cinv2ds, alphas, colors, areas, pol, ws_bin, ws_draw,
+                         ws_draw_bytes, nullptr, image, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
+                         stream, total_patches);
 }
 
 // as egs_splat_draw, with the packed 2D records already built (egs_fused_forward)

@@ -260,16 +260,65 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     ws_bin_bytes = lib.egs_splat_bin_ws_bytes(n)
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
     st = _stream()
-    patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_splat_bin(
-        n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
-        _ptr(total), st)), dev, (n, width, height))
-    gsid = torch.empty(patches, dtype=torch.int32, device=dev)
-    ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
+    key = (n, width, height)
+
+    def draw_exact(patches):
+        gsid = torch.empty(patches, dtype=torch.int32, device=dev)
+        ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
+        ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.egs_splat_draw(n, patches, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                      _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
+                                      _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid), st))
+        return gsid
+
+    def render_exact():
+        """The reference's sequence (gausplat.cu:50-105): bin, read P back, draw -- the GPU idles around the read."""
+        patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_splat_bin(
+            n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
+            _ptr(total), st)), dev, key)
+        return patches, draw_exact(patches)
+
+    # From the second call of a problem size on, the draw stage is enqueued BEHIND the binning stage before the
+    # host has seen P: buffers sized by the largest count met so far (+6 %), the count taken from device memory,
+    # {P, max depth key} delivered into a page-locked mailbox slot by the binning kernels.  `gsid_per_patch` must
+    # come back with exactly P rows, so the host still waits for P -- while the GPU draws.
+    from . import fused as _fused            # (the per-device mailbox / capacity state lives there)
+    ctx = _fused._ctx(dev)
+    cap = ctx.capacity.get(key, 0) if (_fused.ENQUEUE_AHEAD and n > 0) else 0
+    slot = None
+    if cap > 0:
+        with ctx.lock:
+            if ctx.free:
+                slot = ctx.free.pop()
+    if slot is None:
+        patches, gsid = render_exact()
+        if n > 0:
+            with ctx.lock:
+                ctx.capacity[key] = max(ctx.capacity.get(key, 0), _fused._grow(patches))
+        return [image, contrib, final_tau, ranges, gsid]
+    t = _fused._Ticket()
+    t.ctx, t.key, t.cap, t.state, t.status, t.collected, t.slot = ctx, key, cap, None, _fused._Ticket.PENDING, True, slot
+    t.hint = _get_key_bits(dev.index, key)
+    total = torch.empty(2, dtype=torch.int32, device=dev)
+    _lib.check(lib.egs_mailbox_arm(ctx.mb, slot, st))
+    _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, t.hint, _ptr(ws_bin),
+                                    ws_bin_bytes, _ptr(total), C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot)), st))
+    gsid_full = torch.empty(cap, dtype=torch.int32, device=dev)
+    ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
     ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.egs_splat_draw(n, patches, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
-                                  _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
-                                  _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid), st))
-    return [image, contrib, final_tau, ranges, gsid]
+    _lib.check(lib.egs_splat_draw_dev(n, cap, _ptr(total), width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                      _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
+                                      _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), st))
+    with ctx.lock:
+        ctx.pending.append(t)
+    _fused._settle(t, True)                  # one C-side wait on the slot; learns capacity and depth-key bits
+    if t.status == _fused._Ticket.FAILED:
+        if t.patches >= 2**31:
+            raise RuntimeError("splat: %d tile patches overflow int32 indexing" % t.patches)
+        if t.hint < 32 and t.need > t.hint:  # stale depth-key hint: everything again (the stage is idempotent)
+            return [image, contrib, final_tau, ranges, render_exact()[1]]
+        return [image, contrib, final_tau, ranges, draw_exact(t.patches)]   # more patches than ever before
+    return [image, contrib, final_tau, ranges, gsid_full[:t.patches]]
 
 
 def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,

@@ -132,6 +132,22 @@ int egs_splat_draw(int n, int64_t patches, int width, int height, const float* u
                    float* image, int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
                    int32_t* gsid_per_patch, void* stream);
 
+/* The same two stages for a host that does not want the GPU to wait for its read of total_patches (the reference
+ * idles around cudaMemcpy(&P), gausplat.cu:67): egs_splat_bin_mb also stores {P, max depth key} into host_totals
+ * (a page-locked mailbox slot, egs_mailbox_slot / _arm / _fetch below), and egs_splat_draw_dev is enqueued right
+ * behind it with buffers sized by patch_capacity (gsid_per_patch, egs_splat_draw_ws_bytes(n, patch_capacity, ..))
+ * and the real count taken from total_patches[0] on the device.  The host then reads the slot: if the count
+ * exceeds patch_capacity (nothing was written out of bounds) or the depth keys outgrew the hint, the stages are
+ * redone the synchronous way.  gsplatcu.splat works like this from the second call of a problem size on. */
+int egs_splat_bin_mb(int n, int width, int height, const float* us, int32_t* areas, float* depths,
+                     const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                     uint32_t* total_patches, uint32_t* host_totals /*nullable*/, void* stream);
+int egs_splat_draw_dev(int n, int64_t patch_capacity, const uint32_t* total_patches, int width, int height,
+                       const float* us, const float* cinv2ds, const float* alphas, const float* colors,
+                       const int32_t* areas, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                       size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream);
+
 /* gsplatcu.splatB  (ext.cpp:20-32, gausplat.cu:114-159, kernel.cu:809-950).
  * Gradient outputs (zero-filled by the caller): dloss_dus[N,2], dloss_dcinv2ds[N,3],
  * dloss_dalphas[N], dloss_dcolors[N,3].  ws: egs_splat_bwd_ws_bytes(n). */

@@ -247,3 +247,46 @@ def test_backward_in_the_forward_dispatch_order(monkeypatch):
     for x, y in zip(a, b):
         assert np.abs(x).max() > 0
         np.testing.assert_allclose(x, y, rtol=0, atol=2e-6 * max(1.0, np.abs(x).max()))
+
+
+def test_seven_op_splat_enqueues_ahead_too():
+    """``gsplatcu.splat``: from the second call of a problem size on the draw stage is enqueued before P has been
+    read (egs_splat_bin_mb / egs_splat_draw_dev); same five outputs as the synchronous sequence, also when the
+    learnt capacity or the depth-key hint turn out too small, and the in-place cull of depths / areas is kept."""
+    from easygaussiansplatting_amd import fused, scene as S
+    from easygaussiansplatting_amd import gsplatcu as gsc
+    from easygaussiansplatting_amd.function import Camera
+    sc = S.small_scene(6000, 200, 120, 12, seed=8)
+    cam = Camera.from_scene(sc.cam)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    pws, shs, alphas, scales, rots = dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots)
+    us, pcs, depths0 = gsc.project(pws, cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, False)
+    cov3ds = gsc.computeCov3D(rots, scales, depths0, False)[0]
+    cov2ds = gsc.computeCov2D(cov3ds, pcs, cam.Rcw, depths0, cam.fx, cam.fy, 200, 120, False)[0]
+    colors = gsc.sh2Color(shs, pws, cam.twc, False)[0]
+    d1 = depths0.clone()
+    cinv2ds, areas0 = gsc.inverseCov2D(cov2ds, d1, False)[:2]
+
+    def run():
+        d, a = d1.clone(), areas0.clone()
+        out = gsc.splat(120, 200, us, cinv2ds, alphas, d, colors, a)
+        torch.cuda.synchronize()
+        return [x.cpu().numpy() for x in out] + [d.cpu().numpy(), a.cpu().numpy()]
+
+    key = (6000, 200, 120)
+    cap = fused._ctx(torch.device("cuda", 0)).capacity
+    cap.pop(key, None)
+    ref = run()                                              # no capacity yet: the synchronous sequence
+    P = ref[4].shape[0]
+    assert cap[key] > P > 1000
+    for tweak in (None, "cap64", "cap-7", "hint"):
+        if tweak == "cap64":
+            cap[key] = 64
+        elif tweak == "cap-7":
+            cap[key] = P - 7
+        elif tweak == "hint":
+            gsc._set_key_bits(0, key, 1)
+        got = run()
+        for a, b in zip(ref, got):
+            np.testing.assert_array_equal(a, b)
+        assert cap[key] > P and 8 <= gsc._get_key_bits(0, key) <= 32
