@@ -82,6 +82,7 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         "k_radix_hist": None, "k_radix_rowscan": None, "k_radix_scatter": None,  # size depends on the pass
         "k_tile_ranges": P * 4 + T * 8,
         "k_tile_order": T * 12,
+        "k_tile_work": HW * 4 + T * 4,
         # draw, at the mandated op surface: 40 B per patch (u 8, cinv 12, alpha 4, color 12, gsid 4)
         # + ranges + 20 B per pixel out.  (The kernel gathers ONE packed 48-B record + 4-B list value instead.)
         "k_draw": 40 * P + 8 * T + 20 * HW,

@@ -659,6 +659,25 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   }
 }
 constexpr int TILE_ORDER_MAX_T = (TO_REGS + 24) * 1024;   // what k_tile_order handles
+
+// The per-tile work measure of k_draw (sum of the four blocks' largest contributor index + twice the tile's)
+// rebuilt from the `contrib` image, for a backward pass that was not handed the forward pass's record.
+__global__ __launch_bounds__(64) void k_tile_work(int W, int H, int gx, const int32_t* __restrict__ contrib,
+                                                  int32_t* __restrict__ work) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  const int tx0 = (tile % gx) * EGS_TILE, ty0 = (tile / gx) * EGS_TILE;
+  int w = 0, wmax = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = tx0 + (lane & 7) + 8 * (k & 1), py = ty0 + (lane >> 3) + 8 * (k >> 1);
+    int mx = (px < W && py < H) ? contrib[(size_t)py * W + px] : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    w += mx;
+    wmax = max(wmax, mx);
+  }
+  if (lane == 0) work[tile] = w + 2 * wmax;
+}
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
 
@@ -1800,8 +1819,17 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(1) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
   } else {
+    // no record of the forward pass (the seven-op surface: splatB only gets tensors): the work measure is rebuilt
+    // from `contrib`, exactly as k_draw would have left it, and the tiles are ordered by it (k_draw_bwd 465 ->
+    // 445 us against ordering by list length, for a 4-us kernel)
     int32_t* order = (int32_t*)((char*)ws + 2 * align_up((size_t)n * 48, 256));
-    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s);
+    const size_t len = (size_t)tile_order_len(dp.gx, dp.gy);
+    int32_t* work = nullptr;
+    if (by_work && tile_order_mode(1) > 0 && len + (size_t)dp.T <= BWD_ORDER_CAP) {
+      work = order + len;
+      EGS_LAUNCH("k_tile_work", k_tile_work, dim3(dp.T), dim3(64), s, dp.W, dp.H, dp.gx, contrib, work);
+    }
+    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s, work);
     if (rc) return rc;
   }
   // variants of the backward kernel (bit 0: in-row merges of the wave reduction with bank-masked DPP adds instead
