@@ -127,9 +127,11 @@ def cpu_baseline(scene, sample_n):
     full = dt * scene.n / sample_n
     return {"value": round(cam.width * cam.height / full / 1e6, 5), "unit": "Mpix/s (forward only)",
             "cores": 1, "host_cores": os.cpu_count(), "kind": "port",
-            "sample": "first %d of %d iid Gaussians at %dx%d, %.1f s measured, x%.0f linear extrapolation; "
-                      "single-threaded NumPy patch loop == reference forward_cpu.py"
-                      % (sample_n, scene.n, cam.width, cam.height, dt, scene.n / sample_n)}
+            "sample": ("all %d Gaussians at %dx%d, %.1f s measured, no extrapolation; "
+                       % (scene.n, cam.width, cam.height, dt) if sample_n >= scene.n else
+                       "first %d of %d iid Gaussians at %dx%d, %.1f s measured, x%.0f linear extrapolation; "
+                       % (sample_n, scene.n, cam.width, cam.height, dt, scene.n / sample_n)) +
+                      "single-threaded NumPy patch loop == reference forward_cpu.py"}
 
 
 def main():
@@ -145,7 +147,13 @@ def main():
                     help="untimed render steps BEFORE the warm-up steps (~0.15 s): the GPU leaves its idle clocks "
                          "(20 steps measured cold are ~7 %% slower than the steady state a training run sees); "
                          "a count, not a duration, so that all ranks issue the same collectives")
-    ap.add_argument("--cpu-sample", type=int, default=250_000, help="Gaussians in the cpu_baseline sample (0 = skip)")
+    ap.add_argument("--cpu-sample", type=int, default=-1,
+                    help="Gaussians in the cpu_baseline sample (0 = skip; default: the whole scene on a host with >= 64 "
+                         "cores -- about 25 s of single-threaded NumPy -- else the first 250 000, extrapolated)")
+    ap.add_argument("--views-per-rank", type=int, default=1,
+                    help="camera views every rank renders per step (forward + backward each, gradients accumulated; "
+                         "ONE gradient exchange per step): 8 on one GPU = BASELINE configs[3]'s eight ring views; on N "
+                         "GPUs it amortises the 236-MB all-reduce over V renders")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
     ap.add_argument("--extras", action="store_true",
@@ -198,8 +206,11 @@ def main():
             out = render(d["pws"], d["shs"], d["alphas"], d["scales"], d["rots"], cam)
             return out[0], out[3], out[4]
     sc = S.big_scene(a.gaussians, a.width, a.height, a.sh_dim)
-    cams = S.ring_cameras(sc.cam, max(8, world))
-    cam = Camera.from_scene(cams[rank % len(cams)], dev)   # one view per GPU; view 0 = the BASELINE camera
+    V = max(1, a.views_per_rank)
+    cams = S.ring_cameras(sc.cam, max(8, world * V))
+    # rank r renders views r*V .. r*V+V-1 of the ring; view 0 = the BASELINE camera (one view per GPU at V = 1)
+    my_cams = [Camera.from_scene(cams[(rank * V + j) % len(cams)], dev) for j in range(V)]
+    cam = my_cams[0]
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     params = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1).clone(), scales=t(sc.scales),
                   rots=t(sc.rots))
@@ -208,10 +219,15 @@ def main():
     us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)   # gsmodel.py:198-199
     HW = a.width * a.height
     dl = torch.from_numpy(S.normal(1, 77, (3, a.height, a.width)).astype(np.float32)).to(dev) / (3 * HW)
+    if V > 1:
+        dl = dl / V          # the step's gradient is the MEAN over its views (train.py counterpart: Trainer.step)
     order = ("pws", "shs", "alphas", "scales", "rots")
     # the exchange may overlap the tail of the backward pass (chunked preprocess-backward, dist_views):
     # it is then launched from inside backward and only finished here
-    overlap = DV.ChunkedExchange(world) if exchange and a.mode == "fused" else None
+    # (only with ONE backward pass per step: a second view's `.grad +=` would race the in-flight all-reduce of the
+    # same storage, dist_views.ChunkedExchange; with V > 1 the views are accumulated first and exchanged as one
+    # flat buffer -- one collective for V renders)
+    overlap = DV.ChunkedExchange(world) if exchange and a.mode == "fused" and V == 1 else None
     # deferred validation needs every rank to take the same decision about a redo BEFORE any collective is
     # issued; with the overlapped exchange the collectives start inside backward, so renders are then
     # validated at once (the step is exchange-bound there and the host has time to spare)
@@ -223,9 +239,10 @@ def main():
         for p in params.values():
             p.grad = None
         us0.grad = None
-        image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
-                                       params["rots"], us0, cam)
-        image.backward(dl)
+        for c in my_cams:       # V views: forward + backward each, autograd accumulates the parameter gradients
+            image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
+                                           params["rots"], us0, c)
+            image.backward(dl)
         return image
 
     def step(timing=False):
@@ -244,7 +261,7 @@ def main():
         if timing:
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
         if exchange:  # gradient exchange: 59 floats per Gaussian, SUM then mean
-            if overlap is not None and overlap.finish():
+            if overlap is not None and overlap.finish([params[k] for k in order]):
                 pass                  # issued chunk by chunk from inside backward; now complete
             else:
                 flat = fused_path.flat_grad_buffer([params[k] for k in order])
@@ -364,7 +381,7 @@ def main():
 
     # the unmodified-caller surface: GSFunction over the seven ops (six with calc_J=True, splat, splatB and the
     # chain-rule kernel over the stored Jacobians) -- an extra, outside the timed region
-    ops_ms = None
+    ops_ms, ops_kernels = None, None
     if a.mode == "fused" and not a.no_ops and rank == 0 and world == 1:
         GSFunction.mode = "ops"
         for _ in range(8):        # (the first calls allocate the Jacobian tensors and learn the patch capacity)
@@ -374,7 +391,23 @@ def main():
         for _ in range(40):
             render_step()
         torch.cuda.synchronize()
-        ops_ms = (time.perf_counter() - to0) / 40 * 1e3
+        ops_ms = (time.perf_counter() - to0) / 40 * 1e3 / V      # per view
+        if prof:      # per-kernel table of the seven-op step (event-bracketed, outside the timing above)
+            lib.egs_prof_set_filter(None); lib.egs_prof_reset(); lib.egs_prof_enable(1)
+            for _ in range(3):
+                render_step()
+            torch.cuda.synchronize()
+            lib.egs_prof_enable(0)
+            orep = read_report()
+            lib.egs_prof_reset()
+            ops_kernels = {}
+            for k, (c, tot) in sorted(orep.items(), key=lambda kv: -kv[1][1]):
+                row = {"launches_per_step": c // (3 * V), "avg_us": round(tot / c * 1e3, 2),
+                       "ms_per_step": round(tot / (3 * V), 4)}
+                ab = algorithmic_bytes(k, sc.n, P, T, HW, a.sh_dim)
+                if ab:
+                    row["algorithmic_GBs"] = round(ab / (tot / c * 1e-3) / 1e9, 1)
+                ops_kernels[k] = row
         GSFunction.mode = a.mode
         for p in params.values():
             p.grad = None
@@ -496,22 +529,28 @@ def main():
                     pass
 
     cpu = None
-    if rank == 0 and world == 1 and a.cpu_sample > 0:
-        cpu = cpu_baseline(sc, min(a.cpu_sample, sc.n))
+    cpu_sample = a.cpu_sample
+    if cpu_sample < 0:
+        cpu_sample = sc.n if (os.cpu_count() or 1) >= 64 else 250_000
+    if rank == 0 and world == 1 and cpu_sample > 0:
+        cpu = cpu_baseline(sc, min(cpu_sample, sc.n))
 
     if rank == 0:
-        value = world * HW / (ms * 1e-3) / 1e6
+        value = world * V * HW / (ms * 1e-3) / 1e6       # every rank renders V full frames per step
         line = {
             "metric": "rendered Mpix/s fwd+bwd at 1920x1080, 1M Gaussians", "value": round(value, 2),
             "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "1 MI355X per view: %d synthetic Gaussians, %dx%d, SH degree %d, "
+            "config": {"workload": "%s: %d synthetic Gaussians, %dx%d, SH degree %d, "
                                    "forward+backward (GSFunction, mode=%s)%s"
-                                   % (sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim], a.mode,
+                                   % ("1 MI355X per view" if V == 1 else
+                                      "%d ring views per MI355X and step (BASELINE configs[3]'s views, gradients "
+                                      "accumulated)" % V,
+                                      sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim], a.mode,
                                       ", RCCL all-reduce of 59 fp32 grads/Gaussian" if world > 1 else ""),
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
-                       "views_per_step": world, "policy": "gsplatcu", "mode": a.mode,
+                       "views_per_step": world * V, "views_per_rank": V, "policy": "gsplatcu", "mode": a.mode,
                        "validation": "deferred (commit per step)" if deferred else "immediate",
                        "preconditioning": "%d untimed steps before the warm-up steps (clock ramp)" % max(0, a.ramp_steps),
                        "tile_dispatch": "forward: by the work measured at this camera's previous render (list "
@@ -524,6 +563,7 @@ def main():
             "redone_steps": redone[0],
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
             "ops_ms_per_step": None if ops_ms is None else round(ops_ms, 4),
+            "ops_kernels": ops_kernels,
             "fwd_loss_bwd": None if loss_step_ms is None else {
                 "ms": round(loss_step_ms, 4), "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
             "train_step": train_extra, "exchange": exch,

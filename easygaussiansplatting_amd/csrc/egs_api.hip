@@ -130,12 +130,22 @@ extern "C" int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void
 namespace egs {
 struct Mailbox {
   int slots;
-  uint32_t* host;                 // slots x 4 words, page-locked
+  uint32_t* host;                 // slots x 4 words, page-locked, COHERENT (kernel stores are polled by the host)
+  uint32_t* dev;                  // the same memory as the device addresses it
   std::vector<hipEvent_t> ev;     // recorded behind the copy into the slot (egs_mailbox_post)
   std::vector<char> armed;        // 1: the slot is filled by kernel stores and POLLED (egs_mailbox_arm)
   std::vector<hipStream_t> stream;  // ... by kernels of this stream (0 = the default stream)
 };
 constexpr uint32_t MAILBOX_EMPTY = 0xFFFFFFFFu;   // never a patch count (P < 2^31)
+static inline void cpu_relax() {   // spin-wait hint of the host architecture
+#if defined(__x86_64__) || defined(__i386__)
+  __builtin_ia32_pause();
+#elif defined(__aarch64__) || defined(__arm__)
+  __asm__ __volatile__("yield");
+#else
+  __asm__ __volatile__("" ::: "memory");
+#endif
+}
 }  // namespace egs
 
 extern "C" void* egs_mailbox_create(int slots) {
@@ -143,9 +153,19 @@ extern "C" void* egs_mailbox_create(int slots) {
   egs::Mailbox* m = new egs::Mailbox();
   m->slots = slots;
   m->host = nullptr;
-  if (hipHostMalloc((void**)&m->host, (size_t)slots * 16, hipHostMallocDefault) != hipSuccess) {
-    delete m;
-    return nullptr;
+  // coherent (fine-grained) and mapped, explicitly: the slots are written by kernel stores and polled by the host
+  // while the stream is still running -- "default" host memory is only coherent as long as HIP_HOST_COHERENT says so
+  if (hipHostMalloc((void**)&m->host, (size_t)slots * 16, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) {
+    (void)hipGetLastError();
+    if (hipHostMalloc((void**)&m->host, (size_t)slots * 16, hipHostMallocDefault) != hipSuccess) {
+      delete m;
+      return nullptr;
+    }
+  }
+  m->dev = nullptr;
+  if (hipHostGetDevicePointer((void**)&m->dev, m->host, 0) != hipSuccess || !m->dev) {
+    (void)hipGetLastError();
+    m->dev = m->host;              // unified addressing: the host pointer is valid on the device
   }
   memset(m->host, 0xFF, (size_t)slots * 16);
   m->ev.resize(slots, nullptr);
@@ -181,7 +201,7 @@ extern "C" int egs_mailbox_post(void* mb, int slot, const uint32_t* total_patche
 
 extern "C" uint32_t* egs_mailbox_slot(void* mb, int slot) {
   egs::Mailbox* m = (egs::Mailbox*)mb;
-  return (m && slot >= 0 && slot < m->slots) ? m->host + 4 * (size_t)slot : nullptr;
+  return (m && slot >= 0 && slot < m->slots) ? m->dev + 4 * (size_t)slot : nullptr;   // what the kernels store to
 }
 
 // Arm a slot for kernel stores: word 0 (the patch count, stored LAST in stream order by the binning kernels)
@@ -212,7 +232,7 @@ extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out
       const auto t0 = std::chrono::steady_clock::now();
       uint64_t spins = 0;
       while (h[0] == egs::MAILBOX_EMPTY) {
-        __builtin_ia32_pause();
+        egs::cpu_relax();
         if ((++spins & 0xFFF) == 0 &&
             std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {   // (never seen) ask the runtime
           const hipError_t e = hipStreamSynchronize(m->stream[slot]);

@@ -737,7 +737,11 @@ struct DrawParams {
 // XCD a contiguous band of tiles so that its private 4-MiB L2 serves 1/8 of the
 // Gaussian records instead of all of them.  Bijective for any T.
 __device__ __forceinline__ int xcd_tile(int b, const DrawParams& p) {
-  if (p.order) return b < p.ngrid ? p.order[b] : -1;
+  if (p.order) {   // (a caller-held buffer: an index outside the image is treated as padding, never dereferenced)
+    if (b >= p.ngrid) return -1;
+    const int t = p.order[b];
+    return (unsigned)t < (unsigned)p.T ? t : -1;
+  }
   if (p.map_mode == 0) return b < p.T ? b : -1;
   const int xcd = b & 7, k = b >> 3;
   if (p.map_mode == 1) {
@@ -1644,6 +1648,16 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     EGS_HIP(hipMemsetAsync(image, 0, 12 * hw, s));
     EGS_HIP(hipMemsetAsync(contrib, 0, 4 * hw, s));
     EGS_HIP(hipMemsetAsync(final_tau, 0, 4 * hw, s));
+    if (tile_order) {
+      // the caller keeps [order | work] between renders and will trust it next time (order_ready): it must hold
+      // a valid permutation and the work of THIS render (none) whatever happened here
+      const size_t olen = (size_t)tile_order_len(dp.gx, dp.gy);
+      if (!order_ready) {
+        const int rc = tile_order_enqueue(dp, 0, tile_order, olen, patch_range_per_tile, s, nullptr);
+        if (rc) return rc;
+      }
+      EGS_HIP(hipMemsetAsync(tile_order + olen, 0, (size_t)dp.T * 4, s));
+    }
     return 0;
   }
   EGS_CHECK_ARG(ws_bin && ws_draw && gsid_per_patch);

@@ -92,15 +92,32 @@ class ChunkedExchange:
     chunk k + 1 is computed -- with 4 chunks three quarters of the 236 MB are on their way before the backward
     pass ends.  ``finish()`` makes the caller's stream wait for the exchange and turns the sums into means.
     One collective per chunk (its five or six slices as one coalesced RCCL group call).  Every rank must
-    attach for the same backward passes (the collectives have to match)."""
+    attach for the same backward passes (the collectives have to match).
+
+    RESTRICTION (checked, not assumed).  The buffers handed to ``on_chunk`` are the tensors ``fused.backward``
+    RETURNS to autograd: they are reduced in place while autograd still owns them.  That is only right when
+    autograd adopts them as ``.grad`` without copying and nothing else reads them before ``finish()``:
+
+    * exactly ONE backward pass per ``attach()`` ... ``finish()`` -- a second view's ``.grad += new`` would run on
+      the compute stream next to the in-flight all-reduce of the same storage (``begin_backward`` raises);
+      a rank that renders several views per step accumulates them first and exchanges the flat buffer afterwards
+      (``exchange_gradients`` / ``coalesce_grads``: one collective for V views);
+    * the differentiated inputs are LEAF tensors without a ``.grad`` yet (``zero_grad(set_to_none=True)``):
+      with torch activations in front of ``GSFunction`` (non-leaf inputs) downstream nodes would read the slices
+      mid-reduce.  ``finish(params)`` verifies that every ``p.grad`` lives in the storage that was exchanged and
+      raises otherwise -- unreduced gradients never go unnoticed.
+    ``on_chunk`` is always handed FRESH view objects (never the tensor objects returned to autograd: a second
+    reference would make ``AccumulateGrad`` clone them and the reduced values would not reach ``.grad``)."""
 
     def __init__(self, world=None, group=None, chunks=4):
         self.group = group
         self.world = _world(group) if world is None else world
-        self.chunks = chunks
+        self.chunks = max(1, int(chunks))
         self.side = None
         self.works, self.tensors = [], []
         self.used = False
+        self.backwards = 0          # backward passes seen since attach() / finish()
+        self.storages = set()       # data_ptr of every storage handed over since the last finish()
 
     def attach(self):
         import contextlib
@@ -109,11 +126,21 @@ class ChunkedExchange:
         @contextlib.contextmanager
         def cm():
             prev, fused._exchange_hook = fused._exchange_hook, self
+            self.backwards = 0
             try:
                 yield self
             finally:
                 fused._exchange_hook = prev
         return cm()
+
+    def begin_backward(self):
+        """Called by ``fused.backward`` before it hands over the first chunk."""
+        self.backwards += 1
+        if self.backwards > 1:
+            raise RuntimeError(
+                "ChunkedExchange: a second backward pass inside one attach()/finish() -- its gradients would be "
+                "accumulated into buffers that are being all-reduced.  Render ONE view per attach(), or accumulate "
+                "the local views first and call exchange_gradients() afterwards (see the class docstring)")
 
     def on_chunk(self, tensors):
         tensors = [t for t in tensors if t is not None and t.numel() > 0]
@@ -134,11 +161,17 @@ class ChunkedExchange:
                 self.works += [dist.all_reduce(t, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
                                for t in tensors]
         self.tensors += tensors
+        self.storages.update(t.untyped_storage().data_ptr() for t in tensors)
         self.used = True
 
-    def finish(self) -> bool:
-        """Wait (stream-wise) for everything handed over since the last call; False when nothing was."""
+    def finish(self, params=None) -> bool:
+        """Wait (stream-wise) for everything handed over since the last call; False when nothing was.
+        ``params`` (iterable of the differentiated leaf tensors): verify that their ``.grad`` IS the exchanged
+        storage -- raises when autograd copied instead of adopting (non-leaf inputs, a pre-existing ``.grad``,
+        a second reference to the returned tensors), because the reduced values would then be lost."""
+        self.backwards = 0
         if not self.works:
+            self.storages = set()
             return False
         with torch.cuda.stream(self.side):
             for w in self.works:
@@ -147,7 +180,16 @@ class ChunkedExchange:
             if self.world > 1:
                 torch._foreach_div_(self.tensors, float(self.world))
         torch.cuda.current_stream().wait_stream(self.side)
+        storages, self.storages = self.storages, set()
         self.works, self.tensors = [], []
+        if params is not None:
+            for p in params:
+                g = p.grad
+                if g is None or g.untyped_storage().data_ptr() not in storages:
+                    raise RuntimeError(
+                        "ChunkedExchange.finish: a parameter's .grad is not the buffer that was all-reduced (autograd "
+                        "copied or accumulated instead of adopting it: non-leaf input, existing .grad, or several "
+                        "backward passes) -- the exchanged values did not reach it")
         return True
 
 

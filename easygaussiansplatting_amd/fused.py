@@ -74,7 +74,6 @@ class _DeviceCtx:
         # (camera, stream) -> (weakref, its [order | work] buffer, renders so far, problem size): the dispatch order
         # of the tiles is kept between the renders of a camera (a trainer meets every view again each epoch)
         self.tile_work = {}
-        self.tile_work_limit = 4096
         self.lock = threading.RLock()
 
 
@@ -105,6 +104,19 @@ def _settle(t: _Ticket, blocking: bool) -> bool:
     if rc == 0:
         return False
     if rc < 0:
+        # the slot never received its values (a HIP error behind the binning stage): the ticket is settled as
+        # FAILED and its slot handed back, so that later commit() calls do not trip over it again
+        with ctx.lock:
+            if t.status == _Ticket.PENDING:
+                t.status, t.patches, t.need = _Ticket.FAILED, 0, 0
+                ctx.free.append(t.slot)
+                try:
+                    ctx.pending.remove(t)
+                except ValueError:
+                    pass
+                if t.state is not None:
+                    t.state.ticket = None
+                    t.state._patches = 0
         _lib.check(-rc)
     with ctx.lock:
         if t.status != _Ticket.PENDING:
@@ -118,7 +130,7 @@ def _settle(t: _Ticket, blocking: bool) -> bool:
             pass
         ok = t.patches <= t.cap and not (t.hint < 32 and t.need > t.hint) and t.patches < 2**31
         # what the next render of this size starts from
-        _gsc._set_key_bits(ctx.index, t.key, 32 if (t.hint < 32 and t.need > t.hint) else min(32, t.need + 1))
+        _gsc._learn_key_bits(ctx.index, t.key, t.need, missed=(t.hint < 32 and t.need > t.hint))
         ctx.capacity[t.key] = max(ctx.capacity.get(t.key, 0), _grow(min(t.patches, 2**31 - 1)))
         t.status = _Ticket.OK if ok else _Ticket.FAILED
         S = t.state
@@ -269,6 +281,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     #                                refreshed from the latest work every ORDER_REFRESH-th render:
     # no order kernel at all on most renders (10 us forward, 8 us backward at 1080p).
     prev_work, order_ready = None, 0
+    cache_entry = None        # registered only AFTER the draw stage that writes the order buffer was enqueued
     if TILE_WORK_CACHE and n > 0:
         ck = (id(cam), int(st.value or 0))              # one entry per camera and stream, whatever the scene size
         olen = lib.egs_tile_order_len(W, H)
@@ -284,15 +297,31 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             else:
                 S.order = torch.empty(olen, dtype=i32, device=dev)
                 renders = 1
-            if len(ctx.tile_work) > ctx.tile_work_limit:    # (cameras that no longer exist)
-                ctx.tile_work = {k: v for k, v in ctx.tile_work.items() if v[0]() is not None}
-                ctx.tile_work_limit = max(4096, 2 * len(ctx.tile_work))
-            try:
-                ctx.tile_work[ck] = (weakref.ref(cam), S.order, renders, (n, W, H))
-            except TypeError:                           # a camera object that cannot be weakly referenced
-                pass
+        cache_entry = (ck, renders)
     if S.order is None:
         S.order = torch.empty(lib.egs_tile_order_len(W, H), dtype=i32, device=dev)
+
+    def remember_order():
+        """The render that just enqueued its draw stage wrote [order | work] (every path of the library does,
+        patches == 0 included): only now may the NEXT render of this camera rely on it.  A render that raised
+        before this point leaves the cache as it was.  The entry goes when the camera object dies (weakref
+        callback): callers that build a Camera per frame do not pile up order buffers."""
+        if cache_entry is None:
+            return
+        ck, renders = cache_entry
+        tw = ctx.tile_work
+
+        def drop(_ref, ck=ck, tw=tw, lock=ctx.lock):
+            with lock:
+                ent = tw.get(ck)
+                if ent is not None and ent[0] is _ref:
+                    del tw[ck]
+        try:
+            ref = weakref.ref(cam, drop)
+        except TypeError:                               # a camera object that cannot be weakly referenced
+            return
+        with ctx.lock:
+            tw[ck] = (ref, S.order, renders, (n, W, H))
     S.order_by_work = prev_work is not None or order_ready == 1
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
@@ -300,6 +329,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         """Synchronous form: read P back (8 bytes, as the reference does at gausplat.cu:67), then draw."""
         patches = _bin_stage(enqueue_bin, dev, key)
         draw_exact(patches)
+        remember_order()
         S._patches = patches
         if n > 0:
             with ctx.lock:
@@ -322,23 +352,32 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             if ctx.free:
                 t.slot = ctx.free.pop()
                 break
-            oldest = ctx.pending[0]
+            oldest = ctx.pending[0] if ctx.pending else None
+        if oldest is None:
+            raise RuntimeError("fused.forward: no mailbox slot free and no render in flight (slots leaked)")
         _settle(oldest, True)                         # every slot in flight: wait for the oldest render
-    total = torch.empty(2, dtype=i32, device=dev)
-    if MAILBOX_COPY:          # {P, max key} by an 8-byte device-to-host copy behind the binning stage
-        enqueue_bin(t.hint, total)
-        _lib.check(lib.egs_mailbox_post(ctx.mb, t.slot, _ptr(total), st))
-    else:                     # the binning kernels store them into the page-locked slot themselves
-        _lib.check(lib.egs_mailbox_arm(ctx.mb, t.slot, st))
-        host_slot[0] = C.c_void_p(lib.egs_mailbox_slot(ctx.mb, t.slot))
-        enqueue_bin(t.hint, total)
-        host_slot[0] = None   # (a later synchronous re-render must not write into a slot that was handed back)
-    gsid_full = torch.empty(cap, dtype=i32, device=dev)
-    ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
-    _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
-                                          _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
-                                          _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
-                                          _ptr(S.gpack), prev_work, order_ready, st))
+    try:
+        total = torch.empty(2, dtype=i32, device=dev)
+        if MAILBOX_COPY:          # {P, max key} by an 8-byte device-to-host copy behind the binning stage
+            enqueue_bin(t.hint, total)
+            _lib.check(lib.egs_mailbox_post(ctx.mb, t.slot, _ptr(total), st))
+        else:                     # the binning kernels store them into the page-locked slot themselves
+            _lib.check(lib.egs_mailbox_arm(ctx.mb, t.slot, st))
+            host_slot[0] = C.c_void_p(lib.egs_mailbox_slot(ctx.mb, t.slot))
+            enqueue_bin(t.hint, total)
+            host_slot[0] = None   # (a later synchronous re-render must not write into a slot that was handed back)
+        gsid_full = torch.empty(cap, dtype=i32, device=dev)
+        ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
+        _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
+                                              _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
+                                              _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
+                                              _ptr(S.gpack), prev_work, order_ready, st))
+    except BaseException:
+        with ctx.lock:            # the slot of a render that never got on its way goes back to the free list
+            t.status = _Ticket.FAILED
+            ctx.free.append(t.slot)
+        raise
+    remember_order()
     S.gsid = gsid_full                                # entries past P are unused (the kernels walk `ranges`)
     S._patches = None
     S.ticket = t
@@ -423,10 +462,14 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     hook = _exchange_hook
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups
+    if hook is not None:
+        hook.begin_backward()              # one backward pass per attach()/finish(): raises on a second one
     if hook is None or chunks <= 1 or rows >= n:
         launch(0 | keep, 0, n)
         if hook is not None:
-            hook.on_chunk(parts)
+            # FRESH view objects: a second reference to the tensors returned below would make AccumulateGrad
+            # clone them, and the reduced values would never reach .grad
+            hook.on_chunk([p[:] for p in parts])
     else:
         # The chain rule runs in a few row chunks; each chunk's gradient slices go to the exchange as soon as
         # its kernel is enqueued, so the all-reduce of chunk k overlaps the computation of chunk k + 1

@@ -199,6 +199,37 @@ def _get_key_bits(dev_index, key=None) -> int:
 
 def _set_key_bits(dev_index, key, bits) -> None:
     _key_bits[(dev_index, key)] = int(bits)
+    _key_low.pop((dev_index, key), None)
+
+
+_key_low = {}    # (device index, problem key) -> [renders in a row that needed fewer bits, the most they needed]
+KEY_BITS_DECAY = 32   # renders in a row with a smaller need before the hint is lowered
+
+
+def _learn_key_bits(dev_index, key, need, missed=False) -> None:
+    """Update the depth-key bit hint of a problem size from one render's largest key (``need`` bits).
+    The hint is shared by all cameras that render this problem size, so it follows a slowly decaying MAXIMUM:
+    raised at once, lowered only after KEY_BITS_DECAY renders in a row needed less (to the most they needed) --
+    cameras whose depth ranges differ by a bit or two then never miss, where "need + 1 after every success"
+    made them alternate between a miss (a redone step under deferred validation) and a reset.  A miss sets
+    the hint to 32 for the redo; the first success after that adopts need + 1."""
+    k = (dev_index, key)
+    target = min(32, int(need) + 1)
+    if missed:
+        _key_bits[k] = 32
+        _key_low.pop(k, None)
+        return
+    hint = _key_bits.get(k, 32)
+    if hint >= 32 or target >= hint:
+        _key_bits[k] = target
+        _key_low.pop(k, None)
+        return
+    low = _key_low.setdefault(k, [0, 0])
+    low[0] += 1
+    low[1] = max(low[1], target)
+    if low[0] >= KEY_BITS_DECAY:
+        _key_bits[k] = low[1]
+        _key_low.pop(k, None)
 
 
 def _bin_stage(enqueue, device, key=None, while_waiting=None):
@@ -219,7 +250,7 @@ def _bin_stage(enqueue, device, key=None, while_waiting=None):
     if hint < 32 and need > hint:
         enqueue(32, total)
         p, mk = (int(v) & 0xFFFFFFFF for v in total.tolist())
-    _set_key_bits(device.index, key, min(32, need + 1))
+    _learn_key_bits(device.index, key, need)
     if p >= 2**31:
         raise RuntimeError("splat: %d tile patches overflow int32 indexing" % p)
     return p
@@ -299,16 +330,24 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     t = _fused._Ticket()
     t.ctx, t.key, t.cap, t.state, t.status, t.collected, t.slot = ctx, key, cap, None, _fused._Ticket.PENDING, True, slot
     t.hint = _get_key_bits(dev.index, key)
-    total = torch.empty(2, dtype=torch.int32, device=dev)
-    _lib.check(lib.egs_mailbox_arm(ctx.mb, slot, st))
-    _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, t.hint, _ptr(ws_bin),
-                                    ws_bin_bytes, _ptr(total), C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot)), st))
-    gsid_full = torch.empty(cap, dtype=torch.int32, device=dev)
-    ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
-    ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.egs_splat_draw_dev(n, cap, _ptr(total), width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
-                                      _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
-                                      _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), st))
+    try:
+        total = torch.empty(2, dtype=torch.int32, device=dev)
+        _lib.check(lib.egs_mailbox_arm(ctx.mb, slot, st))
+        _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, t.hint,
+                                        _ptr(ws_bin), ws_bin_bytes, _ptr(total),
+                                        C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot)), st))
+        gsid_full = torch.empty(cap, dtype=torch.int32, device=dev)
+        ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
+        ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
+        _lib.check(lib.egs_splat_draw_dev(n, cap, _ptr(total), width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                          _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
+                                          _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid_full),
+                                          st))
+    except BaseException:
+        with ctx.lock:                       # the slot goes back: nothing will ever fetch it
+            t.status = _fused._Ticket.FAILED
+            ctx.free.append(slot)
+        raise
     with ctx.lock:
         ctx.pending.append(t)
     _fused._settle(t, True)                  # one C-side wait on the slot; learns capacity and depth-key bits

@@ -16,6 +16,7 @@ ap.add_argument("--gaussians", type=int, default=1_000_000)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--mode", default="fused", choices=["fused", "ops"], help="GSFunction evaluation (ops = the seven-op surface)")
 ap.add_argument("--train", action="store_true", help="whole optimizer step: GSRawFunction + HIP loss + FusedAdam")
 a = ap.parse_args()
 
@@ -24,6 +25,7 @@ from easygaussiansplatting_amd import scene as S
 from easygaussiansplatting_amd.function import Camera, GSFunction, render
 
 dev = torch.device("cuda", 0)
+GSFunction.mode = a.mode
 sc = S.big_scene(a.gaussians, a.width, a.height, 48)
 cam = Camera.from_scene(sc.cam, dev)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
