@@ -15,7 +15,81 @@
 
 namespace egs {
 
+// ---- row stores of the seven-op kernels ---------------------------------------------------------------------
+// The reference's ops hand back per-Gaussian rows of K floats (K = 3 ... 24: values and Jacobians, 832 B per
+// Gaussian with calc_J).  A lane that stores its own row issues K dword (or K/4 dwordx4) stores whose 64 lanes are
+// 4K bytes apart: every instruction touches 64 different lines and fills 4 or 16 bytes of each -- the AoS store
+// pattern that kept these kernels at 3.0-3.7 TB/s.  The workgroup's 256 rows are ONE contiguous, 16-B aligned span
+// of the output (256 * K * 4 bytes), so the rows are deposited in LDS -- row stride padded to an odd number of words
+// (of 16-B units for K % 4 == 0): conflict-free -- and the span leaves as coalesced dwordx4 stores, full lines.
+// EVERY row is written, culled Gaussians as zeros: the callers allocate with torch.empty, not torch.zeros (the
+// reference's zero-filled outputs, gausplat.cu:170-178 etc., cost 528 B per Gaussian and step of pure fill here).
+template <int K>
+struct RowsOut {
+  static constexpr bool V4 = (K % 4 == 0);
+  static constexpr bool DIRECT = (K <= 2);
+  static constexpr int STRIDE = V4 ? 4 * ((K / 4 + 1) | 1) : (K | 1);   // floats
+  static constexpr int LDS_FLOATS = DIRECT ? 1 : 256 * STRIDE;
+};
+constexpr int cmax(int a, int b) { return a > b ? a : b; }
+
+// all 256 threads of the workgroup call this (barriers inside); `row` of lanes past n is ignored
+template <int K>
+__device__ __forceinline__ void rows_out(const float* row, float* __restrict__ dst, int n, int base, float* lds) {
+  using RO = RowsOut<K>;
+  const int tid = threadIdx.x;
+  const int rows = min(256, n - base);
+  if constexpr (RO::DIRECT) {
+    if (tid < rows) {
+      if constexpr (K == 2) reinterpret_cast<float2*>(dst)[base + tid] = make_float2(row[0], row[1]);
+      else dst[base + tid] = row[0];
+    }
+  } else {
+    __syncthreads();   // the previous user of `lds` is done with it
+    if constexpr (RO::V4) {
+#pragma unroll
+      for (int j = 0; j < K / 4; ++j)
+        *reinterpret_cast<float4*>(lds + tid * RO::STRIDE + 4 * j) =
+            make_float4(row[4 * j], row[4 * j + 1], row[4 * j + 2], row[4 * j + 3]);
+    } else {
+#pragma unroll
+      for (int j = 0; j < K; ++j) lds[tid * RO::STRIDE + j] = row[j];
+    }
+    __syncthreads();
+    float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + (size_t)K * base);
+    const int total = rows * K, nq = total >> 2;
+#pragma unroll
+    for (int j = 0; j < (K + 3) / 4; ++j) {
+      const int f = tid + 256 * j;
+      if (f < nq) {
+        if constexpr (RO::V4) {
+          const int r = f / (K / 4), c = f - r * (K / 4);
+          d4[f] = *reinterpret_cast<const float4*>(lds + r * RO::STRIDE + 4 * c);
+        } else {
+          int r = (4 * f) / K, c = 4 * f - r * K;
+          float v[4];
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            v[t] = lds[r * RO::STRIDE + c];
+            if (++c == K) { c = 0; ++r; }
+          }
+          d4[f] = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+    if constexpr (!RO::V4) {   // <= 3 floats when the last workgroup's row count is not a multiple of four
+      const int f = 4 * nq + tid;
+      if (f < total) {
+        const int r = f / K, c = f - r * K;
+        dst[(size_t)K * base + f] = lds[r * RO::STRIDE + c];
+      }
+    }
+  }
+}
+
 // ---- project                                          (reference kernel.cu:553-617)
+// (60 B per Gaussian: too little to pay for a trip through LDS -- measured 20 us direct, 23 us staged; every row is
+// still written, culled Gaussians as zeros)
 __global__ __launch_bounds__(256) void k_project(int n, const float* __restrict__ pws,
                                                  const float* __restrict__ Rcw,
                                                  const float* __restrict__ tcw, float fx, float fy,
@@ -26,17 +100,22 @@ __global__ __launch_bounds__(256) void k_project(int n, const float* __restrict_
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= n) return;
   const Proj P = project_f(ld3(pws + 3 * (size_t)i), Rcw, tcw, fx, fy, cx, cy);
-  if (near_cull && P.pc.z < EGS_MIN_DEPTH) {
-    depths[i] = EGS_BAD_MARKER;  // everything else stays 0 (caller zero-fills)
+  const bool cull = near_cull && P.pc.z < EGS_MIN_DEPTH;
+  float2* J2 = du_dpcs ? reinterpret_cast<float2*>(du_dpcs + 6 * (size_t)i) : nullptr;   // 24-B rows: 8-B aligned
+  if (cull) {   // everything but the marker reads 0, like the reference's zero-filled outputs
+    reinterpret_cast<float2*>(us)[i] = make_float2(0.f, 0.f);
+    st3(pcs + 3 * (size_t)i, {0.f, 0.f, 0.f});
+    depths[i] = EGS_BAD_MARKER;
+    if (J2) { J2[0] = make_float2(0.f, 0.f); J2[1] = make_float2(0.f, 0.f); J2[2] = make_float2(0.f, 0.f); }
     return;
   }
-  us[2 * (size_t)i + 0] = P.u0;
-  us[2 * (size_t)i + 1] = P.u1;
+  reinterpret_cast<float2*>(us)[i] = make_float2(P.u0, P.u1);
   st3(pcs + 3 * (size_t)i, P.pc);
   depths[i] = P.pc.z;
-  if (du_dpcs) {
-    float* J = du_dpcs + 6 * (size_t)i;  // entries 1,3 stay 0
-    project_jac(P, fx, fy, J[0], J[2], J[4], J[5]);
+  if (J2) {
+    float j00, j02, j11, j12;
+    project_jac(P, fx, fy, j00, j02, j11, j12);
+    J2[0] = make_float2(j00, 0.f); J2[1] = make_float2(j02, 0.f); J2[2] = make_float2(j11, j12);
   }
 }
 
@@ -47,24 +126,28 @@ __global__ __launch_bounds__(256) void k_cov3d(int n, const float* __restrict__ 
                                                float* __restrict__ cov3ds,
                                                float* __restrict__ dcov3d_drots,
                                                float* __restrict__ dcov3d_dscales) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  if (near_cull && depths[i] < EGS_MIN_DEPTH) return;
-  const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);  // 16-B aligned rows
-  const f3 s = ld3(scales + 3 * (size_t)i);
-  const Cov3 c = cov3d_f(q, s);
-  float* o = cov3ds + 6 * (size_t)i;
+  __shared__ float stage[RowsOut<24>::LDS_FLOATS];
+  const int base = blockIdx.x * 256, i = base + threadIdx.x;
+  const bool jac = dcov3d_drots && dcov3d_dscales;
+  float c6[6], dq[24], ds[18];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) o[k] = c.c[k];
-  if (dcov3d_drots && dcov3d_dscales) {
-    float dq[24], ds[18];
-    cov3d_jac(c, q, s, dq, ds);
-    float* oq = dcov3d_drots + 24 * (size_t)i;
+  for (int k = 0; k < 6; ++k) c6[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 24; ++k) oq[k] = dq[k];
-    float* os = dcov3d_dscales + 18 * (size_t)i;
+  for (int k = 0; k < 24; ++k) dq[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) os[k] = ds[k];
+  for (int k = 0; k < 18; ++k) ds[k] = 0.f;
+  if (i < n && !(near_cull && depths[i] < EGS_MIN_DEPTH)) {
+    const float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);  // 16-B aligned rows
+    const f3 s = ld3(scales + 3 * (size_t)i);
+    const Cov3 c = cov3d_f(q, s);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) c6[k] = c.c[k];
+    if (jac) cov3d_jac(c, q, s, dq, ds);
+  }
+  rows_out<6>(c6, cov3ds, n, base, stage);
+  if (jac) {
+    rows_out<24>(dq, dcov3d_drots, n, base, stage);
+    rows_out<18>(ds, dcov3d_dscales, n, base, stage);
   }
 }
 
@@ -77,24 +160,28 @@ __global__ __launch_bounds__(256) void k_cov2d(int n, const float* __restrict__ 
                                                float* __restrict__ cov2ds,
                                                float* __restrict__ dcov2d_dcov3ds,
                                                float* __restrict__ dcov2d_dpcs) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  if (near_cull && depths[i] < EGS_MIN_DEPTH) return;
-  const f3 pc = ld3(pcs + 3 * (size_t)i);
-  float cv[6];
+  __shared__ float stage[RowsOut<18>::LDS_FLOATS];
+  const int base = blockIdx.x * 256, i = base + threadIdx.x;
+  const bool jac = dcov2d_dcov3ds && dcov2d_dpcs;
+  float c3[3] = {0.f, 0.f, 0.f}, J3[18], Jp[9];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) cv[k] = cov3ds[6 * (size_t)i + k];
-  const Cov2 c = cov2d_f(cv, pc, Rcw, fx, fy, limx, limy, clamp_fov);
-  st3(cov2ds + 3 * (size_t)i, {c.c[0], c.c[1], c.c[2]});
-  if (dcov2d_dcov3ds && dcov2d_dpcs) {
-    float J3[18], Jp[9];
-    cov2d_jac(c, pc.z, Rcw, fx, fy, J3, Jp);
-    float* o3 = dcov2d_dcov3ds + 18 * (size_t)i;
+  for (int k = 0; k < 18; ++k) J3[k] = 0.f;
 #pragma unroll
-    for (int k = 0; k < 18; ++k) o3[k] = J3[k];
-    float* op = dcov2d_dpcs + 9 * (size_t)i;
+  for (int k = 0; k < 9; ++k) Jp[k] = 0.f;
+  if (i < n && !(near_cull && depths[i] < EGS_MIN_DEPTH)) {
+    const f3 pc = ld3(pcs + 3 * (size_t)i);
+    float cv[6];
+    const float2* cr = reinterpret_cast<const float2*>(cov3ds + 6 * (size_t)i);   // 24-B rows: 8-B aligned
 #pragma unroll
-    for (int k = 0; k < 9; ++k) op[k] = Jp[k];
+    for (int k = 0; k < 3; ++k) { const float2 v = cr[k]; cv[2 * k] = v.x; cv[2 * k + 1] = v.y; }
+    const Cov2 c = cov2d_f(cv, pc, Rcw, fx, fy, limx, limy, clamp_fov);
+    c3[0] = c.c[0]; c3[1] = c.c[1]; c3[2] = c.c[2];
+    if (jac) cov2d_jac(c, pc.z, Rcw, fx, fy, J3, Jp);
+  }
+  rows_out<3>(c3, cov2ds, n, base, stage);
+  if (jac) {
+    rows_out<18>(J3, dcov2d_dcov3ds, n, base, stage);
+    rows_out<9>(Jp, dcov2d_dpcs, n, base, stage);
   }
 }
 
@@ -106,24 +193,30 @@ __global__ __launch_bounds__(256) void k_sh2color(int n, const float* __restrict
                                                   float* __restrict__ colors,
                                                   float* __restrict__ dcolor_dshs,
                                                   float* __restrict__ dcolor_dpws) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
+  __shared__ float stage[cmax(RowsOut<NC>::LDS_FLOATS, RowsOut<9>::LDS_FLOATS)];
+  const int base = blockIdx.x * 256, i = base + threadIdx.x;
   constexpr int K = 3 * NC;
-  float sh[K];
-  load_sh_row<K>(shs + (size_t)K * i, sh);
-  const ShDir<NC> d = sh_basis_f<NC>(ld3(pws + 3 * (size_t)i), twc);
-  float col[3];
-  sh_color_f<NC>(d, sh, col);
-  st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
-  if (dcolor_dshs && dcolor_dpws) {
-    float* js = dcolor_dshs + (size_t)NC * i;
+  const bool jac = dcolor_dshs && dcolor_dpws;
+  float col[3] = {0.f, 0.f, 0.f}, B[NC], jp[9];
 #pragma unroll
-    for (int c = 0; c < NC; ++c) js[c] = d.B[c];
-    float jp[9];
-    sh_jac_dpw<NC>(d, sh, jp);
-    float* o = dcolor_dpws + 9 * (size_t)i;
+  for (int c = 0; c < NC; ++c) B[c] = 0.f;
 #pragma unroll
-    for (int j = 0; j < 9; ++j) o[j] = jp[j];
+  for (int j = 0; j < 9; ++j) jp[j] = 0.f;
+  if (i < n) {   // colour has no depth test in the reference (kernel.cu:619-725)
+    float sh[K];
+    load_sh_row<K>(shs + (size_t)K * i, sh);
+    const ShDir<NC> d = sh_basis_f<NC>(ld3(pws + 3 * (size_t)i), twc);
+    sh_color_f<NC>(d, sh, col);
+    if (jac) {
+#pragma unroll
+      for (int c = 0; c < NC; ++c) B[c] = d.B[c];
+      sh_jac_dpw<NC>(d, sh, jp);
+    }
+  }
+  rows_out<3>(col, colors, n, base, stage);
+  if (jac) {
+    rows_out<NC>(B, dcolor_dshs, n, base, stage);
+    rows_out<9>(jp, dcolor_dpws, n, base, stage);
   }
 }
 
@@ -134,27 +227,49 @@ __global__ __launch_bounds__(256) void k_inv_cov2d(int n, const float* __restric
                                                    float* __restrict__ cinv2ds,
                                                    int32_t* __restrict__ areas,
                                                    float* __restrict__ dcinv2d_dcov2ds) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  if (near_cull && depths[i] < EGS_MIN_DEPTH) return;
-  const float c2[3] = {cov2ds[3 * (size_t)i], cov2ds[3 * (size_t)i + 1], cov2ds[3 * (size_t)i + 2]};
-  float ci[3];
-  const float det_inv = inv_cov2d_f(c2, det_eps, ci);
-  if (nan_cull && isnan(det_inv)) {
-    depths[i] = EGS_BAD_MARKER;  // in-place contract GSFunction relies on (gsmodel.py:50)
-    return;
-  }
-  st3(cinv2ds + 3 * (size_t)i, {ci[0], ci[1], ci[2]});
-  int rx, ry;
-  radius_f(c2, radius_mode, rx, ry);
-  areas[2 * (size_t)i] = rx;
-  areas[2 * (size_t)i + 1] = ry;
-  if (dcinv2d_dcov2ds) {
-    float J[9];
-    inv_cov2d_jac(c2, det_inv, J);
-    float* o = dcinv2d_dcov2ds + 9 * (size_t)i;
+  __shared__ float stage[RowsOut<9>::LDS_FLOATS];
+  const int base = blockIdx.x * 256, i = base + threadIdx.x;
+  float ci[3] = {0.f, 0.f, 0.f}, ar[2] = {0.f, 0.f}, J[9];
 #pragma unroll
-    for (int k = 0; k < 9; ++k) o[k] = J[k];
+  for (int k = 0; k < 9; ++k) J[k] = 0.f;
+  if (i < n && !(near_cull && depths[i] < EGS_MIN_DEPTH)) {
+    const float c2[3] = {cov2ds[3 * (size_t)i], cov2ds[3 * (size_t)i + 1], cov2ds[3 * (size_t)i + 2]};
+    float cc[3];
+    const float det_inv = inv_cov2d_f(c2, det_eps, cc);
+    if (nan_cull && isnan(det_inv)) {
+      depths[i] = EGS_BAD_MARKER;  // in-place contract GSFunction relies on (gsmodel.py:50)
+    } else {
+      ci[0] = cc[0]; ci[1] = cc[1]; ci[2] = cc[2];
+      int rx, ry;
+      radius_f(c2, radius_mode, rx, ry);
+      ar[0] = __int_as_float(rx); ar[1] = __int_as_float(ry);   // (bit patterns of the int32 radii)
+      if (dcinv2d_dcov2ds) inv_cov2d_jac(c2, det_inv, J);
+    }
+  }
+  rows_out<3>(ci, cinv2ds, n, base, stage);
+  rows_out<2>(ar, reinterpret_cast<float*>(areas), n, base, stage);
+  if (dcinv2d_dcov2ds) rows_out<9>(J, dcinv2d_dcov2ds, n, base, stage);
+}
+
+// row loads of the chain-rule kernel: the widest vector load the row's alignment allows (a dword load per float
+// costs one L1 lookup per lane and float: 24 instructions x 64 lookups for a dcov3d/drot row, 6 x 64 as dwordx4)
+template <int K>
+__device__ __forceinline__ void load_row(const float* __restrict__ row, float* out) {
+  if constexpr (K % 4 == 0) {
+#pragma unroll
+    for (int j = 0; j < K / 4; ++j) {
+      const float4 v = reinterpret_cast<const float4*>(row)[j];
+      out[4 * j] = v.x; out[4 * j + 1] = v.y; out[4 * j + 2] = v.z; out[4 * j + 3] = v.w;
+    }
+  } else if constexpr (K % 2 == 0) {
+#pragma unroll
+    for (int j = 0; j < K / 2; ++j) {
+      const float2 v = reinterpret_cast<const float2*>(row)[j];
+      out[2 * j] = v.x; out[2 * j + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < K; ++j) out[j] = row[j];
   }
 }
 
@@ -172,68 +287,68 @@ __global__ __launch_bounds__(256) void k_chain_rule(
     const float* __restrict__ J_cov2_pc, const float* __restrict__ J_color_pw,
     float* __restrict__ dL_dpw, float* __restrict__ dL_dsh, float* __restrict__ dL_dscale,
     float* __restrict__ dL_drot) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  const f3 gci = ld3(dL_dcinv + 3 * (size_t)i);
-  const float* A = J_cinv_cov2 + 9 * (size_t)i;
-  // dL/dcov2d = dL/dcinv2d @ J (row vector times 3x3)
-  const f3 gc2 = {gci.x * A[0] + gci.y * A[3] + gci.z * A[6], gci.x * A[1] + gci.y * A[4] + gci.z * A[7],
-                  gci.x * A[2] + gci.y * A[5] + gci.z * A[8]};
-  const float* Bm = J_cov2_cov3 + 18 * (size_t)i;
-  float gc3[6];
+  constexpr int K = 3 * NC;
+  __shared__ float stage[cmax(RowsOut<K>::LDS_FLOATS, RowsOut<3>::LDS_FLOATS)];
+  const int base = blockIdx.x * 256, i = base + threadIdx.x;
+  float grot[4] = {0.f, 0.f, 0.f, 0.f}, gsc[3] = {0.f, 0.f, 0.f}, gpw[3] = {0.f, 0.f, 0.f}, gsh[K];
 #pragma unroll
-  for (int k = 0; k < 6; ++k) gc3[k] = gc2.x * Bm[k] + gc2.y * Bm[6 + k] + gc2.z * Bm[12 + k];
-  const float* Cq = J_cov3_rot + 24 * (size_t)i;
-  float* orot = dL_drot + 4 * (size_t)i;
+  for (int k = 0; k < K; ++k) gsh[k] = 0.f;
+  if (i < n) {
+    const f3 gci = ld3(dL_dcinv + 3 * (size_t)i);
+    float A[9];
+    load_row<9>(J_cinv_cov2 + 9 * (size_t)i, A);
+    // dL/dcov2d = dL/dcinv2d @ J (row vector times 3x3)
+    const f3 gc2 = {gci.x * A[0] + gci.y * A[3] + gci.z * A[6], gci.x * A[1] + gci.y * A[4] + gci.z * A[7],
+                    gci.x * A[2] + gci.y * A[5] + gci.z * A[8]};
+    float Bm[18];
+    load_row<18>(J_cov2_cov3 + 18 * (size_t)i, Bm);
+    float gc3[6];
 #pragma unroll
-  for (int k = 0; k < 4; ++k) {
-    float s = 0.f;
+    for (int k = 0; k < 6; ++k) gc3[k] = gc2.x * Bm[k] + gc2.y * Bm[6 + k] + gc2.z * Bm[12 + k];
+    float Cq[24];
+    load_row<24>(J_cov3_rot + 24 * (size_t)i, Cq);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) s += gc3[r] * Cq[4 * r + k];
-    orot[k] = s;
-  }
-  const float* Cs = J_cov3_scale + 18 * (size_t)i;
-  float* osc = dL_dscale + 3 * (size_t)i;
+    for (int k = 0; k < 4; ++k) {
+      float s = 0.f;
 #pragma unroll
-  for (int k = 0; k < 3; ++k) {
-    float s = 0.f;
+      for (int r = 0; r < 6; ++r) s += gc3[r] * Cq[4 * r + k];
+      grot[k] = s;
+    }
+    float Cs[18];
+    load_row<18>(J_cov3_scale + 18 * (size_t)i, Cs);
 #pragma unroll
-    for (int r = 0; r < 6; ++r) s += gc3[r] * Cs[3 * r + k];
-    osc[k] = s;
-  }
-  const f3 gcol = ld3(dL_dcolor + 3 * (size_t)i);
-  const float* Bs = J_color_sh + (size_t)NC * i;
-  float* osh = dL_dsh + (size_t)(3 * NC) * i;
-  {
-    constexpr int K = 3 * NC;
-    float gsh[K];
+    for (int k = 0; k < 3; ++k) {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 6; ++r) s += gc3[r] * Cs[3 * r + k];
+      gsc[k] = s;
+    }
+    const f3 gcol = ld3(dL_dcolor + 3 * (size_t)i);
+    float Bs[NC];
+    load_row<NC>(J_color_sh + (size_t)NC * i, Bs);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const float bc = Bs[c];
-      gsh[3 * c] = gcol.x * bc; gsh[3 * c + 1] = gcol.y * bc; gsh[3 * c + 2] = gcol.z * bc;
+      gsh[3 * c] = gcol.x * Bs[c]; gsh[3 * c + 1] = gcol.y * Bs[c]; gsh[3 * c + 2] = gcol.z * Bs[c];
     }
-    if constexpr (K % 4 == 0) {
+    // dL/dpc = dL/du @ du_dpc + dL/dcov2d @ dcov2d_dpc ; dL/dpw = dL/dpc @ Rcw + dL/dcolor @ dcolor_dpw
+    const float2 gu = reinterpret_cast<const float2*>(dL_du)[i];
+    const float gu0 = gu.x, gu1 = gu.y;
+    float U[6], Pc[9], W[9];
+    load_row<6>(J_u_pc + 6 * (size_t)i, U);
+    load_row<9>(J_cov2_pc + 9 * (size_t)i, Pc);
+    load_row<9>(J_color_pw + 9 * (size_t)i, W);
+    const f3 gpc = {gu0 * U[0] + gu1 * U[3] + gc2.x * Pc[0] + gc2.y * Pc[3] + gc2.z * Pc[6],
+                    gu0 * U[1] + gu1 * U[4] + gc2.x * Pc[1] + gc2.y * Pc[4] + gc2.z * Pc[7],
+                    gu0 * U[2] + gu1 * U[5] + gc2.x * Pc[2] + gc2.y * Pc[5] + gc2.z * Pc[8]};
 #pragma unroll
-      for (int j = 0; j < K / 4; ++j)
-        reinterpret_cast<float4*>(osh)[j] = make_float4(gsh[4 * j], gsh[4 * j + 1], gsh[4 * j + 2], gsh[4 * j + 3]);
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) osh[k] = gsh[k];
-    }
+    for (int k = 0; k < 3; ++k)
+      gpw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
+               gcol.z * W[6 + k];
+    *reinterpret_cast<float4*>(dL_drot + 4 * (size_t)i) = make_float4(grot[0], grot[1], grot[2], grot[3]);
   }
-  // dL/dpc = dL/du @ du_dpc + dL/dcov2d @ dcov2d_dpc ; dL/dpw = dL/dpc @ Rcw + dL/dcolor @ dcolor_dpw
-  const float gu0 = dL_du[2 * (size_t)i], gu1 = dL_du[2 * (size_t)i + 1];
-  const float* U = J_u_pc + 6 * (size_t)i;
-  const float* Pc = J_cov2_pc + 9 * (size_t)i;
-  const f3 gpc = {gu0 * U[0] + gu1 * U[3] + gc2.x * Pc[0] + gc2.y * Pc[3] + gc2.z * Pc[6],
-                  gu0 * U[1] + gu1 * U[4] + gc2.x * Pc[1] + gc2.y * Pc[4] + gc2.z * Pc[7],
-                  gu0 * U[2] + gu1 * U[5] + gc2.x * Pc[2] + gc2.y * Pc[5] + gc2.z * Pc[8]};
-  const float* W = J_color_pw + 9 * (size_t)i;
-  float* opw = dL_dpw + 3 * (size_t)i;
-#pragma unroll
-  for (int k = 0; k < 3; ++k)
-    opw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
-             gcol.z * W[6 + k];
+  rows_out<3>(gsc, dL_dscale, n, base, stage);
+  rows_out<3>(gpw, dL_dpw, n, base, stage);
+  rows_out<K>(gsh, dL_dsh, n, base, stage);   // the 4K-byte dL/dsh rows leave as full lines
 }
 
 // ============================================================================
@@ -375,8 +490,10 @@ __device__ __forceinline__ void stage_span_out(const float* row, float* __restri
 // forward.md steps 1-5 for one Gaussian in one pass (== gsmodel.py:21-35 minus splat):
 // writes exactly what splat / splatB / the backward pass consume.
 // RAW: rots/scales/alphas are the un-activated tensors, shs = low_shs [N,3], shs_high = high_shs [N,K-3]
-template <int NC, bool RAW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8, 8))) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
+// JW: also write dcolor/dpw (dcolor_dpws) for the backward pass -- a training render; the SH Jacobian keeps ~40 more
+// registers alive, so these instances are not pinned to 8 waves per SIMD
+template <int NC, bool RAW, bool JW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAW || JW) ? 1 : 8, 8))) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
                                                         const float* __restrict__ rots,
                                                         const float* __restrict__ scales,
                                                         const float* __restrict__ shs,
@@ -390,7 +507,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8
                                                         float* __restrict__ colors,
                                                         int32_t* __restrict__ areas,
                                                         float4* __restrict__ rec, BinParams bp, BinCountOut bo,
-                                                        uint8_t* __restrict__ visible) {
+                                                        uint8_t* __restrict__ visible,
+                                                        float* __restrict__ dcolor_dpws) {
+  // dcolor_dpws (nullable, [N][9]): dcolor/dpw of every Gaussian, for the backward pass -- the ONLY thing that pass
+  // needs the SH coefficients for (eq (7): dL/dpw += dL/dcolor . dcolor/dpw; dL/dsh needs the basis alone).  36 B
+  // written here save the 4K-byte SH row re-read there (192 B at SH degree 3).
   constexpr int K = 3 * NC;
   constexpr int KH = K - 3;   // width of high_shs
   constexpr int STAGE_FLOATS = (RAW && KH > 0 && RowStage<KH>::LDS_FLOATS > RowStage<12>::LDS_FLOATS)
@@ -406,6 +527,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8
     }
   }
   float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+  float jw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
     float col[3];
@@ -418,6 +540,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8
       const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
       sh_color_f<NC>(d, sh, col);
       if (colors) st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
+      if constexpr (JW) sh_jac_dpw<NC>(d, sh, jw);
     }
     const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
     float u0 = 0.f, u1 = 0.f, depth = EGS_BAD_MARKER, ci[3] = {0.f, 0.f, 0.f};
@@ -463,6 +586,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8
   }
   // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
   if (rec) stage_rows_out<12>(reinterpret_cast<const float*>(r), reinterpret_cast<float*>(rec), n, blockIdx.x * 256, stage);
+  if constexpr (JW) rows_out<9>(jw, dcolor_dpws, n, blockIdx.x * 256, stage);
 }
 
 // backward.md eq (3)(4)(5)(7) == gsmodel.py:71-85 with every Jacobian re-derived in
@@ -470,7 +594,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : 8
 // written by k_draw_bwd: {dalpha, dcolor[3], du[2], dcinv[3], pad[3]}.
 // RAW: parameters as in k_preprocess_fwd<.., true>; gradients come out with respect to the raw tensors
 // (dL_dsh = low_shs [N,3], dL_dsh_high = high_shs [N,K-3]); alphas = alphas_raw (only read when RAW)
-template <int NC, bool RAW>
+template <int NC, bool RAW, bool JW>
 __global__ __launch_bounds__(256) void k_preprocess_bwd(
     int n, PreParams pp, const float* __restrict__ pws, const float* __restrict__ rots,
     const float* __restrict__ scales, const float* __restrict__ shs, const float* __restrict__ shs_high,
@@ -478,22 +602,25 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ tcw, const float* __restrict__ twc, const float* __restrict__ depths,
     const float4* __restrict__ gpack, float* __restrict__ dL_dpw, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_high, float* __restrict__ dL_dalpha, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-    float* __restrict__ dL_du) {
+    float* __restrict__ dL_du, const float* __restrict__ dcolor_dpws) {
+  // dcolor_dpws (nullable): [N][9] left by k_preprocess_fwd; with it this kernel never reads the SH coefficients
   constexpr int K = 3 * NC;
   constexpr int KH = K - 3;
   constexpr int KS = RAW ? (KH > 0 ? KH : 1) : K;   // width of the rows that go through LDS
   __shared__ float stage[RowStage<KS>::LDS_FLOATS];
   const int i = blockIdx.x * 256 + threadIdx.x;
-  float sh[K], gsh[K];
-  if constexpr (RAW) {
-    if constexpr (KH > 0) {
-      if constexpr (KH % 2 == 1) stage_span_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
-      else stage_rows_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+  float sh[JW ? 1 : K], gsh[K];
+  if constexpr (!JW) {
+    if constexpr (RAW) {
+      if constexpr (KH > 0) {
+        if constexpr (KH % 2 == 1) stage_span_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+        else stage_rows_in<KH>(shs_high, n, blockIdx.x * 256, stage, sh + 3);
+      }
+      if (i < n) { sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2]; }
+    } else {
+      if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
+      else if (i < n) load_sh_row<K>(shs + (size_t)K * i, sh);
     }
-    if (i < n) { sh[0] = shs[3 * (size_t)i]; sh[1] = shs[3 * (size_t)i + 1]; sh[2] = shs[3 * (size_t)i + 2]; }
-  } else {
-    if (pp.stage_in) stage_rows_in<K>(shs, n, blockIdx.x * 256, stage, sh);
-    else if (i < n) load_sh_row<K>(shs + (size_t)K * i, sh);
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) gsh[k] = 0.f;
@@ -557,7 +684,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
       }
       float W[9];
-      sh_jac_dpw<NC>(d, sh, W);
+      if constexpr (JW) load_row<9>(dcolor_dpws + 9 * (size_t)i, W);
+      else sh_jac_dpw<NC>(d, sh, W);
       float* opw = dL_dpw + 3 * (size_t)i;  // eq (7)
 #pragma unroll
       for (int k = 0; k < 3; ++k)
@@ -601,6 +729,7 @@ extern "C" int egs_project(int n, const float* pws, const float* Rcw, const floa
   EGS_CHECK_ARG(n >= 0 && pol);
   if (n == 0) return 0;
   EGS_CHECK_ARG(pws && Rcw && tcw && us && pcs && depths);
+  EGS_CHECK_ARG((((uintptr_t)us | (uintptr_t)du_dpcs) & 7) == 0);
   EGS_LAUNCH("k_project", k_project, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, pws, Rcw, tcw, fx,
                      fy, cx, cy, pol->near_cull, us, pcs, depths, du_dpcs);
   EGS_LAUNCH_OK();
@@ -615,6 +744,7 @@ extern "C" int egs_cov3d(int n, const float* rots, const float* scales, const fl
   EGS_CHECK_ARG(rots && scales && depths && cov3ds);
   EGS_CHECK_ARG((dcov3d_drots == nullptr) == (dcov3d_dscales == nullptr));
   EGS_CHECK_ARG(((uintptr_t)rots & 15) == 0);
+  EGS_CHECK_ARG((((uintptr_t)cov3ds | (uintptr_t)dcov3d_drots | (uintptr_t)dcov3d_dscales) & 15) == 0);
   EGS_LAUNCH("k_cov3d", k_cov3d, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, rots, scales, depths,
                      pol->near_cull, cov3ds, dcov3d_drots, dcov3d_dscales);
   EGS_LAUNCH_OK();
@@ -628,6 +758,7 @@ extern "C" int egs_cov2d(int n, const float* cov3ds, const float* pcs, const flo
   if (n == 0) return 0;
   EGS_CHECK_ARG(cov3ds && pcs && Rcw && depths && cov2ds);
   EGS_CHECK_ARG((dcov2d_dcov3ds == nullptr) == (dcov2d_dpcs == nullptr));
+  EGS_CHECK_ARG((((uintptr_t)cov3ds & 7) | (((uintptr_t)cov2ds | (uintptr_t)dcov2d_dcov3ds | (uintptr_t)dcov2d_dpcs) & 15)) == 0);
   float limx, limy;
   fov_limits(pol, fx, fy, width, height, &limx, &limy);
   EGS_LAUNCH("k_cov2d", k_cov2d, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, cov3ds, pcs, Rcw,
@@ -645,6 +776,7 @@ extern "C" int egs_sh2color(int n, int sh_dim, const float* shs, const float* pw
   EGS_CHECK_ARG(shs && pws && twc && colors);
   EGS_CHECK_ARG((dcolor_dshs == nullptr) == (dcolor_dpws == nullptr));
   EGS_CHECK_ARG(sh_dim % 4 != 0 || ((uintptr_t)shs & 15) == 0);
+  EGS_CHECK_ARG((((uintptr_t)colors | (uintptr_t)dcolor_dshs | (uintptr_t)dcolor_dpws) & 15) == 0);
   dim3 g(div_up(n, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
   switch (sh_dim) {
@@ -662,6 +794,7 @@ extern "C" int egs_inv_cov2d(int n, const float* cov2ds, float* depths, const Eg
   EGS_CHECK_ARG(n >= 0 && pol);
   if (n == 0) return 0;
   EGS_CHECK_ARG(cov2ds && depths && cinv2ds && areas);
+  EGS_CHECK_ARG((((uintptr_t)cinv2ds | (uintptr_t)areas | (uintptr_t)dcinv2d_dcov2ds) & 15) == 0);
   EGS_LAUNCH("k_inv_cov2d", k_inv_cov2d, dim3(div_up(n, 256)), dim3(256), (hipStream_t)stream, n, cov2ds, depths,
                      pol->det_eps, pol->near_cull, pol->nan_cull, pol->radius_mode, cinv2ds, areas,
                      dcinv2d_dcov2ds);
@@ -681,6 +814,9 @@ extern "C" int egs_chain_rule(int n, int sh_dim, const float* dloss_dus, const f
   EGS_CHECK_ARG(dloss_dus && dloss_dcinv2ds && dloss_dcolors && Rcw && dcinv2d_dcov2ds && dcov2d_dcov3ds &&
                 dcov3d_drots && dcov3d_dscales && dcolor_dshs && du_dpcs && dcov2d_dpcs && dcolor_dpws &&
                 dloss_dpws && dloss_dshs && dloss_dscales && dloss_drots);
+  EGS_CHECK_ARG((((uintptr_t)dloss_dpws | (uintptr_t)dloss_dshs | (uintptr_t)dloss_dscales | (uintptr_t)dloss_drots |
+                  (uintptr_t)dcov3d_drots | (sh_dim % 12 == 0 ? (uintptr_t)dcolor_dshs : 0)) & 15) == 0);
+  EGS_CHECK_ARG((((uintptr_t)dloss_dus | (uintptr_t)dcov2d_dcov3ds | (uintptr_t)dcov3d_dscales | (uintptr_t)du_dpcs) & 7) == 0);
   dim3 g(div_up(n, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
 #define EGS_CHAIN(NC)                                                                                        \
@@ -716,10 +852,11 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
                               const float* shs, const float* shs_high, const float* alphas, const float* Rcw,
                               const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
                               int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds,
-                              float* colors, int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint,
-                              void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals,
-                              void* stream) {
+                              float* colors, int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws,
+                              int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                              uint32_t* host_totals, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
+  EGS_CHECK_ARG(((uintptr_t)dcolor_dpws & 15) == 0);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
   hipStream_t s = (hipStream_t)stream;
@@ -744,8 +881,16 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
   dim3 g(div_up(n, 256)), b(256);
 #define EGS_PRE(NC, RAW)                                                                                        \
-  EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW>), g, b, s, n, pp, pws, rots, scales, shs, shs_high, \
-             alphas, Rcw, tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo, visible)
+  do {                                                                                                          \
+    if (dcolor_dpws)                                                                                            \
+      EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW, true>), g, b, s, n, pp, pws, rots, scales, shs, \
+                 shs_high, alphas, Rcw, tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo,     \
+                 visible, dcolor_dpws);                                                                         \
+    else                                                                                                        \
+      EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW, false>), g, b, s, n, pp, pws, rots, scales, shs, \
+                 shs_high, alphas, Rcw, tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo,     \
+                 visible, dcolor_dpws);                                                                         \
+  } while (0)
   switch (sh_dim * 2 + (raw ? 1 : 0)) {
     case 6: EGS_PRE(1, false); break;
     case 7: EGS_PRE(1, true); break;
@@ -766,11 +911,12 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
                                  const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                                  const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                                  const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                                 int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                                 size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream) {
+                                 int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws, int key_bits_hint,
+                                 void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals,
+                                 void* stream) {
   return fused_forward_impl(false, n, sh_dim, pws, rots, scales, shs, nullptr, alphas, Rcw, tcw, twc, fx, fy, cx, cy,
-                            width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible, key_bits_hint,
-                            ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
+                            width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible, dcolor_dpws,
+                            key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
 }
 
 extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots_raw,
@@ -778,13 +924,13 @@ extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const 
                                      const float* alphas_raw, const float* Rcw, const float* tcw, const float* twc,
                                      float fx, float fy, float cx, float cy, int width, int height,
                                      const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                                     int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                                     size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals,
-                                     void* stream) {
+                                     int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws,
+                                     int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                                     uint32_t* host_totals, void* stream) {
   EGS_CHECK_ARG(n == 0 || (rec && alphas_raw));  // the activated alpha only exists inside the records
   return fused_forward_impl(true, n, sh_dim, pws, rots_raw, scales_raw, low_shs, high_shs, alphas_raw, Rcw, tcw, twc,
                             fx, fy, cx, cy, width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible,
-                            key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
+                            dcolor_dpws, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
 }
 
 extern "C" size_t egs_fused_backward_ws_bytes(int n) { return egs_splat_bwd_ws_bytes(n); }
@@ -799,7 +945,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
                                const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                float* dloss_dshs, float* dloss_dshs_high, float* dloss_dalphas, float* dloss_dscales,
                                float* dloss_drots, float* dloss_dus, const int32_t* tile_order,
-                               float* grad_records, int phase, int row_begin, int row_count, void* stream) {
+                               float* grad_records, const float* dcolor_dpws, int phase, int row_begin, int row_count,
+                               void* stream) {
   // phase 0: everything; 1: only the draw pass (-> packed gradient records in ws); 2: only the per-Gaussian
   // chain rule, for rows [row_begin, row_begin + row_count) -- a data-parallel caller launches the rows in a
   // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
@@ -834,13 +981,17 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   dim3 g(div_up(row_count, 256)), b(256);
   hipStream_t s = (hipStream_t)stream;
   // row_begin is a multiple of the workgroup's 256 rows: every offset pointer keeps its 16-B alignment
+#define EGS_PREB_ARGS(NC, RAW)                                                                                    \
+  row_count, pp, pws + 3 * r0, rots + 4 * r0, scales + 3 * r0, shs + (RAW ? 3 : sh_dim) * r0,                      \
+      (RAW && shs_high) ? shs_high + kh * r0 : shs_high, alphas + r0, Rcw, tcw, twc, depths + r0,                  \
+      (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0, dloss_dshs + (RAW ? 3 : sh_dim) * r0,                    \
+      (RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high, dloss_dalphas + r0,                  \
+      dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0, dcolor_dpws ? dcolor_dpws + 9 * r0 : dcolor_dpws
 #define EGS_PREB(NC, RAW)                                                                                         \
-  EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW>), g, b, s, row_count, pp, pws + 3 * r0, rots + 4 * r0, \
-             scales + 3 * r0, shs + (RAW ? 3 : sh_dim) * r0, (RAW && shs_high) ? shs_high + kh * r0 : shs_high,    \
-             alphas + r0, Rcw, tcw, twc, depths + r0, (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0,           \
-             dloss_dshs + (RAW ? 3 : sh_dim) * r0,                                                                 \
-             (RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high, dloss_dalphas + r0,           \
-             dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0)
+  do {                                                                                                            \
+    if (dcolor_dpws) EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW, true>), g, b, s, EGS_PREB_ARGS(NC, RAW)); \
+    else EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW, false>), g, b, s, EGS_PREB_ARGS(NC, RAW));     \
+  } while (0)
   switch (sh_dim * 2 + (raw ? 1 : 0)) {
     case 6: EGS_PREB(1, false); break;
     case 7: EGS_PREB(1, true); break;
@@ -852,6 +1003,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
     default: EGS_PREB(16, true); break;
   }
 #undef EGS_PREB
+#undef EGS_PREB_ARGS
   EGS_LAUNCH_OK();
   return 0;
 }
@@ -866,12 +1018,13 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
                                   const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                   float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
                                   float* dloss_drots, float* dloss_dus, const int32_t* tile_order,
-                                  float* grad_records, int phase, int row_begin, int row_count, void* stream) {
+                                  float* grad_records, const float* dcolor_dpws, int phase, int row_begin,
+                                  int row_count, void* stream) {
   return fused_backward_impl(false, n, sh_dim, patches, width, height, pws, rots, scales, shs, nullptr, alphas, Rcw,
                              tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths, contrib,
                              final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, dloss_dpws,
                              dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, tile_order,
-                             grad_records, phase, row_begin, row_count, stream);
+                             grad_records, dcolor_dpws, phase, row_begin, row_count, stream);
 }
 
 extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
@@ -885,11 +1038,12 @@ extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int wi
                                       const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                                       float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                                       float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
-                                      const int32_t* tile_order, float* grad_records, int phase, int row_begin,
-                                      int row_count, void* stream) {
+                                      const int32_t* tile_order, float* grad_records, const float* dcolor_dpws,
+                                      int phase, int row_begin, int row_count, void* stream) {
   return fused_backward_impl(true, n, sh_dim, patches, width, height, pws, rots_raw, scales_raw, low_shs, high_shs,
                              alphas_raw, Rcw, tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths,
                              contrib, final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes,
                              dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
-                             dloss_drots_raw, dloss_dus, tile_order, grad_records, phase, row_begin, row_count, stream);
+                             dloss_drots_raw, dloss_dus, tile_order, grad_records, dcolor_dpws, phase, row_begin,
+                             row_count, stream);
 }

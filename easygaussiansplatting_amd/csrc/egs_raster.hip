@@ -822,6 +822,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
+  // staged entry: 12 floats (BOX: three b128 pieces) or 10 (two b128 + one b64: an entry's broadcast reads are
+  // 50 of the ~130 SIMD cycles it costs, on an LDS pipe the CU's four SIMDs share; b64 is half a b128)
+  // (the third piece keeps the 16-B slot stride: all three reads are immediate offsets from ONE address register)
   __shared__ float4 sA[64], sB[64], sC[64];
   const int lane = threadIdx.x;
   if (p.zero_buf) {   // every workgroup of the grid (padding ones included) clears its slice
@@ -910,8 +913,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
       const float c0 = la + (A.z * Dx * Dx + A.w * Dx * Dy + B.x * Dy * Dy);
       const float c1 = 2.f * A.z * Dx + A.w * Dy, c2 = 2.f * B.x * Dy + A.w * Dx;
       sA[lane] = make_float4(A.z, A.w, B.x, cap);   // qxx, qxy, qyy, cap
-      sB[lane] = make_float4(c0, c1, c2, C.y);      // polynomial about the tile centre; x pixel box (BOX)
-      sC[lane] = make_float4(B.z, B.w, C.x, C.z);   // colour; y pixel box (BOX)
+      if constexpr (BOX) {
+        sB[lane] = make_float4(c0, c1, c2, C.y);      // polynomial about the tile centre; x pixel box
+        sC[lane] = make_float4(B.z, B.w, C.x, C.z);   // colour; y pixel box
+      } else {
+        sB[lane] = make_float4(c0, c1, c2, B.z);      // polynomial about the tile centre; red
+        *reinterpret_cast<float2*>(&sC[lane]) = make_float2(B.w, C.x);   // green, blue
+      }
     }
     __syncthreads();
     // The reach masks of eight consecutive entries packed into one dword (4 bits each), gathered into the
@@ -936,7 +944,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
 #ifdef EGS_DRAW_PROBE_NOK    // LDS probe: two broadcast reads per entry instead of three (WRONG colours)
         const float4 Q = sA[j], P = sB[j], K = make_float4(0.5f, 0.25f, 0.125f, 0.f);
 #else
-        const float4 Q = sA[j], P = sB[j], K = sC[j];  // wave-uniform address: LDS broadcast
+        const float4 Q = sA[j], P = sB[j];            // wave-uniform address: LDS broadcast
+        float4 K;
+        if constexpr (BOX) K = sC[j];
+        else { const float2 gb = *reinterpret_cast<const float2*>(&sC[j]); K = make_float4(P.w, gb.x, gb.y, 0.f); }
 #endif
 #ifdef EGS_DRAW_DUMMY_SALU   // issue-limit probe (tools/lab_issue_probe.sh): N extra scalar instructions per entry
 #pragma unroll
@@ -1881,6 +1892,49 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   return 0;
 }
 }  // namespace egs
+
+// The packed 2D records of the draw kernels as a caller-held buffer: gsplatcu.splat packs them ONCE, draws from them
+// (egs_splat_draw_rec*) and keeps them for the splatB call that follows with the same tensors (egs_splat_bwd_rec) --
+// the seven-op surface otherwise packs twice per training step (2 x 20 us at 1 M Gaussians).
+extern "C" int egs_pack_records(int n, int width, int height, const float* us, const float* cinv2ds,
+                                const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,
+                                void* rec, void* stream) {
+  EGS_CHECK_ARG(n >= 0 && width > 0 && height > 0 && pol);
+  if (n == 0) return 0;
+  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && rec && (areas || pol->footprint != 1));
+  EGS_CHECK_ARG(((uintptr_t)rec & 15) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
+             pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)rec);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// splatB from the packed records (and, nullable, the [order | work] buffer the forward draw left behind: the tiles
+// are then dispatched by the work that draw MEASURED, no k_tile_work pass over `contrib`)
+extern "C" int egs_splat_bwd_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
+                                 const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                                 const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                                 const int32_t* tile_order, float* dloss_dus, float* dloss_dcinv2ds,
+                                 float* dloss_dalphas, float* dloss_dcolors, void* stream) {
+  EGS_CHECK_ARG(n >= 0 && patches >= 0 && width > 0 && height > 0 && pol);
+  if (n == 0) return 0;
+  EGS_CHECK_ARG(rec && ws && dloss_dus && dloss_dcinv2ds && dloss_dalphas && dloss_dcolors);
+  if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
+    set_error(EGS_ERR_WORKSPACE, "splat_bwd workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  float* gpack = nullptr;
+  int rc = splat_bwd_packed(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, contrib,
+                            final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream,
+                            rec, tile_order, nullptr);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,
+             dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
+  EGS_LAUNCH_OK();
+  return 0;
+}
 
 extern "C" int egs_splat_bwd(int n, int64_t patches, int width, int height, const float* us,
                              const float* cinv2ds, const float* alphas, const float* colors,

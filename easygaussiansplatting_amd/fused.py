@@ -34,6 +34,7 @@ REUSE_ORDER = os.environ.get("EGS_BWD_REUSE_ORDER", "1") != "0"   # A/B knob: se
 KEEP_FORWARD_ORDER = 16   # include/egs_hip.h EGS_BWD_KEEP_FORWARD_ORDER
 ORDER_REFRESH = max(2, int(os.environ.get("EGS_TILE_ORDER_REFRESH", "4")))   # renders of a camera between order refreshes
 TILE_WORK_CACHE = os.environ.get("EGS_TILE_WORK_CACHE", "1") != "0"  # A/B knob: forward dispatch order by remembered work
+SAVE_DCOLOR = os.environ.get("EGS_SAVE_DCOLOR", "1") != "0"          # A/B knob: forward keeps dcolor/dpw for backward
 MAILBOX_SLOTS = 64
 
 
@@ -41,7 +42,7 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "order", "order_by_work", "gpack", "width", "height", "ticket", "_patches", "_keep")
+                 "order", "order_by_work", "gpack", "dcw", "width", "height", "ticket", "_patches", "_keep")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
@@ -245,8 +246,8 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     host_slot = [None]       # mailbox slot the binning kernels also write {P, max key} into (enqueue-ahead path)
     tail = lambda hint, total: (_ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc), float(cam.fx), float(cam.fy),
                                 float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
-                                _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), hint, _ptr(ws_bin),
-                                ws_bin_bytes, _ptr(total), host_slot[0], st)
+                                _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), _ptr(S.dcw), hint,
+                                _ptr(ws_bin), ws_bin_bytes, _ptr(total), host_slot[0], st)
     image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
     S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
@@ -254,6 +255,9 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     S.order = None            # [tile dispatch order | per-tile work]: ONE buffer per camera, see below
     # packed gradient records of the backward pass: zeroed on the side by the forward draw kernel (one use)
     S.gpack = torch.empty((max(n, 1), 12), dtype=f32, device=dev) if (need_grad and n > 0) else None
+    # dcolor/dpw per Gaussian, written by the preprocess kernel for the backward pass: that pass then never reads the
+    # SH coefficients (36 B written + read instead of a 4K-byte row re-read; EGS_SAVE_DCOLOR=0: A/B knob)
+    S.dcw = torch.empty((n, 9), dtype=f32, device=dev) if (need_grad and n > 0 and SAVE_DCOLOR) else None
 
     def draw_exact(patches):
         S.gsid = torch.empty(patches, dtype=i32, device=dev)
@@ -451,12 +455,13 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     if raw:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward_raw(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *mid,
-            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), phase, b, c,
-            st))
+            _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack),
+            _ptr(getattr(S, "dcw", None)), phase, b, c, st))
     else:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *mid, _ptr(dalphas),
-            _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), phase, b, c, st))
+            _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), _ptr(getattr(S, "dcw", None)), phase,
+            b, c, st))
     # the forward pass was dispatched by remembered work: the backward pass keeps its order (no second order kernel)
     keep = KEEP_FORWARD_ORDER if (REUSE_ORDER and getattr(S, "order_by_work", False)) else 0
     hook = _exchange_hook

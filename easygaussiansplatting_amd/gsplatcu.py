@@ -89,8 +89,11 @@ def _chk(t, name, dtype, shape):
     return t.contiguous()
 
 
-def _zeros(shape, like, dtype=torch.float32):
-    return torch.zeros(shape, dtype=dtype, device=like.device)
+def _out(shape, like, dtype=torch.float32):
+    """Output of an op: the kernels write EVERY row (culled Gaussians as zeros, what the reference's zero-filled
+    ``torch::full(..., 0)`` outputs read as, gausplat.cu:170-178), so no fill kernel runs -- torch.zeros here cost
+    528 B per Gaussian and training step of pure memset."""
+    return torch.empty(shape, dtype=dtype, device=like.device)
 
 
 def _lib_on(t):
@@ -110,8 +113,8 @@ def project(pws, Rcw, tcw, focal_x, focal_y, center_x, center_y, calc_J):
     tcw = _chk(tcw, "tcw", torch.float32, (3,))
     lib = _lib_on(pws)
     n = pws.shape[0]
-    us = _zeros((n, 2), pws); pcs = _zeros((n, 3), pws); depths = _zeros((n,), pws)
-    J = _zeros((n, 2, 3), pws) if calc_J else None
+    us = _out((n, 2), pws); pcs = _out((n, 3), pws); depths = _out((n,), pws)
+    J = _out((n, 2, 3), pws) if calc_J else None
     _lib.check(lib.egs_project(n, _ptr(pws), _ptr(Rcw), _ptr(tcw), float(focal_x), float(focal_y),
                                float(center_x), float(center_y), C.byref(_pol()), _ptr(us), _ptr(pcs),
                                _ptr(depths), _ptr(J), _stream()))
@@ -126,9 +129,9 @@ def computeCov3D(rots, scales, depths, calc_J):
     scales = _chk(scales, "scales", torch.float32, (n, 3))
     depths = _chk(depths, "depths", torch.float32, (n,))
     lib = _lib_on(rots)
-    cov3ds = _zeros((n, 6), rots)
-    dq = _zeros((n, 6, 4), rots) if calc_J else None
-    ds = _zeros((n, 6, 3), rots) if calc_J else None
+    cov3ds = _out((n, 6), rots)
+    dq = _out((n, 6, 4), rots) if calc_J else None
+    ds = _out((n, 6, 3), rots) if calc_J else None
     _lib.check(lib.egs_cov3d(n, _ptr(rots), _ptr(scales), _ptr(depths), C.byref(_pol()), _ptr(cov3ds),
                              _ptr(dq), _ptr(ds), _stream()))
     return [cov3ds, dq, ds] if calc_J else [cov3ds]
@@ -145,9 +148,9 @@ def computeCov2D(cov3ds, pcs, Rcw, depths, focal_x, focal_y, width, height, calc
     Rcw = _chk(Rcw, "Rcw", torch.float32, (3, 3))
     depths = _chk(depths, "depths", torch.float32, (n,))
     lib = _lib_on(pcs)
-    cov2ds = _zeros((n, 3), pcs)
-    d3 = _zeros((n, 3, 6), pcs) if calc_J else None
-    dpc = _zeros((n, 3, 3), pcs) if calc_J else None
+    cov2ds = _out((n, 3), pcs)
+    d3 = _out((n, 3, 6), pcs) if calc_J else None
+    dpc = _out((n, 3, 3), pcs) if calc_J else None
     _lib.check(lib.egs_cov2d(n, _ptr(cov3ds), _ptr(pcs), _ptr(Rcw), _ptr(depths), float(focal_x),
                              float(focal_y), float(width), float(height), C.byref(_pol()), _ptr(cov2ds),
                              _ptr(d3), _ptr(dpc), _stream()))
@@ -166,9 +169,9 @@ def sh2Color(shs, pws, twc, calc_J):
         raise ValueError("shs must have 3, 12, 27 or 48 columns (SH degree 0..3), got %d" % K)
     twc = _chk(twc, "twc", torch.float32, (3,))
     lib = _lib_on(pws)
-    colors = _zeros((n, 3), pws)
-    dsh = _zeros((n, 1, K // 3), pws) if calc_J else None
-    dpw = _zeros((n, 3, 3), pws) if calc_J else None
+    colors = _out((n, 3), pws)
+    dsh = _out((n, 1, K // 3), pws) if calc_J else None
+    dpw = _out((n, 3, 3), pws) if calc_J else None
     _lib.check(lib.egs_sh2color(n, K, _ptr(shs), _ptr(pws), _ptr(twc), _ptr(colors), _ptr(dsh), _ptr(dpw),
                                 _stream()))
     return [colors, dsh, dpw] if calc_J else [colors]
@@ -182,9 +185,9 @@ def inverseCov2D(cov2ds, depths, calc_J):
     n = cov2ds.shape[0]
     depths = _chk(depths, "depths", torch.float32, (n,))
     lib = _lib_on(cov2ds)
-    cinv = _zeros((n, 3), cov2ds)
-    areas = _zeros((n, 2), cov2ds, torch.int32)
-    J = _zeros((n, 3, 3), cov2ds) if calc_J else None
+    cinv = _out((n, 3), cov2ds)
+    areas = _out((n, 2), cov2ds, torch.int32)
+    J = _out((n, 3, 3), cov2ds) if calc_J else None
     _lib.check(lib.egs_inv_cov2d(n, _ptr(cov2ds), _ptr(depths), C.byref(_pol()), _ptr(cinv), _ptr(areas),
                                  _ptr(J), _stream()))
     return [cinv, areas, J] if calc_J else [cinv, areas]
@@ -266,6 +269,31 @@ def _alphas(alphas, n):
     return _chk(alphas.reshape(n), "alphas", torch.float32, (n,))
 
 
+# What the last `splat` of a device and stream left for the `splatB` that follows it (GSFunction.backward,
+# gsmodel.py:67-69, calls splatB with the very tensors its forward gave to splat): the packed records and the
+# [order | work] buffer.  The memo keeps STRONG references to the four input tensors the records are built from, so their memory cannot be
+# handed to another tensor while the entry lives; an entry is used only when every input is the same memory at the
+# same version (torch's in-place counter) under the same policy -- anything else repacks, exactly as before.
+_splat_memo = {}
+
+
+def _memo_sig(tensors):
+    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+
+
+def _memo_store(dev, st, tensors, width, height, rec, order):
+    _splat_memo[(dev.index, int(st.value or 0))] = (tensors, _memo_sig(tensors), width, height, _policy_name, rec, order)
+
+
+def _memo_lookup(dev, st, tensors, width, height):
+    m = _splat_memo.get((dev.index, int(st.value or 0)))
+    if m is None or m[2] != width or m[3] != height or m[4] != _policy_name:
+        return None, None
+    if m[1] != _memo_sig(tensors) or _memo_sig(m[0]) != m[1]:   # other tensors, or the remembered ones changed since
+        return None, None
+    return m[5], m[6]
+
+
 def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     """-> [image[3,H,W], contrib[H,W] int32, final_tau[H,W],
            patch_range_per_tile[T,2] int32, gsid_per_patch[P] int32].
@@ -292,14 +320,24 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
     st = _stream()
     key = (n, width, height)
+    # The packed 48-B records the draw kernels gather are built ONCE here and kept, with the [dispatch order | measured
+    # work] buffer of the draw, for the splatB call that follows with the same tensors (_SplatMemo): the seven-op
+    # surface otherwise packs the same records twice per training step and rebuilds the per-tile work from `contrib`.
+    rec = torch.empty((max(n, 1), 12), dtype=torch.float32, device=dev)
+    order = torch.empty(lib.egs_tile_order_len(width, height), dtype=torch.int32, device=dev)
+    if n > 0:
+        _lib.check(lib.egs_pack_records(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
+                                        _ptr(areas), pol, _ptr(rec), st))
+        if _pol().footprint != 1:      # (pixel-box records also depend on `areas`, which this op mutates)
+            _memo_store(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order)
 
     def draw_exact(patches):
         gsid = torch.empty(patches, dtype=torch.int32, device=dev)
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw(n, patches, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
-                                      _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
-                                      _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid), st))
+        _lib.check(lib.egs_splat_draw_rec(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
+                                          ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges),
+                                          _ptr(gsid), _ptr(order), None, None, 0, st))
         return gsid
 
     def render_exact():
@@ -339,10 +377,10 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         gsid_full = torch.empty(cap, dtype=torch.int32, device=dev)
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw_dev(n, cap, _ptr(total), width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
-                                          _ptr(colors), _ptr(areas), pol, _ptr(ws_bin), _ptr(ws_draw), ws_draw_bytes,
-                                          _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges), _ptr(gsid_full),
-                                          st))
+        _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, width, height, _ptr(rec), pol, _ptr(ws_bin),
+                                              _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
+                                              _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), _ptr(order), None, None,
+                                              0, st))
     except BaseException:
         with ctx.lock:                       # the slot goes back: nothing will ever fetch it
             t.status = _fused._Ticket.FAILED
@@ -389,10 +427,19 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
     d_color = torch.empty((n, 1, 3), dtype=torch.float32, device=dev)
     ws_bytes = lib.egs_splat_bwd_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
-                                 _ptr(colors), _ptr(areas), C.byref(pol), _ptr(contrib), _ptr(final_tau),
-                                 _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes, _ptr(d_us), _ptr(d_cinv),
-                                 _ptr(d_alpha), _ptr(d_color), _stream()))
+    st = _stream()
+    rec, order = (None, None)
+    if n > 0 and pol.footprint != 1:   # (the pixel-box policy's records also depend on `areas`, which splat mutates)
+        rec, order = _memo_lookup(dev, st, (us, cinv2ds, alphas, colors), width, height)
+    if rec is not None:     # the records (and the measured per-tile work) of the splat call these tensors came from
+        _lib.check(lib.egs_splat_bwd_rec(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
+                                         _ptr(final_tau), _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes,
+                                         _ptr(order), _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha), _ptr(d_color), st))
+    else:
+        _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                     _ptr(colors), _ptr(areas), C.byref(pol), _ptr(contrib), _ptr(final_tau),
+                                     _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes, _ptr(d_us), _ptr(d_cinv),
+                                     _ptr(d_alpha), _ptr(d_color), st))
     return [d_us, d_cinv, d_alpha, d_color]
 
 

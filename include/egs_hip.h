@@ -16,9 +16,12 @@
  *   - `stream` is a hipStream_t (passed as void*); every call only ENQUEUES work
  *     on it -- no device-wide synchronisation, no allocation;
  *   - Jacobian pointers may be NULL (calc_J = False);
- *   - outputs must be zero-filled by the caller (the reference allocates them with
- *     torch::full(.., 0), gausplat.cu:36-38,170,214,265,307,347): culled Gaussians
- *     are left untouched and therefore read as 0;
+ *   - outputs need NO zero-fill by the caller: every op writes every row of every output it is
+ *     handed, culled Gaussians as zeros -- what the reference's torch::full(.., 0) outputs read as
+ *     (gausplat.cu:36-38,170,214,265,307,347) without the 528 B per Gaussian and step of fill
+ *     kernels; per-Gaussian output rows leave the kernels as dwordx4 stores of whole 256-row spans,
+ *     so output pointers of the five per-Gaussian ops and of egs_chain_rule must be 16-B aligned
+ *     (checked; torch allocations are);
  *   - return value: 0 on success, otherwise a hipError_t (or EGS_ERR_*) and
  *     egs_last_error_string() describes it.
  */
@@ -32,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 3
+#define EGS_ABI_VERSION 4
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -148,8 +151,21 @@ int egs_splat_draw_dev(int n, int64_t patch_capacity, const uint32_t* total_patc
                        size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                        int32_t* patch_range_per_tile, int32_t* gsid_per_patch, void* stream);
 
+/* The packed 48-byte 2D records the draw kernels gather (one aligned record per list entry instead of the
+ * reference's four gathers, fetch2shared kernel.cu:13-44) as a CALLER-HELD buffer rec[N][12]: gsplatcu.splat packs
+ * once, draws with egs_splat_draw_rec / _rec_dev and keeps the buffer for the splatB that follows with the same
+ * tensors (egs_splat_bwd_rec; tile_order nullable = the [order | work] buffer of that draw). */
+int egs_pack_records(int n, int width, int height, const float* us, const float* cinv2ds, const float* alphas,
+                     const float* colors, const int32_t* areas /*pixel-box policy only*/, const EgsPolicy* pol,
+                     void* rec, void* stream);
+int egs_splat_bwd_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
+                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                      const int32_t* tile_order /*nullable*/, float* dloss_dus, float* dloss_dcinv2ds,
+                      float* dloss_dalphas, float* dloss_dcolors, void* stream);
+
 /* gsplatcu.splatB  (ext.cpp:20-32, gausplat.cu:114-159, kernel.cu:809-950).
- * Gradient outputs (zero-filled by the caller): dloss_dus[N,2], dloss_dcinv2ds[N,3],
+ * Gradient outputs (fully written): dloss_dus[N,2], dloss_dcinv2ds[N,3],
  * dloss_dalphas[N], dloss_dcolors[N,3].  ws: egs_splat_bwd_ws_bytes(n). */
 size_t egs_splat_bwd_ws_bytes(int n);
 int egs_splat_bwd(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
@@ -207,8 +223,12 @@ int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, co
                       const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                       const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                       const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                      int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                      size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream);
+                      int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws /*nullable*/, int key_bits_hint,
+                      void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream);
+/* dcolor_dpws (nullable, [N][9] floats, 16-B aligned): dcolor/dpw of every Gaussian (what sh2Color's calc_J hands
+ * back as dcolor_dpws, gausplat.cu:298-338), kept for the backward pass: egs_fused_backward given the same pointer
+ * never reads the SH coefficients again -- eq (7)'s colour term is the only thing it needs them for, dL/dsh needs
+ * the basis alone -- i.e. 36 B written here for 4 sh_dim bytes (192 at SH degree 3) not re-read there. */
 int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                        const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image,
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
@@ -280,7 +300,8 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                        float* dloss_dpws, float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
                        float* dloss_drots, float* dloss_dus, const int32_t* tile_order /*nullable*/,
-                       float* grad_records /*nullable: zeroed by the forward draw*/, int phase, int row_begin,
+                       float* grad_records /*nullable: zeroed by the forward draw*/,
+                       const float* dcolor_dpws /*nullable: left by egs_fused_forward*/, int phase, int row_begin,
                        int row_count, void* stream);
 
 /* The same pair on the OPTIMIZER's tensors (gsplat/gsmodel.py:96-129: alphas_raw, scales_raw, rots_raw,
@@ -292,8 +313,9 @@ int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots
                           const float* low_shs, const float* high_shs, const float* alphas_raw, const float* Rcw,
                           const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
                           int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                          int32_t* areas, void* rec, uint8_t* visible, int key_bits_hint, void* ws_bin,
-                          size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream);
+                          int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws /*nullable*/,
+                          int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                          uint32_t* host_totals, void* stream);
 int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
                            const float* rots_raw, const float* scales_raw, const float* low_shs,
                            const float* high_shs, const float* alphas_raw, const float* Rcw, const float* tcw,
@@ -304,8 +326,9 @@ int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int he
                            const float* dloss_dgammas, void* ws, size_t ws_bytes, float* dloss_dpws,
                            float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                            float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
-                           const int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/, int phase,
-                           int row_begin, int row_count, void* stream);
+                           const int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/,
+                           const float* dcolor_dpws /*nullable*/, int phase, int row_begin, int row_count,
+                           void* stream);
 
 /* ---- fused training loss -----------------------------------------
  * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the
