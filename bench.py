@@ -367,7 +367,12 @@ def main():
     with torch.no_grad():
         _, ranges, gsid = forward_only()
         lens = (ranges[:, 1] - ranges[:, 0]).to(torch.int64)
-        P = int(gsid.shape[0]); T = int(ranges.shape[0])
+        P_drawn = int(gsid.shape[0]); T = int(ranges.shape[0])
+        # P of the reference's lists (every tile of every rect, getRects kernel.cu:82-122): what SURVEY 8(d)'s
+        # algorithmic-byte formulas count.  The fused path draws footprint-culled lists (P_drawn <= P).
+        P = int(render(params["pws"].detach(), params["shs"].detach(), params["alphas"].detach(),
+                       params["scales"].detach(), params["rots"].detach(), cam)[4].shape[0]) if a.mode == "fused" \
+            else P_drawn
         max_len = int(lens.max().item())
         pairs = int(lens.sum().item()) * 256
         # forward-only rate (BASELINE configs[1]), untimed by the headline
@@ -557,7 +562,10 @@ def main():
                                         "length at first sight); backward: by the work this render measured"
                                         if fused_path.TILE_WORK_CACHE else "forward: by list length; backward: by "
                                         "the work this render measured",
-                       "patches": P, "tiles": T, "max_list_len": max_len, "pixel_gaussian_pairs": pairs},
+                       "patches": P, "patches_drawn": P_drawn, "tiles": T, "max_list_len": max_len,
+                       "pixel_gaussian_pairs": pairs,
+                       "lists": "footprint-culled (fused path)" if (a.mode == "fused" and fused_path.CULL_LISTS)
+                                else "reference rects"},
             "gpu_busy_ms_per_step": None if gpu_busy_ms is None else round(gpu_busy_ms, 4),
             "wall_over_gpu_busy": None if not gpu_busy_ms else round(ms / gpu_busy_ms, 4),
             "redone_steps": redone[0],

@@ -70,15 +70,15 @@ SIGNATURES = {
     "egs_scan_ws_bytes": (_sz, [_i64]),
     "egs_exclusive_scan_u32": (_i, [_i64, _P, _P, _P, _P, _P, _sz, _P]),
     "egs_chain_rule": (_i, [_i, _i] + [_P] * 16 + [_P]),
-    "egs_fused_forward": (_i, [_i, _i] + [_P] * 8 + [_f] * 4 + [_i, _i, _PP] + [_P] * 8 + [_i, _P, _sz, _P, _P, _P]),
+    "egs_fused_forward": (_i, [_i, _i] + [_P] * 8 + [_f] * 4 + [_i, _i, _PP] + [_P] * 8 + [_i, _i, _P, _sz, _P, _P, _P]),
     "egs_fused_forward_raw": (_i, [_i, _i] + [_P] * 9 + [_f] * 4 + [_i, _i, _PP] + [_P] * 8
-                              + [_i, _P, _sz, _P, _P, _P]),
+                              + [_i, _i, _P, _sz, _P, _P, _P]),
     "egs_fused_backward_raw": (_i, [_i, _i, _i64, _i, _i] + [_P] * 9 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
                                + [_P] * 7 + [_P, _P, _P, _i, _i, _i, _P]),
     "egs_tile_order_len": (_sz, [_i, _i]),
-    "egs_splat_draw_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P]),
+    "egs_splat_draw_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P]),
     "egs_splat_draw_rec_dev": (_i, [_i, _i64, _P, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P,
-                                    _i, _P]),
+                                    _i, _i, _P]),
     "egs_hbm_copy_probe": (_i, [_P, _P, _sz, _P]),
     "egs_mailbox_create": (_P, [_i]),
     "egs_mailbox_destroy": (None, [_P]),

@@ -87,16 +87,42 @@ struct Carver {
 struct BinParams {
   int W, H, gx, gy;
   int footprint, far_cull, depth_key, mutate;
+  int cull_lists;   // lists may drop the tiles of a rect that the footprint alpha' >= alpha_skip cannot reach (fused path)
 };
-// tile rect of one Gaussian packed in 8 bytes: {x0 | y0 << 16, w | h << 16} (tiles; w * h = its patch count)
-__host__ __device__ inline uint2 pack_rect(uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) {
-  return make_uint2(x0 | (y0 << 16), (x1 - x0) | ((y1 - y0) << 16));
-}
+// What the binning stage keeps of a Gaussian (32 bytes, gathered ONCE into depth order by the depth sort's last
+// scatter pass): its footprint -- centre u, the conic in "power form" and the threshold m:
+//     the Gaussian blends into a pixel  <=>  A dx^2 + 2 Bh dx dy + C dy^2 <= m        (d = pixel - u)
+// (A, 2 Bh, C) = -(qxx, qxy, qyy) of the draw record, m = -thr = log2(alpha / alpha_skip): exactly the skip test of
+// the draw kernels (kernel.cu:246) -- and its tile rect (getRects, kernel.cu:82-122).  m = +inf: no footprint
+// culling, the Gaussian is emitted for every tile of its rect (the reference's lists).
+struct BinRec {
+  float ux, uy, A, Bh;
+  float C, m;
+  uint32_t xy;   // x0 | y0 << 16   (tiles)
+  uint32_t wh;   // w | h << 16
+};
+static_assert(sizeof(BinRec) == 32, "BinRec is two dwordx4");
+// The compact form the binning stage works with (16 bytes, gathered ONCE into depth order by the depth sort's last
+// scatter pass):  {x0 | y0 << 16,  w | h << 16 | flags,  b_lo, b_hi}  (tiles).
+//   rect of at most 4 x 4 tiles:  b = 64-bit bitmap of the 8x8 pixel blocks of the rect the footprint reaches, bit
+//     8 by + bx relative to the rect's first block (ALL blocks of the rect when the Gaussian is not cullable).  The
+//     Gaussian is emitted for the tiles with a block set, the list value's mask is the tile's four bits: emission is
+//     bit arithmetic, the square roots of the footprint are taken once per Gaussian, in k_preprocess_fwd.
+//   larger rect (EGS_CR_BIG):  b_lo = patch count, b_hi != 0: cullable -- k_bin_emit walks the rows of the rect with
+//     the full footprint record br[gaussian] (rare: 0.3 % of the patches of the 1 M scene's view 0, 11 % of a ring view).
+#define EGS_CR_BIG 0x80000000u
+#define EGS_CR_WH_MASK 0x7FFFFFFFu
 struct BinCountOut {  // where k_bin_count's results live inside the bin workspace
-  uint2* rc;                       // packed rect (+ implied count) per Gaussian
+  uint4* cr;                       // compact bin record per Gaussian
+  BinRec* br;                      // footprint record, written for the Gaussians with a BIG cullable rect only
   uint32_t *dkeys, *ids, *maxkey;  // maxkey[1 + workgroup] = per-workgroup maximum of the depth keys
 };
-BinParams make_bin_params(int width, int height, const EgsPolicy* pol);
+// list values of the culled lists (fused path): Gaussian index in the low 28 bits, in the high 4 the 8x8 pixel blocks
+// of the tile the footprint reaches (bit k = block (k&1, k>>1)) -- computed ONCE per (tile, Gaussian) at emission
+// instead of per entry and draw kernel, and exact where the draw kernels' own box test is conservative
+#define EGS_GSID_BITS 28
+#define EGS_GSID_MASK 0x0FFFFFFFu
+BinParams make_bin_params(int width, int height, const EgsPolicy* pol, bool cull_lists = false);
 bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out);
 // everything of egs_splat_bin after k_bin_count (max reduce, depth sort, offsets scan)
 // host_totals (nullable): page-locked host uint32[2] the kernels ALSO write {P, max depth key} into (mailbox slot)
@@ -112,7 +138,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      float** gpack, void* stream, const void* rec_in /* packed records or NULL */,
                      const int32_t* tile_order /* dispatch order left by the forward pass, or NULL */,
                      float* grad_records /* [N][12] records ALREADY ZEROED (by the forward draw kernel), or NULL */,
-                     bool keep_forward_order = false /* dispatch the tiles exactly as tile_order says */);
+                     bool keep_forward_order = false /* dispatch the tiles exactly as tile_order says */,
+                     bool masked_lists = false /* gsid_per_patch carries block masks (culled lists, fused path) */);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

@@ -383,6 +383,147 @@ __device__ __forceinline__ uint32_t bin_count_one(const BinParams& p, float ux, 
   return cnt;
 }
 
+// ---- exact footprint of a Gaussian on the tile grid (culled lists of the fused path) ---------------------------
+// One source for the COUNT (k_preprocess_fwd: how many tiles the Gaussian is emitted for) and the EMISSION
+// (k_bin_emit: which ones): both evaluate these functions on the same stored BinRec, so they must be bit-reproducible
+// across kernels -- no FMA contraction (pragma below), hardware rcp / sqrt (one instruction each, the same bits
+// wherever they are issued).  Conservative by construction: the x-extent of {footprint ellipse} n {8-pixel slab} is
+// exact in real arithmetic, the slab is taken continuous in y, and every bound is widened by `eps` (1 % of the
+// extent + 0.05 px, the slack of the draw kernels' own certain-miss box) before it is rounded to pixel centres.
+struct Foot {
+  float ux, uy, A, Bh, C, m;
+  float det, rA, ymax, k, eps;
+  int px_lo, px_hi;   // pixel range of the tile rect in x
+  bool cull;          // false: emit the whole rect, every block reachable
+};
+struct SlabPx { int pl, pr; };   // pixel centres [pl, pr] of a slab inside the footprint; empty: pl > pr
+#pragma clang fp contract(off)
+__device__ __forceinline__ Foot foot_setup(const BinRec& b) {
+  Foot f;
+  f.ux = b.ux; f.uy = b.uy; f.A = b.A; f.Bh = b.Bh; f.C = b.C; f.m = b.m;
+  f.cull = b.m < __int_as_float(0x7f800000);
+  const int x0 = (int)(b.xy & 0xFFFFu), w = (int)(b.wh & 0xFFFFu);
+  f.px_lo = x0 * EGS_TILE;
+  f.px_hi = (x0 + w) * EGS_TILE - 1;
+  f.det = f.A * f.C - f.Bh * f.Bh;
+  const float rdet = __builtin_amdgcn_rcpf(f.det);
+  f.rA = __builtin_amdgcn_rcpf(f.A);
+  const float xext = __builtin_amdgcn_sqrtf(f.m * f.C * rdet);   // largest |dx| of the footprint
+  f.ymax = __builtin_amdgcn_sqrtf(f.m * f.A * rdet);             // largest |dy|
+  f.k = f.Bh * __builtin_amdgcn_rcpf(f.C) * xext;                // the rightmost point sits at dy = -k, the leftmost at +k
+  f.eps = 0.05f + 0.01f * fmaxf(xext, f.ymax);
+  return f;
+}
+// pixel centres of rows [Y0, Y0 + 7] that can lie inside the footprint
+__device__ __forceinline__ SlabPx foot_slab(const Foot& f, int Y0) {
+  SlabPx o;
+  o.pl = 0x7fffffff; o.pr = (int)0x80000000;
+  const float ya = fmaxf((float)Y0 - f.uy - f.eps, -f.ymax - f.eps);
+  const float yb = fminf((float)(Y0 + 7) - f.uy + f.eps, f.ymax + f.eps);
+  if (!(ya <= yb)) return o;
+  const float yr = fminf(fmaxf(-f.k, ya), yb), yl = fminf(fmaxf(f.k, ya), yb);
+  const float Am = f.A * f.m;
+  const float sr = __builtin_amdgcn_sqrtf(fmaxf(Am - f.det * yr * yr, 0.f));
+  const float sl = __builtin_amdgcn_sqrtf(fmaxf(Am - f.det * yl * yl, 0.f));
+  const float xr = f.ux + ((sr - f.Bh * yr) * f.rA + f.eps);
+  const float xl = f.ux + ((-sl - f.Bh * yl) * f.rA - f.eps);
+  if (!(xl <= xr)) return o;     // (NaN: cannot happen for a footprint that passed foot_cullable; stay empty)
+  o.pl = max(f.px_lo, (int)ceilf(fmaxf(xl, -1.0e9f)));
+  o.pr = min(f.px_hi, (int)floorf(fminf(xr, 1.0e9f)));
+  if (o.pl > o.pr) { o.pl = 0x7fffffff; o.pr = (int)0x80000000; }
+  return o;
+}
+// tiles [lo, hi] of tile row `ty` the Gaussian is emitted for (lo > hi: none) and the two slabs of that row
+__device__ __forceinline__ void foot_row(const Foot& f, int ty, SlabPx& s0, SlabPx& s1, int& lo, int& hi) {
+  s0 = foot_slab(f, ty * EGS_TILE);
+  s1 = foot_slab(f, ty * EGS_TILE + 8);
+  lo = min(s0.pl, s1.pl) >> 4;          // (empty slabs hold +-INT extremes: min / max ignore them)
+  hi = max(s0.pr, s1.pr) >> 4;
+  if (s0.pl > s0.pr && s1.pl > s1.pr) { lo = 1; hi = 0; }
+}
+// 4-bit reach mask of tile column tx (bit k = block (k&1, k>>1))
+__device__ __forceinline__ uint32_t foot_mask(const SlabPx& s0, const SlabPx& s1, int tx) {
+  const int X = tx * EGS_TILE;
+  uint32_t m = 0u;
+  if (s0.pl <= X + 7 && s0.pr >= X) m |= 1u;
+  if (s0.pl <= X + 15 && s0.pr >= X + 8) m |= 2u;
+  if (s1.pl <= X + 7 && s1.pr >= X) m |= 4u;
+  if (s1.pl <= X + 15 && s1.pr >= X + 8) m |= 8u;
+  return m;
+}
+// number of tiles the Gaussian is emitted for (the whole rect when it is not cullable)
+__device__ __forceinline__ uint32_t foot_count(const BinRec& b) {
+  const int w = (int)(b.wh & 0xFFFFu), h = (int)(b.wh >> 16), y0 = (int)(b.xy >> 16);
+  if (b.m < 0.f) return 0u;                    // never blends (alpha < alpha_skip)
+  const Foot f = foot_setup(b);
+  if (!f.cull) return (uint32_t)(w * h);
+  uint32_t c = 0u;
+  for (int ry = 0; ry < h; ++ry) {
+    SlabPx s0, s1;
+    int lo, hi;
+    foot_row(f, y0 + ry, s0, s1, lo, hi);
+    if (hi >= lo) c += (uint32_t)(hi - lo + 1);
+  }
+  return c;
+}
+// the 64-bit block bitmap of a rect of at most 4 x 4 tiles (bit 8 by + bx, blocks relative to the rect's first one)
+__device__ __forceinline__ unsigned long long foot_bitmap(const BinRec& b) {
+  const int x0 = (int)(b.xy & 0xFFFFu), y0 = (int)(b.xy >> 16), w = (int)(b.wh & 0xFFFFu), h = (int)(b.wh >> 16);
+  const uint32_t rowfull = (1u << (2 * w)) - 1u;
+  unsigned long long bits = 0ull;
+  if (b.m < 0.f) return 0ull;                  // never blends (alpha < alpha_skip)
+  const Foot f = foot_setup(b);
+  for (int s = 0; s < 2 * h; ++s) {
+    uint32_t row = rowfull;
+    if (f.cull) {
+      const SlabPx sp = foot_slab(f, y0 * EGS_TILE + 8 * s);
+      row = 0u;
+      if (sp.pl <= sp.pr) {
+        const int bl = (sp.pl >> 3) - 2 * x0, br = (sp.pr >> 3) - 2 * x0;     // 0 <= bl <= br < 2 w  (pixel range clamped)
+        row = ((2u << br) - 1u) & ~((1u << bl) - 1u);
+      }
+    }
+    bits |= (unsigned long long)row << (8 * s);
+  }
+  return bits;
+}
+#pragma clang fp contract(fast)
+// tiles of a <= 4 x 4 rect that have a block set: bit 16 ty + 2 tx
+__device__ __forceinline__ unsigned long long cr_tile_bits(unsigned long long blocks) {
+  unsigned long long t = blocks | (blocks >> 1);
+  t |= t >> 8;
+  return t & 0x0055005500550055ull;
+}
+__device__ __forceinline__ uint32_t cr_count(const uint4& c) {
+  if (c.y & EGS_CR_BIG) return c.z;
+  return (uint32_t)__popcll(cr_tile_bits(((unsigned long long)c.w << 32) | c.z));
+}
+// The footprint record of one Gaussian.  `cull`: the lists may drop tiles the footprint cannot reach (fused path);
+// otherwise, and whenever the conic does not describe an ellipse the bounds above hold for (same rule as the
+// certain-miss box of make_record), m = +inf and the Gaussian keeps every tile of its rect.
+__device__ __forceinline__ BinRec make_binrec(float ux, float uy, float c0, float c1, float c2, float alpha,
+                                              float alpha_skip, bool cull, const uint4& rect, uint32_t cnt_rect) {
+  BinRec b;
+  const float inf = __int_as_float(0x7f800000);
+  b.ux = ux; b.uy = uy;
+  b.A = -EGS_NHL2E * c0; b.Bh = -EGS_NHL2E * c1; b.C = -EGS_NHL2E * c2;   // -(qxx, qxy / 2, qyy) of the draw record
+  b.m = inf;
+  b.xy = cnt_rect ? (rect.x | (rect.y << 16)) : 0u;
+  b.wh = cnt_rect ? ((rect.z - rect.x) | ((rect.w - rect.y) << 16)) : 0u;
+  if (cull && alpha_skip > 0.f) {
+    const float det = c0 * c2 - c1 * c1;
+    if (det > 1e-4f * c0 * c2 && c0 > 0.f && c2 > 0.f && alpha == alpha) {
+      if (alpha >= alpha_skip) {
+        const float m = log2f(alpha / alpha_skip);      // = -thr of the draw record
+        if (m == m && m < inf) b.m = m;
+      } else {
+        b.m = -1.f;                                      // alpha' <= alpha < skip everywhere: never blends (kernel.cu:246)
+      }
+    }
+  }
+  return b;
+}
+
 // per-workgroup (256 threads) maximum of the depth keys -> maxkey[1 + workgroup]; no atomics (a
 // same-address atomicMax per wave measured +170 us); k_max_reduce folds the <= 4 K partial maxima
 // `wm`: four words of LDS (the caller's: k_preprocess_fwd lends its staging buffer -- 16 bytes of its own would

@@ -493,7 +493,10 @@ __device__ __forceinline__ void stage_span_out(const float* row, float* __restri
 // JW: also write dcolor/dpw (dcolor_dpws) for the backward pass -- a training render; the SH Jacobian keeps ~40 more
 // registers alive, so these instances are not pinned to 8 waves per SIMD
 template <int NC, bool RAW, bool JW>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAW || JW) ? 1 : 8, 8))) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
+#ifndef EGS_PRE_JW_WAVES       // A/B knob: minimum waves per SIMD of the JW instances (register cap 512 / waves)
+#define EGS_PRE_JW_WAVES 1
+#endif
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (JW ? EGS_PRE_JW_WAVES : 8), 8))) void k_preprocess_fwd(int n, PreParams pp, const float* __restrict__ pws,
                                                         const float* __restrict__ rots,
                                                         const float* __restrict__ scales,
                                                         const float* __restrict__ shs,
@@ -528,6 +531,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAW || JW)
   }
   float4 r[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   float jw[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  uint4 crec = make_uint4(0u, 0u, 0u, 0u);
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
     float col[3];
@@ -559,13 +563,32 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAW || JW)
         radius_f(c2.c, pp.radius_mode, rx, ry);
       }
     }
-    if (bo.rc) {  // getRects + depth key of the binning stage, straight from registers (no k_bin_count pass)
+    const float alpha_act = (rec || bo.br) ? (RAW ? act_alpha(alphas[i]) : alphas[i]) : 0.f;
+    if (bo.br) {  // getRects + depth key of the binning stage, straight from registers (no k_bin_count pass)
       uint4 rect;
       bool cull;
       const uint32_t cnt = bin_count_one(bp, u0, u1, (float)rx, (float)ry, depth, rect, dkey, cull);
       if (cull) { depth = EGS_BAD_MARKER; rx = 0; ry = 0; }  // in-place contract of splat (kernel.cu:114-119)
       bo.ids[i] = (uint32_t)i;
-      bo.rc[i] = cnt ? pack_rect(rect.x, rect.y, rect.z, rect.w) : make_uint2(0u, 0u);
+      // the footprint record of the binning stage and the number of tiles the Gaussian is emitted for: its rect
+      // (the reference's lists) or, bp.cull_lists, the tiles its footprint alpha' >= alpha_skip can reach
+      const BinRec brec = make_binrec(u0, u1, ci[0], ci[1], ci[2], alpha_act, pp.alpha_skip, bp.cull_lists != 0,
+                                      rect, cnt);
+      if (cnt) {
+        const uint32_t w = brec.wh & 0xFFFFu, h = brec.wh >> 16;
+        if (w <= 4u && h <= 4u) {          // the blocks the footprint reaches, as a bitmap: emission is bit arithmetic
+          const unsigned long long bits = foot_bitmap(brec);
+          crec = make_uint4(brec.xy, brec.wh, (uint32_t)bits, (uint32_t)(bits >> 32));
+        } else {                           // a big rect: counted here, walked row by row by k_bin_emit
+          const bool walk = brec.m < __int_as_float(0x7f800000);
+          crec = make_uint4(brec.xy, brec.wh | EGS_CR_BIG, walk ? foot_count(brec) : cnt, walk ? 1u : 0u);
+          if (walk) {
+            float4* o = reinterpret_cast<float4*>(bo.br + i);
+            o[0] = make_float4(brec.ux, brec.uy, brec.A, brec.Bh);
+            o[1] = make_float4(brec.C, brec.m, __uint_as_float(brec.xy), __uint_as_float(brec.wh));
+          }
+        }
+      }
       bo.dkeys[i] = dkey;
     }
     // us / cinv2ds / colors / areas are only needed by callers that go on with the seven-op surface; the
@@ -577,12 +600,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((RAW || JW)
     if (areas) { areas[2 * (size_t)i] = rx; areas[2 * (size_t)i + 1] = ry; }
     // the packed 2D record of the draw kernels, straight from registers (no k_pack_records pass)
     if (rec)
-      make_record(u0, u1, ci[0], ci[1], ci[2], RAW ? act_alpha(alphas[i]) : alphas[i], col[0], col[1], col[2], rx, ry,
+      make_record(u0, u1, ci[0], ci[1], ci[2], alpha_act, col[0], col[1], col[2], rx, ry,
                   pp.W, pp.H, pp.footprint, pp.alpha_skip, r);
   }
-  if (bo.rc) {
+  if (bo.br) {
     __syncthreads();   // (RAW: every wave is done with the rows staged in)
     block_max_key(dkey, bo.maxkey, reinterpret_cast<uint32_t*>(stage));
+    if (i < n) bo.cr[i] = crec;     // (16 B per lane, consecutive lanes: full lines)
   }
   // 48-B records leave as full lines (lane-strided 16-B pieces cost 3x the write requests)
   if (rec) stage_rows_out<12>(reinterpret_cast<const float*>(r), reinterpret_cast<float*>(rec), n, blockIdx.x * 256, stage);
@@ -853,9 +877,10 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
                               const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
                               int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds,
                               float* colors, int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws,
-                              int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                              uint32_t* host_totals, void* stream) {
+                              int cull_lists, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                              uint32_t* total_patches, uint32_t* host_totals, void* stream) {
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && total_patches);
+  EGS_CHECK_ARG(!cull_lists || (rec && n < (1 << EGS_GSID_BITS)));   // culled lists are drawn from the records only
   EGS_CHECK_ARG(((uintptr_t)dcolor_dpws & 15) == 0);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
@@ -877,7 +902,7 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
     set_error(EGS_ERR_WORKSPACE, "bin workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
-  const BinParams bp = make_bin_params(width, height, pol);
+  const BinParams bp = make_bin_params(width, height, pol, cull_lists != 0);
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
   dim3 g(div_up(n, 256)), b(256);
 #define EGS_PRE(NC, RAW)                                                                                        \
@@ -911,12 +936,12 @@ extern "C" int egs_fused_forward(int n, int sh_dim, const float* pws, const floa
                                  const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                                  const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                                  const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                                 int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws, int key_bits_hint,
-                                 void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals,
-                                 void* stream) {
+                                 int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws, int cull_lists,
+                                 int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                                 uint32_t* host_totals, void* stream) {
   return fused_forward_impl(false, n, sh_dim, pws, rots, scales, shs, nullptr, alphas, Rcw, tcw, twc, fx, fy, cx, cy,
                             width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible, dcolor_dpws,
-                            key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
+                            cull_lists, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
 }
 
 extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots_raw,
@@ -925,12 +950,13 @@ extern "C" int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const 
                                      float fx, float fy, float cx, float cy, int width, int height,
                                      const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
                                      int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws,
-                                     int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                                     uint32_t* host_totals, void* stream) {
+                                     int cull_lists, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                                     uint32_t* total_patches, uint32_t* host_totals, void* stream) {
   EGS_CHECK_ARG(n == 0 || (rec && alphas_raw));  // the activated alpha only exists inside the records
   return fused_forward_impl(true, n, sh_dim, pws, rots_raw, scales_raw, low_shs, high_shs, alphas_raw, Rcw, tcw, twc,
                             fx, fy, cx, cy, width, height, pol, us, depths, cinv2ds, colors, areas, rec, visible,
-                            dcolor_dpws, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals, stream);
+                            dcolor_dpws, cull_lists, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, host_totals,
+                            stream);
 }
 
 extern "C" size_t egs_fused_backward_ws_bytes(int n) { return egs_splat_bwd_ws_bytes(n); }
@@ -952,7 +978,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && patches >= 0);
   const bool keep_order = (phase & EGS_BWD_KEEP_FORWARD_ORDER) != 0;
-  phase &= ~EGS_BWD_KEEP_FORWARD_ORDER;
+  const bool masked = (phase & EGS_BWD_CULLED_LISTS) != 0;
+  phase &= ~(EGS_BWD_KEEP_FORWARD_ORDER | EGS_BWD_CULLED_LISTS);
   EGS_CHECK_ARG(phase >= 0 && phase <= 2);
   if (phase != 2) { row_begin = 0; row_count = n; }
   EGS_CHECK_ARG(row_begin >= 0 && row_count >= 0 && row_begin + (int64_t)row_count <= n && row_begin % 256 == 0);
@@ -970,7 +997,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   if (phase != 2) {
     int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
                               patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec,
-                              tile_order, grad_records, keep_order);
+                              tile_order, grad_records, keep_order, masked);
     if (rc) return rc;
     if (phase == 1) return 0;
   }

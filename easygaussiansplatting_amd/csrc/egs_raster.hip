@@ -33,6 +33,15 @@
 #ifndef EGS_TILE_ORDER_B_DEFAULT
 #define EGS_TILE_ORDER_B_DEFAULT 1
 #endif
+// getRanges folded into the last scatter pass of the tile sort (one thread per digit run, atomicMin / Max at the run
+// ends): built, bit-identical, and measured 5 us SLOWER per step than the separate 8-us k_tile_ranges pass in three
+// same-box A/B pairs (0.9226 vs 0.9278 ms) -- the scatter kernel is latency-bound and pays for the extra tail.  Off.
+#ifndef EGS_RANGES_FOLD
+#define EGS_RANGES_FOLD 0
+#endif
+#ifndef EGS_DRAW_LDS3          // A/B knob: 1 = the staged entry as three b128 pieces for every policy (round 2)
+#define EGS_DRAW_LDS3 0
+#endif
 
 namespace egs {
 
@@ -125,10 +134,19 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
     int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
     const uint32_t* __restrict__ maxkey, const uint32_t* __restrict__ n_dev,
-    const uint2* __restrict__ gsrc, uint2* __restrict__ gdst) {
-  // gsrc != NULL (last pass of the depth sort): the 8-byte record gsrc[value] of every item is gathered into
-  // sorted order on the way out (gdst[pos]) -- the random reads hide behind this kernel's stores instead of
-  // heading the dependent scan kernel that follows
+    const uint4* __restrict__ gsrc, uint4* __restrict__ gdst, uint32_t* __restrict__ cdst,
+    int32_t* __restrict__ ranges_out) {
+  // ranges_out != NULL (last pass of the tile sort): getRanges (reference kernel.cu:125-150) on the way out.  Inside a
+  // digit run of the workgroup's LDS-sorted tile the items are in full-key order (the earlier passes sorted the lower
+  // digits, every pass is stable) and their output positions are consecutive, so a key change inside a run IS a range
+  // boundary: plain stores.  Whether the first / last item of a run starts / ends its key's range depends on the
+  // neighbouring workgroup: those two go through atomicMin / atomicMax (ranges initialised to (INT_MAX, 0) by
+  // k_bin_emit; tiles without patches are put back to (0, 0) by k_draw).  One thread per digit run does this (a run
+  // is almost always ONE tile), nothing per item; no separate pass over the sorted keys (k_tile_ranges: 8 us).
+  // gsrc != NULL (last pass of the depth sort): the 16-byte compact bin record gsrc[value] of every item is gathered
+  // into sorted order on the way out (gdst[pos]) -- the random reads hide behind this kernel's stores instead of
+  // heading the dependent scan kernel that follows -- and its patch count goes to cdst[pos]: the two scan kernels
+  // then stream 4 bytes per Gaussian
   if (n_dev) n = min(n, (int64_t)*n_dev);
   constexpr int RS_TILE = RS_THREADS * RS_IPT;       // items per workgroup
   constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // contiguous items per wave
@@ -142,7 +160,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
         const uint32_t v = vals_in[idx];
         keys_out[idx] = keys_in[idx];
         vals_out[idx] = v;
-        if (gsrc) gdst[idx] = gsrc[v];
+        if (gsrc) { const uint4 c = gsrc[v]; gdst[idx] = c; cdst[idx] = cr_count(c); }
       }
     }
     return;
@@ -209,6 +227,20 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     }
   }
   __syncthreads();
+  if (ranges_out && cnt > 0u) {   // thread `tid` owns the run of digit `tid`: local slots [ds, ds + cnt)
+    const uint32_t k0 = skey[ds], k1 = skey[ds + cnt - 1u];
+    const uint32_t gpos = gbase - ds;          // global position of local slot i of this run: gpos + i
+    atomicMin(&ranges_out[2 * (size_t)k0], (int32_t)(gpos + ds));
+    atomicMax(&ranges_out[2 * (size_t)k1 + 1], (int32_t)(gpos + ds + cnt));
+    if (k0 != k1) {               // several tiles in one run (rare: a run of the last pass is one tile's share of
+      uint32_t kp = k0;           // 4096 consecutive items of the pass before)
+      for (uint32_t i = ds + 1u; i < ds + cnt; ++i) {
+        const uint32_t k = skey[i];
+        if (k != kp) { ranges_out[2 * (size_t)k] = (int32_t)(gpos + i); ranges_out[2 * (size_t)kp + 1] = (int32_t)(gpos + i); }
+        kp = k;
+      }
+    }
+  }
   const int64_t rem = n - blockbase;
   const int nvalid = rem < RS_TILE ? (int)rem : RS_TILE;
 #pragma unroll
@@ -220,7 +252,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
       const uint32_t v = sval[slot];
       keys_out[pos] = k;
       vals_out[pos] = v;
-      if (gsrc) gdst[pos] = gsrc[v];
+      if (gsrc) { const uint4 c = gsrc[v]; gdst[pos] = c; cdst[pos] = cr_count(c); }
     }
   }
 }
@@ -247,7 +279,8 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
                       int begin_bit, int end_bit, const SortWs& w, hipStream_t s,
                       const uint32_t* maxkey = nullptr, const uint32_t* n_dev = nullptr,
                       uint32_t* mk_parts = nullptr, int nparts = 0, uint32_t* mk_out = nullptr,
-                      uint32_t* mk_host = nullptr, const uint2* gsrc = nullptr, uint2* gdst = nullptr) {
+                      uint32_t* mk_host = nullptr, const uint4* gsrc = nullptr, uint4* gdst = nullptr,
+                      uint32_t* cdst = nullptr, int32_t* ranges_out = nullptr) {
   // gsrc/gdst: gdst[j] = gsrc[value of the j-th item of the sorted sequence], written by the last pass
   if (n <= 0) return 0;
   uint32_t *ki = keys, *vi = vals, *ko = keys_alt, *vo = vals_alt;
@@ -261,7 +294,7 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
     const bool first = shift == begin_bit && mk_parts != nullptr;      // this pass produces maxkey[0]
     const uint32_t* mk = first ? nullptr : maxkey;
     const bool last = shift + width >= end_bit;
-    const uint2* gs = last ? gsrc : nullptr;
+    const uint4* gs = last ? gsrc : nullptr;
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
                  w.nblocks, w.hist, mk, n_dev);
@@ -272,10 +305,10 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
                mk, first ? mk_parts : (uint32_t*)nullptr, nparts, mk_out, mk_host);
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
-                 dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst);
+                 dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst, cdst, last ? ranges_out : (int32_t*)nullptr);
     else
       EGS_LAUNCH("k_radix_scatter", k_radix_scatter<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n,
-                 shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst);
+                 shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst, cdst, last ? ranges_out : (int32_t*)nullptr);
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
@@ -364,7 +397,7 @@ static int exclusive_scan(int64_t n, const uint32_t* in, const uint32_t* gather,
 // kernel (egs_preprocess.hip) does the same through bin_count_one and skips this launch
 __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const float* __restrict__ us,
                                                    int32_t* __restrict__ areas, float* __restrict__ depths,
-                                                   uint2* __restrict__ rc,
+                                                   uint4* __restrict__ cr,
                                                    uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
                                                    uint32_t* __restrict__ maxkey) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -380,7 +413,22 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
       areas[2 * (size_t)i + 1] = 0;
     }
     ids[i] = (uint32_t)i;
-    rc[i] = cnt ? pack_rect(rect.x, rect.y, rect.z, rect.w) : make_uint2(0u, 0u);
+    // the seven-op surface returns the reference's lists: every tile of the rect (a full bitmap / an unculled big rect)
+    uint4 c = make_uint4(0u, 0u, 0u, 0u);
+    if (cnt) {
+      const uint32_t w = rect.z - rect.x, h = rect.w - rect.y;
+      c.x = rect.x | (rect.y << 16);
+      c.y = w | (h << 16);
+      if (w <= 4u && h <= 4u) {
+        const unsigned long long row = (1ull << (2 * w)) - 1ull;
+        unsigned long long bits = 0ull;
+        for (uint32_t r = 0; r < 2 * h; ++r) bits |= row << (8 * r);
+        c.z = (uint32_t)bits; c.w = (uint32_t)(bits >> 32);
+      } else {
+        c.y |= EGS_CR_BIG; c.z = cnt; c.w = 0u;
+      }
+    }
+    cr[i] = c;
     dkeys[i] = key;
   }
   __shared__ uint32_t wm[4];
@@ -388,32 +436,23 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
 }
 
 // ---- offsets of the Gaussians' patch runs, in depth order -------------------------------------------------
-// The depth sort moves (key, id) pairs only; what the binning needs of a Gaussian afterwards is its packed
-// rect (8 bytes).  It is gathered ONCE into depth order (rc_sorted) -- by the last scatter pass of the depth
-// sort, next to its stores (k_bin_scan_partials with ids == NULL then streams rc_sorted; with ids it does the
-// gather itself: 18.8 us instead of 7) -- and the scan kernels and k_bin_emit stream contiguous arrays.  (The first version gathered counts[ids[j]] in both scan
-// kernels and rects[ids[j]] in k_bin_emit: three dependent gathers through the sorted ids, 2.6-4x the
-// algorithmic traffic by the PMC counters.)
-__device__ __forceinline__ uint32_t rc_count(uint2 r) { return (r.y & 0xFFFFu) * (r.y >> 16); }
-
-__global__ __launch_bounds__(256) void k_bin_scan_partials(const uint32_t* __restrict__ ids,
-                                                           const uint2* __restrict__ rc, int64_t n,
-                                                           uint2* __restrict__ rc_sorted,
+// The depth sort moves (key, id) pairs only; what the binning needs of a Gaussian afterwards is its footprint record
+// (32 bytes) and its patch count.  Both are gathered ONCE into depth order -- by the last scatter pass of the depth
+// sort, next to its stores -- and the scan kernels (counts) and k_bin_emit (records) stream contiguous arrays.  (The
+// first version gathered counts[ids[j]] in both scan kernels and rects[ids[j]] in k_bin_emit: three dependent
+// gathers through the sorted ids, 2.6-4x the algorithmic traffic by the PMC counters.)
+__global__ __launch_bounds__(256) void k_bin_scan_partials(const uint32_t* __restrict__ cnt_sorted, int64_t n,
                                                            uint32_t* __restrict__ partials) {
   __shared__ uint32_t sm[4];
   const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
   uint32_t s = 0;
-  uint2 r[SC_IPT];
+  if (base + SC_IPT <= n) {
+    const uint4 a = *reinterpret_cast<const uint4*>(cnt_sorted + base), b = *reinterpret_cast<const uint4*>(cnt_sorted + base + 4);
+    s = a.x + a.y + a.z + a.w + b.x + b.y + b.z + b.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < SC_IPT; ++k) {      // all gathers in flight before the first use
-    const int64_t i = base + k;
-    r[k] = (i < n) ? (ids ? rc[ids[i]] : rc_sorted[i]) : make_uint2(0u, 0u);
-  }
-#pragma unroll
-  for (int k = 0; k < SC_IPT; ++k) {
-    const int64_t i = base + k;
-    if (ids && i < n) rc_sorted[i] = r[k];
-    s += rc_count(r[k]);
+    for (int k = 0; k < SC_IPT; ++k)
+      if (base + k < n) s += cnt_sorted[base + k];
   }
   s = wave_inclusive_scan(s);
   if ((threadIdx.x & 63) == 63) sm[threadIdx.x >> 6] = s;
@@ -421,7 +460,7 @@ __global__ __launch_bounds__(256) void k_bin_scan_partials(const uint32_t* __res
   if (threadIdx.x == 0) partials[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 
-__global__ __launch_bounds__(256) void k_bin_scan_apply(const uint2* __restrict__ rc_sorted, int64_t n,
+__global__ __launch_bounds__(256) void k_bin_scan_apply(const uint32_t* __restrict__ cnt_sorted, int64_t n,
                                                         const uint32_t* __restrict__ partials,
                                                         uint32_t* __restrict__ out, uint32_t* __restrict__ total,
                                                         uint32_t* __restrict__ total_host) {
@@ -438,23 +477,34 @@ __global__ __launch_bounds__(256) void k_bin_scan_apply(const uint2* __restrict_
   const int64_t base = (int64_t)blockIdx.x * SC_TILE + (int64_t)threadIdx.x * SC_IPT;
   uint32_t v[SC_IPT];
   uint32_t s = 0;
+  if (base + SC_IPT <= n) {
+    const uint4 a = *reinterpret_cast<const uint4*>(cnt_sorted + base), b = *reinterpret_cast<const uint4*>(cnt_sorted + base + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+  } else {
 #pragma unroll
-  for (int k = 0; k < SC_IPT; ++k) {
-    const int64_t i = base + k;
-    v[k] = (i < n) ? rc_count(rc_sorted[i]) : 0u;
-    s += v[k];
+    for (int k = 0; k < SC_IPT; ++k) v[k] = (base + k < n) ? cnt_sorted[base + k] : 0u;
   }
+#pragma unroll
+  for (int k = 0; k < SC_IPT; ++k) s += v[k];
   uint32_t blocksum;
   uint32_t ex = block256_exclusive_scan(s, sm, &blocksum) + prefix;
   if (total && blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
     *total = prefix + blocksum;
     if (total_host) *total_host = prefix + blocksum;   // the mailbox slot (page-locked host memory), no copy
   }
+  if (base + SC_IPT <= n) {
+    uint4 a, b;
+    a.x = ex; a.y = a.x + v[0]; a.z = a.y + v[1]; a.w = a.z + v[2];
+    b.x = a.w + v[3]; b.y = b.x + v[4]; b.z = b.y + v[5]; b.w = b.z + v[6];
+    *reinterpret_cast<uint4*>(out + base) = a;
+    *reinterpret_cast<uint4*>(out + base + 4) = b;
+  } else {
 #pragma unroll
-  for (int k = 0; k < SC_IPT; ++k) {
-    const int64_t i = base + k;
-    if (i < n) out[i] = ex;
-    ex += v[k];
+    for (int k = 0; k < SC_IPT; ++k) {
+      const int64_t i = base + k;
+      if (i < n) out[i] = ex;
+      ex += v[k];
+    }
   }
 }
 
@@ -464,37 +514,41 @@ __global__ __launch_bounds__(256) void k_bin_scan_apply(const uint2* __restrict_
 // scattered dwords (measured HBM traffic 149 MB for 33 MB of output).  Here the workgroup's 256 Gaussians
 // own ONE contiguous output span (offsets are a prefix sum): output slot s finds its owner by binary
 // search over the 256 offsets in LDS, so all lanes work and consecutive lanes write consecutive addresses.
+// The Gaussian is emitted for the tiles its compact bin record names (egs_common.h): for a rect of at most 4 x 4 tiles
+// slot r of its run is the r-th tile (row-major) with a block set in the record's bitmap -- bit arithmetic; a big
+// cullable rect is walked row by row with its full footprint record (foot_row, the function that COUNTED its tiles in
+// k_preprocess_fwd).  with_masks: the list value carries the tile's 4-bit block mask above the Gaussian index.
 __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t* __restrict__ ids,
                                                   const uint32_t* __restrict__ offsets,
-                                                  const uint2* __restrict__ rc_sorted,
+                                                  const uint4* __restrict__ cr_sorted,
+                                                  const BinRec* __restrict__ br,
                                                   uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid,
-                                                  uint32_t cap, int32_t* __restrict__ ranges, int n_ranges) {
+                                                  uint32_t cap, int32_t* __restrict__ ranges, int n_ranges,
+                                                  int with_masks) {
   __shared__ uint32_t s_off[257];   // offsets relative to the workgroup's first one; [256] = span length
-  __shared__ uint32_t s_g[256], s_xy[256], s_w[256];
+  __shared__ uint32_t s_g[256];
+  __shared__ uint4 s_cr[256];
   const int tid = threadIdx.x;
   const int j = blockIdx.x * 256 + tid;
-  // tiles without patches keep (0, 0): k_tile_ranges, three sorts further down the stream, only writes the
-  // tiles that have some -- zeroed here instead of by a separate 5-us fill in front of this kernel
-  for (int i = j; i < n_ranges; i += gridDim.x * 256) ranges[i] = 0;
-  uint32_t off = 0, cnt = 0, g = 0, xy = 0, w = 1;
+  // (INT_MAX, 0) = "no patches yet": the last scatter pass of the tile sort lowers / raises them (getRanges folded in)
+  for (int i = j; i < n_ranges; i += gridDim.x * 256) ranges[i] = ((i & 1) || !EGS_RANGES_FOLD) ? 0 : 0x7fffffff;
+  uint32_t off = 0, g = 0;
+  uint4 c = make_uint4(0u, 0u, 0u, 0u);
   if (j < n) {
     g = ids[j];
-    const uint2 r = rc_sorted[j];
+    c = cr_sorted[j];
     off = offsets[j];
-    cnt = rc_count(r);
-    if (cnt) { xy = r.x; w = r.y & 0xFFFFu; }
   }
   // first offset of the workgroup (thread 0 always has a valid j) and the span length
   __shared__ uint32_t s_first, s_last;
   if (tid == 0) s_first = off;
   const int last = min(255, n - 1 - blockIdx.x * 256);
-  if (tid == last) s_last = off + cnt;
+  if (tid == last) s_last = off + cr_count(c);
   __syncthreads();
   const uint32_t first = s_first;
   s_off[tid] = (j < n) ? off - first : 0xFFFFFFFFu;   // lanes past the end never own a slot
   s_g[tid] = g;
-  s_xy[tid] = xy;
-  s_w[tid] = w;
+  s_cr[tid] = c;
   const uint32_t span = s_last - first;
   __syncthreads();
   for (uint32_t s0 = tid; s0 < span; s0 += 256) {
@@ -504,12 +558,60 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
 #pragma unroll
     for (int step = 128; step >= 1; step >>= 1)
       if (s_off[lo + step] <= s0) lo += step;     // s_off[lo + step] with lo + step <= 255
-    const uint32_t r = s0 - s_off[lo];
-    const uint32_t ww = s_w[lo], xy0 = s_xy[lo];
-    const uint32_t ry = r / ww, rx = r - ry * ww;
+    uint32_t r = s0 - s_off[lo];
+    const uint4 cc = s_cr[lo];
+    const int x0 = (int)(cc.x & 0xFFFFu), y0 = (int)(cc.x >> 16);
+    const int w = (int)(cc.y & 0xFFFFu), h = (int)((cc.y & EGS_CR_WH_MASK) >> 16);
+    uint32_t tile = 0u, mask = 0xFu;
+    if (!(cc.y & EGS_CR_BIG)) {
+      const unsigned long long blocks = ((unsigned long long)cc.w << 32) | cc.z;
+      const unsigned long long tb = cr_tile_bits(blocks);
+      int ty = 0, tx = 0;
+      uint32_t rb = 0u;
+      bool found = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                 // the tile row that holds the r-th tile
+        const uint32_t bq = (uint32_t)(tb >> (16 * q)) & 0x55u;
+        const uint32_t pc = (uint32_t)__popc(bq);
+        if (!found) {
+          if (r < pc) { rb = bq; ty = q; found = true; }
+          else r -= pc;
+        }
+      }
+      found = false;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                 // the r-th set tile of that row
+        if (((rb >> (2 * q)) & 1u) && !found) {
+          if (r == 0u) { tx = q; found = true; }
+          else --r;
+        }
+      }
+      tile = (uint32_t)(y0 + ty) * (uint32_t)gx + (uint32_t)(x0 + tx);
+      mask = ((uint32_t)(blocks >> (16 * ty + 2 * tx)) & 3u) | (((uint32_t)(blocks >> (16 * ty + 8 + 2 * tx)) & 3u) << 2);
+    } else if (cc.w == 0u) {                        // big rect, not cullable: every tile, every block
+      const uint32_t ry = r / (uint32_t)w, rx = r - ry * (uint32_t)w;
+      tile = (uint32_t)(y0 + (int)ry) * (uint32_t)gx + (uint32_t)x0 + rx;
+    } else {                                        // big cullable rect: walk its rows
+      const BinRec b = br[s_g[lo]];
+      const Foot f = foot_setup(b);
+      mask = 0u;
+      for (int ry = 0; ry < h; ++ry) {
+        SlabPx sa, sb;
+        int tlo, thi;
+        foot_row(f, y0 + ry, sa, sb, tlo, thi);
+        const uint32_t wd = thi >= tlo ? (uint32_t)(thi - tlo + 1) : 0u;
+        if (r < wd) {
+          const int tx = tlo + (int)r;
+          tile = (uint32_t)(y0 + ry) * (uint32_t)gx + (uint32_t)tx;
+          mask = foot_mask(sa, sb, tx);
+          break;
+        }
+        r -= wd;
+      }
+    }
     if (first + s0 >= cap) break;   // (only when the buffers were sized from an earlier call: see egs_splat_draw_rec_dev)
-    tkeys[first + s0] = ((xy0 >> 16) + ry) * (uint32_t)gx + (xy0 & 0xFFFFu) + rx;
-    gsid[first + s0] = s_g[lo];
+    tkeys[first + s0] = tile;
+    gsid[first + s0] = with_masks ? (s_g[lo] | (mask << EGS_GSID_BITS)) : s_g[lo];
   }
 }
 
@@ -731,6 +833,9 @@ struct DrawParams {
   // k_draw only (nullable): per-tile work measure for the backward pass's dispatch order -- how far the tile
   // actually walked its list (early termination makes that 0.6 .. 1.0 of the list length, tile by tile)
   int32_t* work_out;
+  // the list values carry the tile's 4-bit block mask in their high bits (culled lists of the fused path, k_bin_emit):
+  // the kernels take it from there instead of testing the record's certain-miss box per entry
+  int masked;
 };
 
 // Workgroup b runs on XCD b % 8 (observed dispatch order; speed only): give each
@@ -818,7 +923,7 @@ __device__ __forceinline__ float min_hi(float x, float hi) {
 }
 
 template <bool BOX, bool FLOOR, bool CLAMP, bool SKIP>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKIP) ? 8 : 6, 8))) void k_draw(DrawParams p, const int32_t* __restrict__ ranges,
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKIP) ? 8 : 6, 8))) void k_draw(DrawParams p, int32_t* __restrict__ ranges,
                                              const int32_t* __restrict__ gsid,
                                              const float4* __restrict__ rec, float* __restrict__ image,
                                              int32_t* __restrict__ contrib, float* __restrict__ final_tau) {
@@ -843,6 +948,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   if (n <= 0) {  // empty tile: image = 0, contrib = 0 and final_tau = 0 (NOT 1), exactly what the
                  // reference's early return leaves in its zero-filled outputs (kernel.cu:182)
     if (p.work_out && lane == 0) p.work_out[tile] = 0;
+    // a tile without patches still holds the (INT_MAX, 0) the binning initialised it with: (0, 0), as the reference
+    if (lane == 0 && (r0 != 0 || r1 != 0)) { ranges[2 * (size_t)tile] = 0; ranges[2 * (size_t)tile + 1] = 0; }
     const size_t HW0 = (size_t)p.W * p.H;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -896,13 +1003,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   for (int base = 0; base < n && live != 0; base += 64) {
     __syncthreads();  // single-wave workgroup: orders the LDS reads of the previous chunk
     int mymask = 0;   // reach mask of the entry THIS lane staged (lane j <-> entry base + j)
-    const int g = gnext;
+    const int gm = gnext;
+    const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
     if (base + 64 + lane < n) gnext = gsid[r0 + base + 64 + lane];
     if (base + lane < n) {
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
       // the record's thr = log2(skip / alpha), +inf for an entry that never blends (alpha < skip, or
       // alpha < 0 when there is no skip test): such an entry reaches nothing
-      if (C.w < INFINITY) mymask = reach_mask<BOX>(A, C, tx0, ty0);
+      if (C.w < INFINITY) mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<BOX>(A, C, tx0, ty0);
       // alpha' = exp2(e), e = log2(alpha) + log2 exp(-maha/2) (F.5.1, common.cuh:85-88, pre-scaled conic):
       // no multiply by alpha; the floor (maha >= 0) and the 0.99 clamp are ONE min against `cap`
       const float la = SKIP ? lskip - C.w : __builtin_amdgcn_logf(B.y);
@@ -913,7 +1021,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
       const float c0 = la + (A.z * Dx * Dx + A.w * Dx * Dy + B.x * Dy * Dy);
       const float c1 = 2.f * A.z * Dx + A.w * Dy, c2 = 2.f * B.x * Dy + A.w * Dx;
       sA[lane] = make_float4(A.z, A.w, B.x, cap);   // qxx, qxy, qyy, cap
-      if constexpr (BOX) {
+      if constexpr (BOX || EGS_DRAW_LDS3) {
         sB[lane] = make_float4(c0, c1, c2, C.y);      // polynomial about the tile centre; x pixel box
         sC[lane] = make_float4(B.z, B.w, C.x, C.z);   // colour; y pixel box
       } else {
@@ -946,7 +1054,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
 #else
         const float4 Q = sA[j], P = sB[j];            // wave-uniform address: LDS broadcast
         float4 K;
-        if constexpr (BOX) K = sC[j];
+        if constexpr (BOX || EGS_DRAW_LDS3) K = sC[j];
         else { const float2 gb = *reinterpret_cast<const float2*>(&sC[j]); K = make_float4(P.w, gb.x, gb.y, 0.f); }
 #endif
 #ifdef EGS_DRAW_DUMMY_SALU   // issue-limit probe (tools/lab_issue_probe.sh): N extra scalar instructions per entry
@@ -1208,11 +1316,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     __syncthreads();
     const int idx = c * 64 + lane;
     int mymask = 0;  // reach mask of the entry THIS lane staged (lane j <-> entry c*64 + j)
-    const int g = gnext;
+    const int gm = gnext;
+    const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
     if (c > 0) gnext = gsid[r0 + idx - 64];
     if (idx < n) {
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
-      mymask = reach_mask<BOX>(A, C, tx0, ty0);
+      mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<BOX>(A, C, tx0, ty0);
       sA[lane] = A;
       sB[lane] = B;
       sC[lane] = C;
@@ -1388,20 +1497,24 @@ __global__ __launch_bounds__(256) void k_unpack_grads(int n, const float4* __res
 // host orchestration
 // ============================================================================
 struct BinLayout {
-  uint2 *rc, *rc_sorted;   // packed rects in Gaussian order / in depth order
+  uint4 *cr, *cr_sorted;         // compact bin records in Gaussian order / in depth order
+  uint32_t* cnt_sorted;          // patch counts in depth order (written next to cr_sorted)
+  BinRec* br;                    // full footprint records (Gaussian order; written for big cullable rects only)
   uint32_t *dkeys, *dkeys_alt, *ids, *ids_alt, *offsets, *scan_partials, *maxkey;
   SortWs sort;
 };
 static size_t bin_ws_bytes(int n) {
   const size_t N = (size_t)(n > 0 ? n : 1);
-  return 2 * align_up(N * 8, 256) + 5 * align_up(N * 4, 256) + scan_ws_bytes(n) + sort_ws_bytes(n) +
-         align_up((64 + N / 256 + 1) * 4, 256) + 4096;
+  return 2 * align_up(N * 16, 256) + align_up(N * 32, 256) + 6 * align_up(N * 4, 256) + scan_ws_bytes(n) +
+         sort_ws_bytes(n) + align_up((64 + N / 256 + 1) * 4, 256) + 4096;
 }
 static bool bin_carve(void* ws, size_t bytes, int n, BinLayout* L) {
   Carver cv(ws, bytes);
   const size_t N = (size_t)(n > 0 ? n : 1);
-  L->rc = cv.take<uint2>(N);
-  L->rc_sorted = cv.take<uint2>(N);
+  L->cr = cv.take<uint4>(N);
+  L->cr_sorted = cv.take<uint4>(N);
+  L->br = cv.take<BinRec>(N);
+  L->cnt_sorted = cv.take<uint32_t>(N);
   L->dkeys = cv.take<uint32_t>(N);
   L->dkeys_alt = cv.take<uint32_t>(N);
   L->ids = cv.take<uint32_t>(N);
@@ -1460,6 +1573,7 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
   p.zero_n4 = 0;
   p.zero_per = 0;
   p.work_out = nullptr;
+  p.masked = 0;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
@@ -1576,26 +1690,28 @@ static int splat_bin_impl(int n, int width, int height, const float* us, int32_t
     return EGS_ERR_WORKSPACE;
   }
   const BinParams p = make_bin_params(width, height, pol);
-  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.rc,
+  EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.cr,
              L.dkeys, L.ids, L.maxkey);
   EGS_LAUNCH_OK();
   return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, host_totals);
 }
 
 namespace egs {
-BinParams make_bin_params(int width, int height, const EgsPolicy* pol) {
+BinParams make_bin_params(int width, int height, const EgsPolicy* pol, bool cull_lists) {
   BinParams p;
   p.W = width; p.H = height;
   p.gx = div_up(width, EGS_TILE); p.gy = div_up(height, EGS_TILE);
   p.footprint = pol->footprint; p.far_cull = pol->far_cull; p.depth_key = pol->depth_key;
   p.mutate = (pol->footprint == 0);
+  // footprint culling needs the skip test it is derived from (kernel.cu:246) and the tile footprint rule
+  p.cull_lists = cull_lists && pol->footprint == 0 && pol->alpha_skip > 0.f;
   return p;
 }
 
 bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* out) {
   BinLayout L;
   if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) return false;
-  out->rc = L.rc; out->dkeys = L.dkeys; out->ids = L.ids; out->maxkey = L.maxkey;
+  out->cr = L.cr; out->br = L.br; out->dkeys = L.dkeys; out->ids = L.ids; out->maxkey = L.maxkey;
   return true;
 }
 
@@ -1615,16 +1731,17 @@ int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_
   // (the largest depth key -- total_patches[1], and the mailbox slot's second word -- comes out of the first
   // pass's rowscan kernel)
   int rc = radix_sort(n, L.dkeys, L.ids, L.dkeys_alt, L.ids_alt, 0, end_bit, L.sort, s, L.maxkey, nullptr, L.maxkey,
-                      div_up(n, 256), total_patches + 1, host_totals ? host_totals + 1 : nullptr, L.rc, L.rc_sorted);
+                      div_up(n, 256), total_patches + 1, host_totals ? host_totals + 1 : nullptr, L.cr, L.cr_sorted,
+                      L.cnt_sorted);
   if (rc) return rc;
   if (sort_passes(0, end_bit) & 1) {  // odd pass count: bring the result back to the primary buffers
     EGS_HIP(hipMemcpyAsync(L.dkeys, L.dkeys_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     EGS_HIP(hipMemcpyAsync(L.ids, L.ids_alt, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
   }
   const int nb = div_up(n, SC_TILE);
-  EGS_LAUNCH("k_bin_scan_partials", k_bin_scan_partials, dim3(nb), dim3(256), s, (const uint32_t*)nullptr, L.rc,
-             (int64_t)n, L.rc_sorted, L.scan_partials);
-  EGS_LAUNCH("k_bin_scan_apply", k_bin_scan_apply, dim3(nb), dim3(256), s, L.rc_sorted, (int64_t)n, L.scan_partials,
+  EGS_LAUNCH("k_bin_scan_partials", k_bin_scan_partials, dim3(nb), dim3(256), s, L.cnt_sorted, (int64_t)n,
+             L.scan_partials);
+  EGS_LAUNCH("k_bin_scan_apply", k_bin_scan_apply, dim3(nb), dim3(256), s, L.cnt_sorted, (int64_t)n, L.scan_partials,
              L.offsets, total_patches, host_totals);
   EGS_LAUNCH_OK();
   return 0;
@@ -1638,7 +1755,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
                            void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
                            float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr,
-                           int order_ready = 0) {
+                           int order_ready = 0, int flags = 0) {
+  // flags & EGS_DRAW_CULLED_LISTS: the binning stage counted the footprint-culled tiles (egs_fused_forward with
+  // cull_lists): the lists are emitted with block masks in the high bits of their values and drawn from those
   // order_ready != 0: tile_order already holds a dispatch order (an earlier render through the SAME buffer left
   // it there): it is used as it stands, no k_tile_order launch; the work part is still rewritten by the draw
   // prev_tile_work != NULL (T ints): the work the draw kernel measured per tile the LAST time this camera was
@@ -1652,6 +1771,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   EGS_CHECK_ARG(image && contrib && final_tau && patch_range_per_tile);
   hipStream_t s = (hipStream_t)stream;
   DrawParams dp = make_draw_params(width, height, pol);
+  const bool masked = (flags & EGS_DRAW_CULLED_LISTS) && pol->footprint == 0 && pol->alpha_skip > 0.f;
+  EGS_CHECK_ARG(!masked || n < (1 << EGS_GSID_BITS));
+  dp.masked = masked ? 1 : 0;
   if (grad_records && n > 0 && (patches == 0)) EGS_HIP(hipMemsetAsync(grad_records, 0, (size_t)n * 48, s));
   if (n == 0 || patches == 0) {  // nothing to draw: all outputs are zero
     const size_t hw = (size_t)width * height;
@@ -1688,17 +1810,20 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   uint32_t* k1 = (passes & 1) ? D.tkeys : D.tkeys_alt;
   uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
-  EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.rc_sorted, k0,
-                     v0, (uint32_t)patches, patch_range_per_tile, 2 * dp.T);
+  EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.cr_sorted,
+             B.br, k0, v0, (uint32_t)patches, patch_range_per_tile, 2 * dp.T, dp.masked);
   const float4* rec = rec_in ? rec_in : D.rec;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, D.rec);
   EGS_LAUNCH_OK();
-  int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s, nullptr, patches_dev);
+  int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s, nullptr, patches_dev, nullptr, 0, nullptr, nullptr,
+                      nullptr, nullptr, nullptr,   // (its last pass also writes the tile ranges)
+                      EGS_RANGES_FOLD ? patch_range_per_tile : (int32_t*)nullptr);
   if (rc) return rc;
-  EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
-                     patch_range_per_tile, patches_dev);
+  if (!EGS_RANGES_FOLD)
+    EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
+               patch_range_per_tile, patches_dev);
   if (order_ready && tile_order && tile_order_mode(0) > 0 && dp.T <= TILE_ORDER_MAX_T) {
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(0) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
@@ -1768,13 +1893,13 @@ extern "C" int egs_splat_draw_rec(int n, int64_t patches, int width, int height,
                                   const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                   float* image, int32_t* contrib, float* final_tau,
                                   int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                  float* grad_records, const int32_t* prev_tile_work, int order_ready,
+                                  float* grad_records, const int32_t* prev_tile_work, int order_ready, int flags,
                                   void* stream) {
   EGS_CHECK_ARG(rec || n == 0);
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
                          patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order, grad_records,
-                         prev_tile_work, order_ready);
+                         prev_tile_work, order_ready, flags);
 }
 
 // as egs_splat_draw_rec, enqueued BEFORE the host has read total_patches: patch_capacity sizes
@@ -1785,7 +1910,7 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                                       const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
                                       float* image, int32_t* contrib, float* final_tau,
                                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
-                                      float* grad_records, const int32_t* prev_tile_work, int order_ready,
+                                      float* grad_records, const int32_t* prev_tile_work, int order_ready, int flags,
                                       void* stream) {
   EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
   if (host_totals)
@@ -1793,7 +1918,7 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
   return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
                          patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records,
-                         prev_tile_work, order_ready);
+                         prev_tile_work, order_ready, flags);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]
@@ -1808,7 +1933,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                      float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order,
-                     float* grad_records, bool keep_forward_order) {
+                     float* grad_records, bool keep_forward_order, bool masked_lists) {
   hipStream_t s = (hipStream_t)stream;
   const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
   // [N][12] packed gradient records: the caller's (already zeroed by the forward draw kernel) or a piece of ws
@@ -1821,6 +1946,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   EGS_CHECK_ARG(rec_in || (us && cinv2ds && alphas && colors && (areas || pol->footprint != 1)));
   EGS_CHECK_ARG(rec_in || (us && alphas && colors && (pol->footprint == 0 || areas)));
   DrawParams dp = make_draw_params(width, height, pol, true);
+  dp.masked = (masked_lists && pol->footprint == 0 && pol->alpha_skip > 0.f) ? 1 : 0;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);

@@ -35,6 +35,9 @@ KEEP_FORWARD_ORDER = 16   # include/egs_hip.h EGS_BWD_KEEP_FORWARD_ORDER
 ORDER_REFRESH = max(2, int(os.environ.get("EGS_TILE_ORDER_REFRESH", "4")))   # renders of a camera between order refreshes
 TILE_WORK_CACHE = os.environ.get("EGS_TILE_WORK_CACHE", "1") != "0"  # A/B knob: forward dispatch order by remembered work
 SAVE_DCOLOR = os.environ.get("EGS_SAVE_DCOLOR", "1") != "0"          # A/B knob: forward keeps dcolor/dpw for backward
+CULL_LISTS = os.environ.get("EGS_CULL_LISTS", "1") != "0"            # A/B knob: footprint-culled tile lists
+CULLED_LISTS = 32         # include/egs_hip.h EGS_BWD_CULLED_LISTS
+GSID_MASK = 0x0FFFFFFF    # csrc/egs_common.h EGS_GSID_MASK
 MAILBOX_SLOTS = 64
 
 
@@ -42,13 +45,24 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "order", "order_by_work", "gpack", "dcw", "width", "height", "ticket", "_patches", "_keep")
+                 "order", "order_by_work", "gpack", "dcw", "culled", "width", "height", "ticket", "_patches", "_keep")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
         if self.ticket is not None:
             _settle(self.ticket, True)
         return self._patches
+
+    def gaussian_ids(self):
+        """The tile lists as Gaussian indices, int32[P].  With footprint-culled lists (``culled``) the raw ``gsid``
+        values carry the tile's 4-bit block mask above the low 28 bits; this strips it."""
+        g = self.gsid[:self.patch_count()]
+        return (g & GSID_MASK) if self.culled else g
+
+    def block_masks(self):
+        """The 4-bit mask of 8x8 pixel blocks per list entry (bit k = block (k & 1, k >> 1)); 15 for unculled lists."""
+        g = self.gsid[:self.patch_count()]
+        return ((g >> 28) & 15) if self.culled else torch.full_like(g, 15)
 
 
 class _Ticket:
@@ -238,6 +252,11 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     # the draw kernels (forward and backward) work from the packed records alone: us / cinv2ds / colors /
     # areas are not materialised
     S.us = S.cinv2ds = S.colors = S.areas = None
+    # Footprint-culled lists: a Gaussian is listed only for the tiles of its rect that {alpha' >= alpha_skip} can
+    # reach, and every list value carries the tile's block mask (include/egs_hip.h EGS_DRAW_CULLED_LISTS).  The
+    # lists are internal to this path -- the seven-op surface always returns the reference's.
+    pol_ = _pol()
+    S.culled = bool(CULL_LISTS and pol_.footprint == 0 and pol_.alpha_skip > 0 and n < (1 << 28))
     S.depths = torch.empty((n,), dtype=f32, device=dev)
     S.rec = torch.empty((max(n, 1), 12), dtype=f32, device=dev)   # packed 2D records, reused by backward
     mask = torch.empty((n,), dtype=torch.bool, device=dev)        # depths > 0.2, written by the kernel
@@ -246,8 +265,8 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     host_slot = [None]       # mailbox slot the binning kernels also write {P, max key} into (enqueue-ahead path)
     tail = lambda hint, total: (_ptr(alphas), _ptr(Rcw), _ptr(tcw), _ptr(twc), float(cam.fx), float(cam.fy),
                                 float(cam.cx), float(cam.cy), W, H, pol, _ptr(S.us), _ptr(S.depths), _ptr(S.cinv2ds),
-                                _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), _ptr(S.dcw), hint,
-                                _ptr(ws_bin), ws_bin_bytes, _ptr(total), host_slot[0], st)
+                                _ptr(S.colors), _ptr(S.areas), _ptr(S.rec), _ptr(mask), _ptr(S.dcw),
+                                1 if S.culled else 0, hint, _ptr(ws_bin), ws_bin_bytes, _ptr(total), host_slot[0], st)
     image = torch.empty((3, H, W), dtype=f32, device=dev)       # fully written by the draw stage
     S.contrib = torch.empty((H, W), dtype=i32, device=dev)
     S.final_tau = torch.empty((H, W), dtype=f32, device=dev)
@@ -265,7 +284,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                           _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
-                                          order_ready, st))
+                                          order_ready, 1 if S.culled else 0, st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -375,7 +394,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
                                               _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
                                               _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
-                                              _ptr(S.gpack), prev_work, order_ready, st))
+                                              _ptr(S.gpack), prev_work, order_ready, 1 if S.culled else 0, st))
     except BaseException:
         with ctx.lock:            # the slot of a render that never got on its way goes back to the free list
             t.status = _Ticket.FAILED
@@ -464,6 +483,8 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
             b, c, st))
     # the forward pass was dispatched by remembered work: the backward pass keeps its order (no second order kernel)
     keep = KEEP_FORWARD_ORDER if (REUSE_ORDER and getattr(S, "order_by_work", False)) else 0
+    if getattr(S, "culled", False):
+        keep |= CULLED_LISTS          # the list values carry block masks
     hook = _exchange_hook
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups

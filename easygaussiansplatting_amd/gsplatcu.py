@@ -337,7 +337,7 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges),
-                                          _ptr(gsid), _ptr(order), None, None, 0, st))
+                                          _ptr(gsid), _ptr(order), None, None, 0, 0, st))
         return gsid
 
     def render_exact():
@@ -380,7 +380,7 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, width, height, _ptr(rec), pol, _ptr(ws_bin),
                                               _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
                                               _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), _ptr(order), None, None,
-                                              0, st))
+                                              0, 0, st))
     except BaseException:
         with ctx.lock:                       # the slot goes back: nothing will ever fetch it
             t.status = _fused._Ticket.FAILED

@@ -223,8 +223,9 @@ int egs_fused_forward(int n, int sh_dim, const float* pws, const float* rots, co
                       const float* shs, const float* alphas, const float* Rcw, const float* tcw,
                       const float* twc, float fx, float fy, float cx, float cy, int width, int height,
                       const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
-                      int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws /*nullable*/, int key_bits_hint,
-                      void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* stream);
+                      int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws /*nullable*/, int cull_lists,
+                      int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
+                      uint32_t* host_totals, void* stream);
 /* dcolor_dpws (nullable, [N][9] floats, 16-B aligned): dcolor/dpw of every Gaussian (what sh2Color's calc_J hands
  * back as dcolor_dpws, gausplat.cu:298-338), kept for the backward pass: egs_fused_backward given the same pointer
  * never reads the SH coefficients again -- eq (7)'s colour term is the only thing it needs them for, dL/dsh needs
@@ -234,7 +235,7 @@ int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void
                        int32_t* contrib, float* final_tau, int32_t* patch_range_per_tile,
                        int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
                        float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/,
-                       int order_ready, void* stream);
+                       int order_ready, int flags /* EGS_DRAW_CULLED_LISTS or 0 */, void* stream);
 /* prev_tile_work (nullable, T ints): the work part of the tile_order buffer an EARLIER render of the same camera
  * left behind; the forward dispatch order then sorts by it instead of by the list lengths.  Any values are
  * legal (every permutation of the tiles gives the same image), good ones balance the launch.  It may be the work
@@ -261,7 +262,7 @@ int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_
                            void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                            int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
                            float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/,
-                           int order_ready, void* stream);
+                           int order_ready, int flags, void* stream);
 /* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
  * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
 int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
@@ -286,6 +287,15 @@ size_t egs_fused_backward_ws_bytes(int n);
  * (prev_tile_work != NULL), so the backward pass keeps that order instead of sorting the tiles again by the
  * work this render measured (one k_tile_order launch, 8 us, less; without the flag it sorts). */
 #define EGS_BWD_KEEP_FORWARD_ORDER 16
+/* OR-ed into `phase` / passed as `flags` of egs_splat_draw_rec*: the lists are the FOOTPRINT-CULLED ones of
+ * egs_fused_forward(cull_lists = 1).  A Gaussian is then listed only for the tiles of its rect (getRects,
+ * kernel.cu:82-122) that its footprint {alpha' >= alpha_skip} can reach -- the tiles left out are tiles in which the
+ * reference `continue`s on every pixel (kernel.cu:246), so images and gradients are unchanged, but list positions
+ * (and with them `contrib`) refer to the culled lists -- and every list value carries, above the low 28 bits of the
+ * Gaussian index, the 4-bit mask of the 8x8 pixel blocks of the tile the footprint reaches.  Internal to the fused
+ * path: the seven-op surface (egs_splat_bin / egs_splat_draw) always produces the reference's lists. */
+#define EGS_BWD_CULLED_LISTS 32
+#define EGS_DRAW_CULLED_LISTS 1
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
  * phase 2: only the per-Gaussian chain rule for rows [row_begin, row_begin + row_count), row_begin a multiple
  * of 256, reading the records phase 1 left in the SAME ws: a data-parallel caller launches the rows in a few
@@ -314,8 +324,8 @@ int egs_fused_forward_raw(int n, int sh_dim, const float* pws, const float* rots
                           const float* tcw, const float* twc, float fx, float fy, float cx, float cy, int width,
                           int height, const EgsPolicy* pol, float* us, float* depths, float* cinv2ds, float* colors,
                           int32_t* areas, void* rec, uint8_t* visible, float* dcolor_dpws /*nullable*/,
-                          int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
-                          uint32_t* host_totals, void* stream);
+                          int cull_lists, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
+                          uint32_t* total_patches, uint32_t* host_totals, void* stream);
 int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
                            const float* rots_raw, const float* scales_raw, const float* low_shs,
                            const float* high_shs, const float* alphas_raw, const float* Rcw, const float* tcw,

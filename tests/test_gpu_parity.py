@@ -597,6 +597,45 @@ def _oracle_2d(sc, cam, rows=None, calc_J=False):
     return us, ci[0], col[0], depths, J
 
 
+def check_culled_lists(st, tiles, us, cinv2ds, alphas, depths32, rects, width, skip=0.002):
+    """The fused path's tile lists are FOOTPRINT-CULLED (include/egs_hip.h EGS_DRAW_CULLED_LISTS): for every tile in
+    ``tiles`` the device list must be the reference's list -- all Gaussians whose rect (getRects, kernel.cu:82-122)
+    covers the tile, in (depth key, index) order -- minus ONLY entries that blend into no pixel of the tile
+    (alpha' < alpha_skip everywhere: the reference ``continue``s, kernel.cu:246), and every block mask must cover the
+    8x8 blocks in which some pixel passes that test.  us / cinv2ds / alphas: the oracle's float64 2D Gaussians;
+    rects [N,4] tiles (x0, y0, x1, y1); depths32: the device's depths (their mm keys order the lists)."""
+    rg = host(st.ranges)
+    ids = host(st.gaussian_ids()); masks = host(st.block_masks())
+    gx = (width + 15) // 16
+    keys = O.depth_keys(depths32, O.POLICY_G).astype(np.int64)
+    dropped = kept = blocks_dev = blocks_true = 0
+    for t in tiles:
+        ty, tx = divmod(int(t), gx)
+        cover = np.nonzero((rects[:, 0] <= tx) & (tx < rects[:, 2]) & (rects[:, 1] <= ty) & (ty < rects[:, 3]))[0]
+        ref = cover[np.lexsort((cover, keys[cover]))]                  # the reference's list of this tile
+        dev_ids = ids[rg[t, 0]:rg[t, 1]]; dev_m = masks[rg[t, 0]:rg[t, 1]]
+        pos = {int(g): i for i, g in enumerate(ref)}
+        where = np.array([pos.get(int(g), -1) for g in dev_ids], np.int64)
+        assert (where >= 0).all(), "a listed Gaussian's rect does not cover tile %d" % t
+        assert (np.diff(where) > 0).all(), "tile %d: not a subsequence of the reference's list" % t
+        py, px = np.meshgrid(ty * 16 + np.arange(16.0), tx * 16 + np.arange(16.0), indexing="ij")
+        dx = us[ref, 0][:, None, None] - px; dy = us[ref, 1][:, None, None] - py
+        maha = (cinv2ds[ref, 0][:, None, None] * dx * dx + cinv2ds[ref, 2][:, None, None] * dy * dy
+                + 2 * cinv2ds[ref, 1][:, None, None] * dx * dy)
+        ap = alphas[ref][:, None, None] * np.exp(-0.5 * np.maximum(maha, 0))
+        hit = ap >= skip * (1 + 1e-3)                                   # clearly above the threshold (fp32 device maths)
+        true_m = np.zeros(ref.size, np.int64)
+        for k in range(4):
+            blk = hit[:, 8 * (k >> 1):8 * (k >> 1) + 8, 8 * (k & 1):8 * (k & 1) + 8].any((1, 2))
+            true_m |= blk.astype(np.int64) << k
+        listed = np.zeros(ref.size, bool); listed[where] = True
+        assert not (true_m[~listed] != 0).any(), "tile %d: a contributing entry was culled" % t
+        assert not (true_m[where] & ~dev_m.astype(np.int64)).any(), "tile %d: a block mask misses a contributing block" % t
+        dropped += int((~listed).sum()); kept += int(listed.sum())
+        blocks_dev += int(sum(bin(int(m)).count("1") for m in dev_m)); blocks_true += int(sum(bin(int(m)).count("1") for m in true_m))
+    return dropped, kept, blocks_dev, blocks_true
+
+
 def test_full_size_fused_and_raw_paths(gsc, big):
     """BASELINE configs[1]/[2] on the path bench.py times: ``GSFunction`` in mode "fused" (k_preprocess_fwd,
     record-only draw, k_draw_bwd, k_preprocess_bwd) at 1 M Gaussians / 1920x1080 against the float64 oracle --
@@ -616,9 +655,11 @@ def test_full_size_fused_and_raw_paths(gsc, big):
     for p in P.values():
         p.requires_grad_(True)
     dl = S.normal(8, 1, (3, H, W)).astype(np.float32) / (H * W)
+    # the state (tile lists) of the same render: need_grad=True runs the very kernel instance GSFunction.forward runs
+    # (the one that also keeps dcolor/dpw for the backward pass), so the two renders are bit-identical
     img_t, mask_t, st = fused.forward(P["pws"].detach(), P["shs"].detach(), P["alphas"].detach(), P["scales"].detach(),
-                                      P["rots"].detach(), cam)       # the state (tile lists) of the same render
-    rg, gs = host(st.ranges), host(st.gsid)
+                                      P["rots"].detach(), cam, need_grad=True)
+    rg, gs = host(st.ranges), host(st.gaussian_ids())
     hcont, htau = host(st.contrib), host(st.final_tau)
     us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
     image, mask = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
@@ -631,9 +672,15 @@ def test_full_size_fused_and_raw_paths(gsc, big):
     # the mask is depths > 0.2 AFTER getRects marked the Gaussians without a tile (kernel.cu:114-119, gsmodel.py:50);
     # float32 (device) vs float64 (oracle) centres may disagree on a Gaussian that just touches the image border
     d_marked = o_depths.astype(np.float32).copy()
-    O.get_rects(o_us.astype(np.float32), o_areas.copy(), d_marked, W, H, O.POLICY_G)
+    o_rects, _ = O.get_rects(o_us.astype(np.float32), o_areas.copy(), d_marked, W, H, O.POLICY_G)
     hmask = host(mask)
     assert (hmask != (d_marked > 0.2)).sum() <= 4 and 0 < (~hmask).sum() < sc.n // 2
+    # the lists of this path are footprint-culled: subsets of the reference's, nothing that blends is missing
+    assert st.culled
+    dropped, kept, bdev, btrue = check_culled_lists(st, sel[:8], o_us, o_ci, sc.alphas.astype(np.float64),
+                                                    host(st.depths), o_rects.astype(np.int64), W)
+    assert kept > 1000 and 0.03 < dropped / (dropped + kept) < 0.3, (dropped, kept)
+    assert btrue <= bdev <= 1.35 * btrue, (bdev, btrue)                 # masks are tight, not just safe
     alphas64 = sc.alphas.astype(np.float64)
     o_img, o_cont, o_tau = O.draw(W, H, rg, gs, o_us, o_ci, alphas64, o_col, None, O.POLICY_G, tiles=sel)
     gx = (W + 15) // 16

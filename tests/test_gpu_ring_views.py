@@ -22,7 +22,7 @@ import pytest
 
 from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
-from tests.test_gpu_parity import _oracle_2d, close, dev, host
+from tests.test_gpu_parity import _oracle_2d, check_culled_lists, close, dev, host
 
 pytestmark = pytest.mark.gpu
 
@@ -76,9 +76,11 @@ def test_eight_ring_views_full_size():
     for v in range(N_VIEWS):
         cam, cnp = cams[v], cams_np[v]
         with torch.no_grad():
-            img_t, mask_t, st = fused.forward(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam)
+            # (need_grad=True: the kernel instance GSFunction.forward runs -- bit-identical renders)
+            img_t, mask_t, st = fused.forward(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam,
+                                              need_grad=True)
         npatch = st.patch_count()
-        rg, gs = host(st.ranges), host(st.gsid)[:npatch]
+        rg, gs = host(st.ranges), host(st.gaussian_ids())
         hcont, htau, hdepth = host(st.contrib), host(st.final_tau), host(st.depths)
         # ---- invariants of the tile lists (size-independent properties)
         lens = rg[:, 1] - rg[:, 0]
@@ -92,11 +94,13 @@ def test_eight_ring_views_full_size():
         assert (np.diff(comp)[inner[1:]] > 0).all(), "a tile list is not sorted by (depth key, index) in view %d" % v
         o_us, o_ci, o_col, o_depths, o_areas = _oracle_2d(sc, cnp)
         d_marked = o_depths.astype(np.float32).copy()
-        _, counts = O.get_rects(o_us.astype(np.float32), o_areas.copy(), d_marked, W, H, O.POLICY_G)
+        o_rects, counts = O.get_rects(o_us.astype(np.float32), o_areas.copy(), d_marked, W, H, O.POLICY_G)
         allp = np.bincount(gs, minlength=sc.n)
-        # float32 (device) vs float64 (oracle) centres/radii may disagree on a Gaussian whose rect edge sits on a
-        # tile border: counted, a handful out of a million
-        assert (allp != counts).sum() <= 300, (v, (allp != counts).sum())
+        # The lists are footprint-culled: a Gaussian appears for at most the tiles of its rect.  (float32 (device) vs
+        # float64 (oracle) centres / radii may disagree on a rect whose edge sits on a tile border: a handful in a
+        # million may exceed the oracle's count.)
+        assert st.culled and (allp > counts).sum() <= 300, (v, (allp > counts).sum())
+        assert 0.80 * counts.sum() < npatch < 0.95 * counts.sum(), (v, npatch, counts.sum())
         hmask = host(mask_t)
         assert (hmask != (d_marked > 0.2)).sum() <= 16
         stats.append((npatch, int(lens.max()), int((~hmask).sum()), int(keys.max()).bit_length()))
@@ -107,6 +111,9 @@ def test_eight_ring_views_full_size():
         him = host(image)
         sel = (S.uniform01(40 + v, 2, (8,)) * T).astype(np.int64)
         sel = np.array([t for t in sel if lens[t] > 0] or [int(np.argmax(lens))])
+        dropped, kept, bdev, btrue = check_culled_lists(st, sel[:4], o_us, o_ci, alphas64, hdepth,
+                                                        o_rects.astype(np.int64), W)
+        assert dropped > 0 and btrue <= bdev, (v, dropped, kept, bdev, btrue)
         o_img, o_cont, o_tau = O.draw(W, H, rg, gs, o_us, o_ci, alphas64, o_col, None, O.POLICY_G, tiles=sel)
         nflip = 0
         for t in sel:

@@ -24,7 +24,7 @@ gx = (W + 15) // 16
 T = ranges.shape[0]
 lens = ranges[:, 1] - ranges[:, 0]
 tile_of = torch.repeat_interleave(torch.arange(T, device=dev), lens)          # [P]
-g = st.gsid[:P].long()
+g = st.gaussian_ids().long()
 rec = st.rec[g]                                                              # [P, 12]
 ux, uy, qxx, qxy, qyy = rec[:, 0], rec[:, 1], rec[:, 2], rec[:, 3], rec[:, 4]
 e1, e2, thr = rec[:, 9], rec[:, 10], rec[:, 11]
