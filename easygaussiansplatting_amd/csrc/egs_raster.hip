@@ -128,7 +128,10 @@ __global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hi
 // is found with per-wave ballot multi-split (deterministic, no LDS atomics), the tile is written
 // digit-sorted into LDS, and then streamed out so that consecutive lanes write consecutive
 // addresses inside each digit run (coalesced) instead of 64 scattered dwords per instruction.
-template <int RS_IPT>
+// EXTRA (compiled in, so that the plain instance keeps its registers: 4 / 6 resident workgroup-waves per SIMD instead
+// of 3 / 5 with the code below merely present): 1 = gather records on the way out (last pass of the depth sort),
+// 2 = write the tile ranges (last pass of the tile sort, EGS_RANGES_FOLD)
+template <int RS_IPT, int EXTRA>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
@@ -160,7 +163,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
         const uint32_t v = vals_in[idx];
         keys_out[idx] = keys_in[idx];
         vals_out[idx] = v;
-        if (gsrc) { const uint4 c = gsrc[v]; gdst[idx] = c; cdst[idx] = cr_count(c); }
+        if constexpr (EXTRA == 1) { const uint4 c = gsrc[v]; gdst[idx] = c; cdst[idx] = cr_count(c); }
       }
     }
     return;
@@ -227,7 +230,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     }
   }
   __syncthreads();
-  if (ranges_out && cnt > 0u) {   // thread `tid` owns the run of digit `tid`: local slots [ds, ds + cnt)
+  if (EXTRA == 2 && cnt > 0u) {   // thread `tid` owns the run of digit `tid`: local slots [ds, ds + cnt)
     const uint32_t k0 = skey[ds], k1 = skey[ds + cnt - 1u];
     const uint32_t gpos = gbase - ds;          // global position of local slot i of this run: gpos + i
     atomicMin(&ranges_out[2 * (size_t)k0], (int32_t)(gpos + ds));
@@ -252,7 +255,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
       const uint32_t v = sval[slot];
       keys_out[pos] = k;
       vals_out[pos] = v;
-      if (gsrc) { const uint4 c = gsrc[v]; gdst[pos] = c; cdst[pos] = cr_count(c); }
+      if constexpr (EXTRA == 1) { const uint4 c = gsrc[v]; gdst[pos] = c; cdst[pos] = cr_count(c); }
     }
   }
 }
@@ -303,12 +306,16 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
                  w.nblocks, w.hist, mk, n_dev);
     EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals, shift,
                mk, first ? mk_parts : (uint32_t*)nullptr, nparts, mk_out, mk_host);
-    if (rs_ipt(n) == 8)
-      EGS_LAUNCH("k_radix_scatter", k_radix_scatter<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, shift,
-                 dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst, cdst, last ? ranges_out : (int32_t*)nullptr);
-    else
-      EGS_LAUNCH("k_radix_scatter", k_radix_scatter<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n,
-                 shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst, cdst, last ? ranges_out : (int32_t*)nullptr);
+    int32_t* ro = last ? ranges_out : (int32_t*)nullptr;
+#define EGS_SCATTER(IPT, EXTRA)                                                                                     \
+  EGS_LAUNCH("k_radix_scatter", (k_radix_scatter<IPT, EXTRA>), dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, \
+             shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst, cdst, ro)
+    if (rs_ipt(n) == 8) {
+      if (gs) EGS_SCATTER(8, 1); else if (ro) EGS_SCATTER(8, 2); else EGS_SCATTER(8, 0);
+    } else {
+      if (gs) EGS_SCATTER(16, 1); else if (ro) EGS_SCATTER(16, 2); else EGS_SCATTER(16, 0);
+    }
+#undef EGS_SCATTER
     uint32_t* t = ki; ki = ko; ko = t;
     t = vi; vi = vo; vo = t;
   }
