@@ -9,7 +9,7 @@ needs an independent restatement is the one device kernel of this row:
   ``faiss.IndexFlatL2(3).search(pws, 2)`` that read_write_model.py:216-220 clips into the initial scale.
   faiss (pinned only as ``faiss-gpu`` without version in the reference's requirements.txt) is absent
   here; IndexFlatL2 is an exact brute-force index, so the result is defined by the metric itself.
-  Computed in float64, blockwise.
+  Computed in float64, blockwise.  ``faiss_flat_l2_second`` restates the float32 formula faiss evaluates it with.
 """
 import numpy as np
 
@@ -25,6 +25,38 @@ def nn_sqdist(points, block=2048):
             np.maximum(sq[a:a + block, None] + sq[None, :] - 2 * pa @ p.T, 0)
         d[np.arange(pa.shape[0]), np.arange(a, a + pa.shape[0])] = np.inf
         out[a:a + block] = d.min(1)
+    return out
+
+
+def faiss_flat_l2_second(points, block=1024):
+    """The value reference read_write_model.py:219-222 actually reads: column 1 of
+    ``faiss.IndexFlatL2(3).search(pws, 2)`` -- the SECOND smallest squared L2 distance of every row, the query itself
+    included -- in faiss's own float32 arithmetic for more than 20 queries (faiss/utils/distances.cpp,
+    ``exhaustive_L2sqr_blas``, ``distance_compute_blas_threshold`` = 20; unchanged between faiss 1.5 and 1.8):
+
+        norms[i] = sum_k x[i,k]^2              (fvec_norms_L2sqr, float32)
+        ip       = x y^T                        (sgemm, float32)
+        dis[i,j] = norms_x[i] + norms_y[j] - 2 ip[i,j];   if (dis < 0) dis = 0
+
+    faiss is absent from this image and pinned without a version by the reference (requirements.txt: ``faiss-gpu``),
+    so this is a restatement of its PUBLISHED formula, not an output of the library: the summation order inside
+    sgemm is BLAS's own.  tests/test_io_spec_fixtures.py bounds it against the exact metric, tests/test_gpu_io.py
+    bounds the HIP kernel against both."""
+    x = np.ascontiguousarray(points, np.float32)
+    n = x.shape[0]
+    norms = np.zeros(n, np.float32)
+    for k in range(x.shape[1]):
+        norms += x[:, k] * x[:, k]
+    out = np.zeros(n, np.float32)
+    for a in range(0, n, block):
+        xa = x[a:a + block]
+        ip = xa @ x.T                                           # float32 sgemm
+        dis = norms[a:a + block, None] + norms[None, :] - np.float32(2) * ip
+        dis = np.maximum(dis, np.float32(0))
+        if n < 2:
+            out[a:a + block] = np.float32(np.inf)
+        else:
+            out[a:a + block] = np.partition(dis, 1, axis=1)[:, 1]
     return out
 
 

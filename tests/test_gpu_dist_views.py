@@ -60,10 +60,11 @@ def _worker(rank, world, port, q, chunked):
             for p in P.values():
                 p.grad = None
             if chunked:
-                ex = DV.ChunkedExchange(world, chunks=4)
+                ex = DV.ChunkedExchange(world, chunks=chunked)          # the chunk count is a knob: 2, 4, 8
                 with ex.attach():
                     _render(P, cams[rank], dl)
-                assert ex.finish() and ex.used
+                # finish(params) also verifies that every .grad IS the storage that was exchanged
+                assert ex.finish([P[k] for k in ORDER]) and ex.used
                 calls = None
             else:
                 _render(P, cams[rank], dl)
@@ -97,7 +98,7 @@ def _spawn(target, args):
     return sorted(res, key=lambda r: r[0])
 
 
-@pytest.mark.parametrize("chunked", [False, True])
+@pytest.mark.parametrize("chunked", [0, 2, 4, 8])
 def test_two_rank_hip_gradients_equal_one_process_two_view_accumulation(chunked):
     res = _spawn(_worker, (chunked,))
     sc, cams, dl = _setup()

@@ -29,6 +29,25 @@ def test_nn_sqdist_matches_oracle(n):
         assert got[5] == 0 and got[9] == 0
 
 
+def test_nn_sqdist_within_the_bound_of_the_faiss_formula():
+    """read_write_model.py:216-222 reads column 1 of ``faiss.IndexFlatL2.search(pws, 2)``.  faiss evaluates
+    ||x||^2 + ||y||^2 - 2 <x, y> in float32 (restated in oracle/io_oracle.py::faiss_flat_l2_second), whose rounding
+    error scales with the NORMS; the kernel subtracts first.  Both sit inside that bound of the exact metric, and the
+    initial scales (the value clipped to [0.01, 3]) they lead to differ by less than the bound too."""
+    from easygaussiansplatting_amd.knn import nn_sqdist
+    rng = np.random.default_rng(11)
+    for n, spread, offset in ((3000, 2.0, 0.0), (3000, 3.0, 20.0)):
+        p = (rng.standard_normal((n, 3)) * spread + offset).astype(np.float32)
+        got = nn_sqdist(p).cpu().numpy().astype(np.float64)
+        exact = io_oracle.nn_sqdist(p)
+        fa = io_oracle.faiss_flat_l2_second(p).astype(np.float64)
+        norms = (p.astype(np.float64) ** 2).sum(1)
+        bound = 16 * np.finfo(np.float32).eps * (norms + norms.max())
+        assert (np.abs(got - exact) <= 2e-5 * exact + 1e-7).all()              # the kernel: relative to the DISTANCE
+        assert (np.abs(fa - exact) <= bound).all() and (np.abs(fa - got) <= bound + 2e-5 * exact).all()
+        assert np.abs(np.clip(fa, 0.01, 3) - np.clip(got, 0.01, 3)).max() <= bound.max()
+
+
 def test_points_to_gaussians_on_device_matches_reference(tmp_path):
     from easygaussiansplatting_amd import colmap
     g = load_golden("g9_io.npz")
