@@ -514,6 +514,33 @@ def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
     assert not g_f["pws"][:40].any() and not g_f["shs"][:40].any()          # culled Gaussians get zero gradients
 
 
+def test_nan_conic_is_skipped_not_blended(gsc):
+    """Fixture G10 (tests/golden/make_golden_nan.py): Gaussians whose conic holds inf / NaN -- every Mahalanobis term
+    they produce is NaN.  The CUDA extension's ``max(0.0f, NaN) == 0`` makes them blend at min(0.99, alpha)
+    (kernel.cu:243-246); this build skips them in ``splat`` AND ``splatB``: the image is the one of the two finite
+    Gaussians alone, every gradient is finite, the two degenerate Gaussians receive none.  DELIBERATE deviation."""
+    g = load_golden("g10_nan_conic.npz")
+    W, H = int(g["width"]), int(g["height"])
+    gsc.set_policy("gsplatcu")
+    us, ci, al, col = dev(g["us"]), dev(g["cinv2ds"]), dev(g["alphas"]), dev(g["colors"])
+    depths, areas = dev(g["depths"]), dev(g["areas"], np.int32)
+    image, contrib, tau, ranges, gsid = gsc.splat(H, W, us, ci, al, depths, col, areas)
+    assert np.array_equal(host(ranges), g["ranges"]) and np.array_equal(host(gsid), g["gsid"])
+    him = host(image)
+    assert np.isfinite(him).all()
+    assert np.abs(him - g["image_skip"]).max() < 1e-5 and np.array_equal(host(contrib), g["contrib_skip"])
+    assert np.abs(host(tau) - g["tau_skip"]).max() < 1e-5
+    # ... and that IS a deviation from the reference's arithmetic: the CUDA result differs on every pixel of both tiles
+    assert (np.abs(him - g["image_cuda"]).max(0) > 1e-3).mean() > 0.9
+    dl = dev(S.normal(4, 4, (3, H, W)).astype(np.float32))
+    grads = gsc.splatB(H, W, us, ci, al, depths, col, contrib, tau, ranges, gsid, dl)
+    for t in grads:
+        t = host(t).reshape(4, -1)
+        assert np.isfinite(t).all() and not t[1].any() and not t[2].any() and t[0].any() and t[3].any()
+    # the fused path never sees such conics (its 2D Gaussians come from its own preprocess kernel, where a NaN
+    # determinant culls the Gaussian, kernel.cu:300-305)
+
+
 # --------------------------------------------------------------------------- BASELINE size (1 M Gaussians, 1920x1080)
 @pytest.fixture(scope="module")
 def big(gsc):

@@ -243,3 +243,26 @@ def test_g7_gau_loss_and_gradient(tag):
     scale = np.abs(g["grad_" + tag]).max()
     assert np.abs(grad - g["grad_" + tag]).max() < 1e-6 * scale
     assert (grad[:, : g["x_" + tag].shape[1] // 3] != 0).any()          # SSIM part acts where |x-y| = 0
+
+
+def test_g10_nan_conic_semantics():
+    """Fixture G10: a NaN Mahalanobis term is SKIPPED by this build's definition (oracle NAN_MAHA = "skip") where the
+    CUDA extension's max(0.f, NaN) = 0 blends the Gaussian at min(0.99, alpha) (kernel.cu:243-246, NAN_MAHA = "cuda")."""
+    g = load_golden("g10_nan_conic.npz")
+    W, H = int(g["width"]), int(g["height"])
+    try:
+        for mode in ("skip", "cuda"):
+            O.NAN_MAHA = mode
+            with np.errstate(all="ignore"):
+                img, cont, tau, ranges, gsid = O.splat(H, W, g["us"], g["cinv2ds"], g["alphas"].astype(np.float64),
+                                                       g["depths"].copy(), g["colors"], g["areas"].copy(), O.POLICY_G)
+            assert np.abs(img - g["image_" + mode]).max() < 1e-6 and np.array_equal(cont, g["contrib_" + mode])
+    finally:
+        O.NAN_MAHA = "skip"
+    # skip == the two finite Gaussians alone
+    keep = np.array([0, 3])
+    img2 = O.splat(H, W, g["us"][keep], g["cinv2ds"][keep], g["alphas"][keep].astype(np.float64), g["depths"][keep].copy(),
+                   g["colors"][keep], g["areas"][keep].copy(), O.POLICY_G)[0]
+    assert np.abs(img2 - g["image_skip"]).max() < 1e-6
+    # cuda: Gaussian 2 (NaN conic, alpha 0.5, in front of 0 and 3) tints EVERY pixel of both tiles
+    assert (np.abs(g["image_cuda"] - g["image_skip"]).max(0) > 1e-3).all()
