@@ -318,12 +318,21 @@ __device__ __forceinline__ void sh_jac_dpw(const ShDir<NC>& o, const float* sh, 
   }
 }
 
+#ifndef EGS_SH_NT_LOAD
+#define EGS_SH_NT_LOAD 0
+#endif
 template <int K>
 __device__ __forceinline__ void load_sh_row(const float* __restrict__ row, float* sh) {
   if constexpr (K % 4 == 0) {  // 48- or 192-B rows: dwordx4 loads
 #pragma unroll
     for (int j = 0; j < K / 4; ++j) {
+#if EGS_SH_NT_LOAD        // A/B knob: streaming (non-temporal) loads of the SH rows -- measured k_preprocess_fwd 99 -> 172 us,
+                          // k_sh2color 86 -> 132 us: the 12 loads of a lane re-touch its lines and live on the cache hits
+      typedef float f4v_ __attribute__((ext_vector_type(4)));
+      const f4v_ v = __builtin_nontemporal_load(reinterpret_cast<const f4v_*>(row) + j);
+#else
       const float4 v = reinterpret_cast<const float4*>(row)[j];
+#endif
       sh[4 * j] = v.x; sh[4 * j + 1] = v.y; sh[4 * j + 2] = v.z; sh[4 * j + 3] = v.w;
     }
   } else {
