@@ -239,10 +239,13 @@ def main():
         for p in params.values():
             p.grad = None
         us0.grad = None
-        for c in my_cams:       # V views: forward + backward each, autograd accumulates the parameter gradients
-            image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
-                                           params["rots"], us0, c)
-            image.backward(dl)
+        # V views: forward + backward each; from the second view on the chain-rule kernel adds this view's gradients
+        # to the leaves' .grad itself (fused.accumulate_in_kernel) instead of autograd accumulating fresh tensors
+        with (fused_path.accumulate_in_kernel() if (V > 1 and a.mode == "fused") else contextlib.nullcontext()):
+            for c in my_cams:
+                image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
+                                               params["rots"], us0, c)
+                image.backward(dl)
         return image
 
     def step(timing=False):

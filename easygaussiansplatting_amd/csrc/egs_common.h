@@ -108,13 +108,18 @@ static_assert(sizeof(BinRec) == 32, "BinRec is two dwordx4");
 //     8 by + bx relative to the rect's first block (ALL blocks of the rect when the Gaussian is not cullable).  The
 //     Gaussian is emitted for the tiles with a block set, the list value's mask is the tile's four bits: emission is
 //     bit arithmetic, the square roots of the footprint are taken once per Gaussian, in k_preprocess_fwd.
+//   rect of at most 8 x 8 tiles (EGS_CR_TILEMAP, cullable Gaussians only):  b = 64-bit bitmap of the TILES of the rect
+//     the footprint reaches, bit 8 ty + tx; emission finds slot r's tile by bit arithmetic and evaluates the two
+//     8-row slabs of THAT tile with the full footprint record br[gaussian] for its block mask (11 % of the patches of
+//     a ring view of the 1 M scene sit in rects larger than 4 x 4 tiles, 0.3 % of view 0's).
 //   larger rect (EGS_CR_BIG):  b_lo = patch count, b_hi != 0: cullable -- k_bin_emit walks the rows of the rect with
-//     the full footprint record br[gaussian] (rare: 0.3 % of the patches of the 1 M scene's view 0, 11 % of a ring view).
+//     br[gaussian]; b_hi == 0: every tile of the rect.
 #define EGS_CR_BIG 0x80000000u
-#define EGS_CR_WH_MASK 0x7FFFFFFFu
+#define EGS_CR_TILEMAP 0x40000000u
+#define EGS_CR_WH_MASK 0x3FFFFFFFu
 struct BinCountOut {  // where k_bin_count's results live inside the bin workspace
   uint4* cr;                       // compact bin record per Gaussian
-  BinRec* br;                      // footprint record, written for the Gaussians with a BIG cullable rect only
+  BinRec* br;                      // footprint record, written for the cullable Gaussians with a rect larger than 4 x 4 tiles only
   uint32_t *dkeys, *ids, *maxkey;  // maxkey[1 + workgroup] = per-workgroup maximum of the depth keys
 };
 // list values of the culled lists (fused path): Gaussian index in the low 28 bits, in the high 4 the 8x8 pixel blocks

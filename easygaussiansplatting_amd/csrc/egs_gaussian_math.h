@@ -496,6 +496,20 @@ __device__ __forceinline__ unsigned long long foot_bitmap(const BinRec& b) {
   }
   return bits;
 }
+// the 64-bit TILE bitmap of a cullable rect of at most 8 x 8 tiles (bit 8 ty + tx)
+__device__ __forceinline__ unsigned long long foot_tilemap(const BinRec& b) {
+  const int x0 = (int)(b.xy & 0xFFFFu), y0 = (int)(b.xy >> 16), h = (int)(b.wh >> 16);
+  if (b.m < 0.f) return 0ull;
+  const Foot f = foot_setup(b);
+  unsigned long long bits = 0ull;
+  for (int ry = 0; ry < h; ++ry) {
+    SlabPx s0, s1;
+    int lo, hi;
+    foot_row(f, y0 + ry, s0, s1, lo, hi);
+    if (hi >= lo) bits |= (unsigned long long)(((2u << (hi - x0)) - 1u) & ~((1u << (lo - x0)) - 1u)) << (8 * ry);
+  }
+  return bits;
+}
 #pragma clang fp contract(fast)
 // tiles of a <= 4 x 4 rect that have a block set: bit 16 ty + 2 tx
 __device__ __forceinline__ unsigned long long cr_tile_bits(unsigned long long blocks) {
@@ -505,7 +519,8 @@ __device__ __forceinline__ unsigned long long cr_tile_bits(unsigned long long bl
 }
 __device__ __forceinline__ uint32_t cr_count(const uint4& c) {
   if (c.y & EGS_CR_BIG) return c.z;
-  return (uint32_t)__popcll(cr_tile_bits(((unsigned long long)c.w << 32) | c.z));
+  const unsigned long long b = ((unsigned long long)c.w << 32) | c.z;
+  return (uint32_t)__popcll((c.y & EGS_CR_TILEMAP) ? b : cr_tile_bits(b));
 }
 // The footprint record of one Gaussian.  `cull`: the lists may drop tiles the footprint cannot reach (fused path);
 // otherwise, and whenever the conic does not describe an ellipse the bounds above hold for (same rule as the

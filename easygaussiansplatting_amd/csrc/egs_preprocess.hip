@@ -420,8 +420,10 @@ __device__ __forceinline__ void stage_rows_in(const float* __restrict__ src, int
 }
 
 // the inverse: every lane deposits its row, the workgroup stores the span coalesced
+// accum: dst += rows (a read-modify-write of the same coalesced span) instead of dst = rows
 template <int K>
-__device__ __forceinline__ void stage_rows_out(const float* row, float* __restrict__ dst, int n, int base, float* lds) {
+__device__ __forceinline__ void stage_rows_out(const float* row, float* __restrict__ dst, int n, int base, float* lds,
+                                               bool accum = false) {
   using RS = RowStage<K>;
   const int rows = min(256, n - base);
   const int tid = threadIdx.x;
@@ -437,7 +439,11 @@ __device__ __forceinline__ void stage_rows_out(const float* row, float* __restri
     for (int j = 0; j < RS::Q; ++j) {
       const int f = tid + 256 * j;
       const int r = f / RS::Q, c = f - r * RS::Q;
-      if (r < rows) d4[f] = *reinterpret_cast<const float4*>(lds + r * RS::STRIDE + 4 * c);
+      if (r < rows) {
+        float4 v = *reinterpret_cast<const float4*>(lds + r * RS::STRIDE + 4 * c);
+        if (accum) { const float4 o = d4[f]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        d4[f] = v;
+      }
     }
   } else {
 #pragma unroll
@@ -448,7 +454,7 @@ __device__ __forceinline__ void stage_rows_out(const float* row, float* __restri
     for (int j = 0; j < K; ++j) {
       const int f = tid + 256 * j;
       const int r = f / K, c = f - r * K;
-      if (r < rows) d1[f] = lds[r * RS::STRIDE + c];
+      if (r < rows) d1[f] = lds[r * RS::STRIDE + c] + (accum ? d1[f] : 0.f);
     }
   }
 }
@@ -471,7 +477,8 @@ __device__ __forceinline__ void stage_span_in(const float* __restrict__ src, int
 }
 
 template <int K>
-__device__ __forceinline__ void stage_span_out(const float* row, float* __restrict__ dst, int n, int base, float* lds) {
+__device__ __forceinline__ void stage_span_out(const float* row, float* __restrict__ dst, int n, int base, float* lds,
+                                               bool accum = false) {
   const int rows = min(256, n - base);
   const int tid = threadIdx.x;
   __syncthreads();   // everyone is done reading the staged input rows
@@ -480,8 +487,13 @@ __device__ __forceinline__ void stage_span_out(const float* row, float* __restri
   __syncthreads();
   const int total = rows * K, nq = total >> 2;
   float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + (size_t)K * base);
-  for (int f = tid; f < nq; f += 256) d4[f] = reinterpret_cast<const float4*>(lds)[f];
-  for (int f = 4 * nq + tid; f < total; f += 256) dst[(size_t)K * base + f] = lds[f];
+  for (int f = tid; f < nq; f += 256) {
+    float4 v = reinterpret_cast<const float4*>(lds)[f];
+    if (accum) { const float4 o = d4[f]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+    d4[f] = v;
+  }
+  for (int f = 4 * nq + tid; f < total; f += 256)
+    dst[(size_t)K * base + f] = lds[f] + (accum ? dst[(size_t)K * base + f] : 0.f);
 }
 
 // Occupancy: 20 KB of LDS per workgroup = exactly 8 workgroups per CU (8 waves per SIMD, which needs <= 64 VGPRs).
@@ -579,9 +591,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (
         if (w <= 4u && h <= 4u) {          // the blocks the footprint reaches, as a bitmap: emission is bit arithmetic
           const unsigned long long bits = foot_bitmap(brec);
           crec = make_uint4(brec.xy, brec.wh, (uint32_t)bits, (uint32_t)(bits >> 32));
-        } else {                           // a big rect: counted here, walked row by row by k_bin_emit
+        } else {                           // a bigger rect
           const bool walk = brec.m < __int_as_float(0x7f800000);
-          crec = make_uint4(brec.xy, brec.wh | EGS_CR_BIG, walk ? foot_count(brec) : cnt, walk ? 1u : 0u);
+          if (walk && w <= 8u && h <= 8u) {   // its TILES as a bitmap; k_bin_emit evaluates the slabs of one tile
+            const unsigned long long bits = foot_tilemap(brec);
+            crec = make_uint4(brec.xy, brec.wh | EGS_CR_TILEMAP, (uint32_t)bits, (uint32_t)(bits >> 32));
+          } else {                            // counted here, walked row by row by k_bin_emit
+            crec = make_uint4(brec.xy, brec.wh | EGS_CR_BIG, walk ? foot_count(brec) : cnt, walk ? 1u : 0u);
+          }
           if (walk) {
             float4* o = reinterpret_cast<float4*>(bo.br + i);
             o[0] = make_float4(brec.ux, brec.uy, brec.A, brec.Bh);
@@ -626,8 +643,11 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ tcw, const float* __restrict__ twc, const float* __restrict__ depths,
     const float4* __restrict__ gpack, float* __restrict__ dL_dpw, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_high, float* __restrict__ dL_dalpha, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-    float* __restrict__ dL_du, const float* __restrict__ dcolor_dpws) {
+    float* __restrict__ dL_du, const float* __restrict__ dcolor_dpws, int accum) {
   // dcolor_dpws (nullable): [N][9] left by k_preprocess_fwd; with it this kernel never reads the SH coefficients
+  // accum: the five (six) parameter-gradient outputs already hold the gradients of EARLIER views of the step and this
+  // view's are ADDED to them (dL_du is per view and always written): a rank that renders V views per step then needs
+  // no separate accumulation kernels (torch's `.grad += new`: 976 B per Gaussian and view against 488 here)
   constexpr int K = 3 * NC;
   constexpr int KH = K - 3;
   constexpr int KS = RAW ? (KH > 0 ? KH : 1) : K;   // width of the rows that go through LDS
@@ -655,15 +675,17 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const f3 gci = {gb.z, gb.w, gc.x};
     if constexpr (RAW) {
       const float al = act_alpha(alphas[i]);
-      dL_dalpha[i] = ga.x * al * (1.f - al);   // sigmoid'
+      dL_dalpha[i] = ga.x * al * (1.f - al) + (accum ? dL_dalpha[i] : 0.f);   // sigmoid'
     } else {
-      dL_dalpha[i] = ga.x;
+      dL_dalpha[i] = ga.x + (accum ? dL_dalpha[i] : 0.f);
     }
     dL_du[2 * (size_t)i] = gu0; dL_du[2 * (size_t)i + 1] = gu1;
     if (pp.near_cull && depths[i] < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
-      st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
-      st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
-      st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
+      if (!accum) {
+        st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
+        st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
+        st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
+      }
     } else {
       const f3 pw = ld3(pws + 3 * (size_t)i);
       float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
@@ -694,6 +716,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
               (gq.z - q.w * qg) / qnorm};
         gs = {gs.x * s.x, gs.y * s.y, gs.z * s.z};
       }
+      if (accum) {
+        const float4 o = *reinterpret_cast<const float4*>(dL_drot + 4 * (size_t)i);
+        gq = {gq.w + o.x, gq.x + o.y, gq.y + o.z, gq.z + o.w};
+        const f3 os = ld3(dL_dscale + 3 * (size_t)i);
+        gs = {gs.x + os.x, gs.y + os.y, gs.z + os.z};
+      }
       st4(dL_drot + 4 * (size_t)i, gq);      // eq (3)
       st3(dL_dscale + 3 * (size_t)i, gs);    // eq (4)
       float j00, j02, j11, j12;
@@ -714,17 +742,20 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         opw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
-                 gcol.z * W[6 + k];
+                 gcol.z * W[6 + k] + (accum ? opw[k] : 0.f);
     }
   }
   if constexpr (RAW) {
-    if (i < n) { dL_dsh[3 * (size_t)i] = gsh[0]; dL_dsh[3 * (size_t)i + 1] = gsh[1]; dL_dsh[3 * (size_t)i + 2] = gsh[2]; }
+    if (i < n) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dL_dsh[3 * (size_t)i + k] = gsh[k] + (accum ? dL_dsh[3 * (size_t)i + k] : 0.f);
+    }
     if constexpr (KH > 0) {
-      if constexpr (KH % 2 == 1) stage_span_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage);
-      else stage_rows_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage);
+      if constexpr (KH % 2 == 1) stage_span_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage, accum != 0);
+      else stage_rows_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage, accum != 0);
     }
   } else {
-    stage_rows_out<K>(gsh, dL_dsh, n, blockIdx.x * 256, stage);
+    stage_rows_out<K>(gsh, dL_dsh, n, blockIdx.x * 256, stage, accum != 0);
   }
 }
 
@@ -979,7 +1010,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && patches >= 0);
   const bool keep_order = (phase & EGS_BWD_KEEP_FORWARD_ORDER) != 0;
   const bool masked = (phase & EGS_BWD_CULLED_LISTS) != 0;
-  phase &= ~(EGS_BWD_KEEP_FORWARD_ORDER | EGS_BWD_CULLED_LISTS);
+  const int accum = (phase & EGS_BWD_ACCUMULATE) ? 1 : 0;
+  phase &= ~(EGS_BWD_KEEP_FORWARD_ORDER | EGS_BWD_CULLED_LISTS | EGS_BWD_ACCUMULATE);
   EGS_CHECK_ARG(phase >= 0 && phase <= 2);
   if (phase != 2) { row_begin = 0; row_count = n; }
   EGS_CHECK_ARG(row_begin >= 0 && row_count >= 0 && row_begin + (int64_t)row_count <= n && row_begin % 256 == 0);
@@ -1013,7 +1045,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
       (RAW && shs_high) ? shs_high + kh * r0 : shs_high, alphas + r0, Rcw, tcw, twc, depths + r0,                  \
       (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0, dloss_dshs + (RAW ? 3 : sh_dim) * r0,                    \
       (RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high, dloss_dalphas + r0,                  \
-      dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0, dcolor_dpws ? dcolor_dpws + 9 * r0 : dcolor_dpws
+      dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0, dcolor_dpws ? dcolor_dpws + 9 * r0 : dcolor_dpws, \
+      accum
 #define EGS_PREB(NC, RAW)                                                                                         \
   do {                                                                                                            \
     if (dcolor_dpws) EGS_LAUNCH("k_preprocess_bwd", (k_preprocess_bwd<NC, RAW, true>), g, b, s, EGS_PREB_ARGS(NC, RAW)); \

@@ -570,7 +570,34 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
     const int x0 = (int)(cc.x & 0xFFFFu), y0 = (int)(cc.x >> 16);
     const int w = (int)(cc.y & 0xFFFFu), h = (int)((cc.y & EGS_CR_WH_MASK) >> 16);
     uint32_t tile = 0u, mask = 0xFu;
-    if (!(cc.y & EGS_CR_BIG)) {
+    if (cc.y & EGS_CR_TILEMAP) {                    // <= 8 x 8 tiles: the r-th set bit of the tile bitmap
+      const unsigned long long tb = ((unsigned long long)cc.w << 32) | cc.z;
+      int ty = 0, tx = 0;
+      uint32_t rb = 0u;
+      bool found = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const uint32_t bq = (uint32_t)(tb >> (8 * q)) & 0xFFu;
+        const uint32_t pc = (uint32_t)__popc(bq);
+        if (!found) {
+          if (r < pc) { rb = bq; ty = q; found = true; }
+          else r -= pc;
+        }
+      }
+      found = false;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        if (((rb >> q) & 1u) && !found) {
+          if (r == 0u) { tx = q; found = true; }
+          else --r;
+        }
+      }
+      tile = (uint32_t)(y0 + ty) * (uint32_t)gx + (uint32_t)(x0 + tx);
+      const BinRec b = br[s_g[lo]];                 // the block mask: the two slabs of this tile only
+      const Foot f = foot_setup(b);
+      const SlabPx sa = foot_slab(f, (y0 + ty) * EGS_TILE), sb = foot_slab(f, (y0 + ty) * EGS_TILE + 8);
+      mask = foot_mask(sa, sb, x0 + tx);
+    } else if (!(cc.y & EGS_CR_BIG)) {
       const unsigned long long blocks = ((unsigned long long)cc.w << 32) | cc.z;
       const unsigned long long tb = cr_tile_bits(blocks);
       int ty = 0, tx = 0;

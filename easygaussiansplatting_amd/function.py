@@ -77,8 +77,11 @@ class GSFunction(torch.autograd.Function):
             return (None,) * 7
         if ctx.mode == "fused":
             pws, shs, alphas, scales, rots = ctx.saved_tensors
+            acc = _fused.accumulation_targets((pws, shs, alphas, scales, rots))
             dpws, dshs, dalphas, dscales, drots, dus = _fused.backward(
-                pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous())
+                pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous(), accumulate=acc)
+            if acc is not None:      # added to the leaves' .grad inside the kernel: nothing for autograd to accumulate
+                return None, None, None, None, None, dus, None
             return dpws, dshs, dalphas, dscales, drots, dus, None
         (us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile, gsid_per_patch,
          dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales, dcolor_dshs, du_dpcs, dcov2d_dpcs,
@@ -116,9 +119,12 @@ class GSRawFunction(torch.autograd.Function):
         if dloss_dgammas is None:
             return (None,) * 8
         pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw = ctx.saved_tensors
+        acc = _fused.accumulation_targets((pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw))
         dpws, dlow, dhigh, dalphas, dscales, drots, dus = _fused.backward(
             pws, low_shs, alphas_raw, scales_raw, rots_raw, ctx.cam, ctx.state, dloss_dgammas.contiguous(),
-            high_shs=high_shs)
+            high_shs=high_shs, accumulate=acc)
+        if acc is not None:
+            return None, None, None, None, None, None, dus, None
         return dpws, dlow, dhigh, dalphas, dscales, drots, dus, None
 
 

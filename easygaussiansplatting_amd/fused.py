@@ -37,6 +37,7 @@ TILE_WORK_CACHE = os.environ.get("EGS_TILE_WORK_CACHE", "1") != "0"  # A/B knob:
 SAVE_DCOLOR = os.environ.get("EGS_SAVE_DCOLOR", "1") != "0"          # A/B knob: forward keeps dcolor/dpw for backward
 CULL_LISTS = os.environ.get("EGS_CULL_LISTS", "1") != "0"            # A/B knob: footprint-culled tile lists
 CULLED_LISTS = 32         # include/egs_hip.h EGS_BWD_CULLED_LISTS
+ACCUMULATE = 64           # include/egs_hip.h EGS_BWD_ACCUMULATE
 GSID_MASK = 0x0FFFFFFF    # csrc/egs_common.h EGS_GSID_MASK
 MAILBOX_SLOTS = 64
 
@@ -425,11 +426,57 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     return image, mask, S
 
 
-def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, high_shs=None):
+class accumulate_in_kernel:
+    """``with fused.accumulate_in_kernel(): ...`` -- backward passes of ``GSFunction`` / ``GSRawFunction`` inside the
+    block ADD their parameter gradients to the ``.grad`` the leaves already hold, inside the chain-rule kernel, and
+    return ``None`` for them to autograd (which then leaves ``.grad`` alone) -- instead of handing autograd fresh
+    tensors that it accumulates with separate kernels (976 B per Gaussian and view against 488).  For a rank that
+    renders several views per step.  Only taken when every differentiated input is a leaf whose ``.grad`` came out
+    of this module's backward (slices of one buffer, ``flat_grad_buffer``); the first view of a step, non-leaf inputs
+    or foreign ``.grad`` tensors go the ordinary way.  Tensor hooks / post-accumulate hooks of the leaves do not
+    fire for the views accumulated this way."""
+
+    def __enter__(self):
+        self._prev = getattr(_tls_acc, "on", False)
+        _tls_acc.on = True
+        return self
+
+    def __exit__(self, et, ev, tb):
+        _tls_acc.on = self._prev
+        return False
+
+
+class _AccFlag:          # process-wide (autograd runs backward on its own thread)
+    on = False
+
+
+_tls_acc = _AccFlag()
+
+
+def accumulation_targets(leaves):
+    """The ``.grad`` tensors of ``leaves`` when the coming backward may add to them in place (see
+    ``accumulate_in_kernel``), else None."""
+    if not getattr(_tls_acc, "on", False) or _exchange_hook is not None:
+        return None
+    grads = []
+    for t in leaves:
+        g = t.grad if (t.is_leaf and t.requires_grad) else None
+        if g is None or g.dtype != torch.float32 or not g.is_contiguous() or g.shape != t.shape or \
+                (g.data_ptr() & 15) or g.device != t.device:
+            return None
+        grads.append(g)
+    if flat_grad_buffer(leaves) is None:      # not the one-buffer layout this module's backward hands out
+        return None
+    return grads
+
+
+def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, high_shs=None, accumulate=None):
     """-> (dloss_dpws[N,3], dloss_dshs[N,K], dloss_dalphas[N,1], dloss_dscales[N,3],
            dloss_drots[N,4], dloss_dus[N,2])  -- the gradient tuple of gsmodel.py:87-93.
     With ``high_shs`` (raw tensors, see ``forward``): -> (dpws, dlow_shs[N,3], dhigh_shs[N,K-3],
-    dalphas_raw[N,1], dscales_raw, drots_raw, dus)."""
+    dalphas_raw[N,1], dscales_raw, drots_raw, dus).
+    ``accumulate``: the five (raw: six) gradient tensors of earlier views, in the order of the return tuple; this
+    view's gradients are ADDED to them by the kernel and the same tensors are returned."""
     raw = high_shs is not None
     pws = _chk(pws, "pws", torch.float32, (None, 3))
     n = pws.shape[0]
@@ -451,12 +498,15 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     # ``flat_grad_buffer(params)`` instead of five or six latency-bound ones (autograd adopts the slices as
     # ``.grad`` without copying).
     widths = [3, 3, K - 3, 1, 3, 4] if raw else [3, K, 1, 3, 4]
-    starts, at = [], 0
-    for w in widths:                      # every slice starts 16-B aligned (the kernels store dwordx4)
-        starts.append(at)
-        at += (n * w + 3) // 4 * 4
-    flat = torch.empty(at, dtype=f32, device=dev)
-    parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]
+    if accumulate is not None:
+        parts = [g.view(n, w) for g, w in zip(accumulate, widths)]
+    else:
+        starts, at = [], 0
+        for w in widths:                      # every slice starts 16-B aligned (the kernels store dwordx4)
+            starts.append(at)
+            at += (n * w + 3) // 4 * 4
+        flat = torch.empty(at, dtype=f32, device=dev)
+        parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]
     if raw:
         dpws, dshs, dhigh, dalphas, dscales, drots = parts
     else:
@@ -485,6 +535,8 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     keep = KEEP_FORWARD_ORDER if (REUSE_ORDER and getattr(S, "order_by_work", False)) else 0
     if getattr(S, "culled", False):
         keep |= CULLED_LISTS          # the list values carry block masks
+    if accumulate is not None:
+        keep |= ACCUMULATE            # the outputs hold earlier views' gradients: add to them
     hook = _exchange_hook
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups
@@ -502,7 +554,7 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
         launch(1 | keep, 0, 0)
         for b in range(0, n, rows):
             c = min(rows, n - b)
-            launch(2, b, c)
+            launch(2 | (keep & ACCUMULATE), b, c)
             hook.on_chunk([p[b:b + c] for p in parts])
     if raw:
         return dpws, dshs, dhigh, dalphas, dscales, drots, dus

@@ -134,13 +134,15 @@ class Trainer:
         # step.  commit() (one wait for the binning stage of the last view, while its draw and backward
         # kernels are still queued) tells whether some view outgrew the buffers sized from earlier renders;
         # that happens while the trainer still meets new views, and the step is then redone exactly.
-        with _fused.deferred() as d:
-            loss_sum, gnorm, count = self._render_views(mine, len(view_ids))
-            incomplete = d.commit()
-        if incomplete:
-            self.redone_steps += 1
-            self.opt.zero_grad(set_to_none=True)
-            loss_sum, gnorm, count = self._render_views(mine, len(view_ids))   # validated render by render
+        # (from the second local view on the chain-rule kernel adds to the leaves' .grad itself: accumulate_in_kernel)
+        with _fused.accumulate_in_kernel():
+            with _fused.deferred() as d:
+                loss_sum, gnorm, count = self._render_views(mine, len(view_ids))
+                incomplete = d.commit()
+            if incomplete:
+                self.redone_steps += 1
+                self.opt.zero_grad(set_to_none=True)
+                loss_sum, gnorm, count = self._render_views(mine, len(view_ids))   # validated render by render
         if self.world > 1:   # sum over ranks of (sum over local views)/V == mean over all views
             DV.allreduce_sum_(DV.coalesce_grads(list(self.params.values())) + [gnorm, count, loss_sum])
         self.grad_accum += gnorm

@@ -295,6 +295,11 @@ size_t egs_fused_backward_ws_bytes(int n);
  * Gaussian index, the 4-bit mask of the 8x8 pixel blocks of the tile the footprint reaches.  Internal to the fused
  * path: the seven-op surface (egs_splat_bin / egs_splat_draw) always produces the reference's lists. */
 #define EGS_BWD_CULLED_LISTS 32
+/* OR-ed into `phase` of egs_fused_backward(_raw): the parameter-gradient outputs (dloss_dpws, dloss_dshs | low + high,
+ * dloss_dalphas, dloss_dscales, dloss_drots) already hold the gradients of earlier views of the step; this view's are
+ * ADDED to them by the chain-rule kernel (dloss_dus is per view and always written).  Replaces autograd's separate
+ * accumulation kernels for a rank that renders several views per step (bench.py --views-per-rank, Trainer.step). */
+#define EGS_BWD_ACCUMULATE 64
 #define EGS_DRAW_CULLED_LISTS 1
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
  * phase 2: only the per-Gaussian chain rule for rows [row_begin, row_begin + row_count), row_begin a multiple

@@ -118,3 +118,43 @@ def test_parameter_gradients_share_one_buffer(n):
     img.backward(dl)
     assert fused.flat_grad_buffer(q) is not None
     assert fused.flat_grad_buffer(q[:3]) is None         # does not tile the buffer
+
+
+@pytest.mark.parametrize("raw", [False, True])
+def test_accumulate_in_kernel_equals_autograd_accumulation(raw):
+    """Several views per step: inside ``fused.accumulate_in_kernel()`` the chain-rule kernel adds a view's parameter
+    gradients to the leaves' ``.grad`` itself (EGS_BWD_ACCUMULATE) and autograd is handed None -- same sums as
+    autograd's own accumulation of per-view tensors, the ``.grad`` buffers stay the ONE flat allocation."""
+    import numpy as np
+    from easygaussiansplatting_amd import fused, scene as S
+    from easygaussiansplatting_amd.function import Camera, GSFunction, GSRawFunction
+    from easygaussiansplatting_amd.trainer import raw_params_from_scene
+    GSFunction.mode = "fused"
+    sc = S.small_scene(5000, 160, 96, 48, seed=31)
+    sc.pws[:30, 2] = -9.0                                  # some culled rows: they must keep what they hold
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 3, radius=5.0)]
+    dls = [torch.from_numpy(S.normal(6, v, (3, 96, 160)).astype(np.float32)).cuda() / (3 * 96 * 160) for v in range(3)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+
+    def leaves():
+        if raw:
+            p = raw_params_from_scene(sc, "cuda")
+            return [p[k] for k in ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")]
+        return [dev(a).requires_grad_(True) for a in (sc.pws, sc.shs, sc.alphas.reshape(-1, 1), sc.scales, sc.rots)]
+
+    def run(in_kernel):
+        L = leaves()
+        us = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+        import contextlib
+        with (fused.accumulate_in_kernel() if in_kernel else contextlib.nullcontext()):
+            for cam, dl in zip(cams, dls):
+                img, _ = (GSRawFunction if raw else GSFunction).apply(*L, us, cam)
+                img.backward(dl)
+        torch.cuda.synchronize()
+        assert fused.flat_grad_buffer(L) is not None
+        return [t.grad.clone() for t in L] + [us.grad.clone()]
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        scale = float(x.abs().max())
+        assert scale > 0 and float((x - y).abs().max()) <= 2e-5 * scale     # atomics order of k_draw_bwd only
+    assert not a[0][:30].any() and not b[0][:30].any()
