@@ -17,6 +17,8 @@ rows.sort()
 # the last step = from the last k_preprocess_fwd on
 # (with the two-stream forward the side-stream part is k_preprocess_fwd<.., 2>: not a step boundary)
 starts = [i for i, r in enumerate(rows) if "k_preprocess_fwd" in r[2] and ", 2>(" not in r[2]]
+if len(starts) < 2:      # the seven-op surface: a step starts with project
+    starts = [i for i, r in enumerate(rows) if "k_project" in r[2]]
 i0, i1 = starts[-2], starts[-1]
 step = rows[i0:i1]
 t0 = step[0][0]
