@@ -121,6 +121,8 @@ struct BinCountOut {  // where k_bin_count's results live inside the bin workspa
   uint4* cr;                       // compact bin record per Gaussian
   BinRec* br;                      // footprint record, written for the cullable Gaussians with a rect larger than 4 x 4 tiles only
   uint32_t *dkeys, *ids, *maxkey;  // maxkey[1 + workgroup] = per-workgroup maximum of the depth keys
+  uint32_t* sort_sup;              // the depth sort's superblock sums: the producing kernel ZEROES them on the side
+  uint32_t sort_sup_words;
 };
 // list values of the culled lists (fused path): Gaussian index in the low 28 bits, in the high 4 the 8x8 pixel blocks
 // of the tile the footprint reaches (bit k = block (k&1, k>>1)) -- computed ONCE per (tile, Gaussian) at emission

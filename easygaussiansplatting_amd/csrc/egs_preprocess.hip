@@ -533,6 +533,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (
                                    ? RowStage<KH>::LDS_FLOATS : RowStage<12>::LDS_FLOATS;
   __shared__ float stage[STAGE_FLOATS];
   const int i = blockIdx.x * 256 + threadIdx.x;
+  if (bo.cr)     // the superblock sums of the depth sort that follows must start from zero
+    for (uint32_t z = (uint32_t)i; z < bo.sort_sup_words; z += gridDim.x * 256u) bo.sort_sup[z] = 0u;
   uint32_t dkey = 0u;
   float sh[K];
   if constexpr (RAW) {   // 180-B high_shs rows cannot be dwordx4-loaded per lane: the workgroup's span through LDS

@@ -55,18 +55,49 @@ constexpr int64_t RS_SHORT = 5 << 19;              // <= 2.6 M items: 2048-item 
 static int rs_ipt(int64_t n) { return n <= RS_SHORT ? 8 : 16; }
 
 // `maxkey` (nullable, device): upper bound of all keys.  A pass whose digit is 0 for every key
-// ((*maxkey >> shift) == 0) is the identity permutation: hist/rowscan return at once and
+// ((*maxkey >> shift) == 0) is the identity permutation: hist returns at once and
 // scatter degenerates to a coalesced copy.
+//
+// Per pass TWO kernels, not three.  The per-workgroup digit counts go to hist[block][digit] (block-major: coalesced
+// rows) and, by one atomic per non-empty digit, into the sums of SUPERBLOCKS of RS_SB workgroups, sup[superblock][digit]
+// (zeroed by the kernel that ran before the sort).  The scatter kernel then builds its own offsets from at most
+// RS_SB - 1 hist rows of its superblock and the <= 32 superblock rows: no row-scan launch in between (it was a
+// 256-workgroup kernel over <= 1 MB, 5-6 us of launch and drain four times per step).
+//
+// mk_parts != NULL (first pass of the depth sort): workgroup 0 also folds the per-workgroup maxima of the keys
+// (maxkey[1 + i], left by the kernel that produced them) into maxkey[0] -- the later passes test it -- and into
+// up to two more places (mk_out: next to P in device memory; mk_host: the page-locked mailbox slot).  The first
+// pass itself never consults maxkey: with shift 0 it could only detect "every key is 0", where the pass is the
+// identity anyway.
+constexpr int RS_SB = 32;           // workgroups per superblock
 template <int RS_IPT>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __restrict__ keys, int64_t n,
                                                            int shift, uint32_t dmask, int nblocks,
-                                                           uint32_t* __restrict__ hist,
+                                                           uint32_t* __restrict__ hist, uint32_t* __restrict__ sup,
                                                            const uint32_t* __restrict__ maxkey,
-                                                           const uint32_t* __restrict__ n_dev) {
+                                                           const uint32_t* __restrict__ n_dev,
+                                                           uint32_t* __restrict__ mk_parts, int nparts,
+                                                           uint32_t* __restrict__ mk_out,
+                                                           uint32_t* __restrict__ mk_host) {
   constexpr int RS_TILE = RS_THREADS * RS_IPT;
   __shared__ uint32_t h[256];
+  __shared__ uint32_t sm[4];
   const int tid = threadIdx.x;
-  if (maxkey && ((*maxkey >> shift) == 0u)) return;
+  if (mk_parts && blockIdx.x == 0) {
+    uint32_t mk = 0u;
+    for (int i = tid; i < nparts; i += 256) mk = max(mk, mk_parts[1 + i]);
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
+    if ((tid & 63) == 0) sm[tid >> 6] = mk;
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
+      mk_parts[0] = m;
+      if (mk_out) *mk_out = m;
+      if (mk_host) *mk_host = m;
+    }
+  }
+  if (!mk_parts && maxkey && ((*maxkey >> shift) == 0u)) return;
   if (n_dev) n = min(n, (int64_t)*n_dev);   // `n` is a capacity: the real count is on the device
   h[tid] = 0;
   __syncthreads();
@@ -77,51 +108,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
     if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & dmask], 1u);
   }
   __syncthreads();
-  hist[(size_t)tid * nblocks + blockIdx.x] = h[tid];  // digit-major: row = digit
-}
-
-// one workgroup per digit: exclusive scan of that digit's per-block counts (in
-// place) and the digit total.
-//
-// mk_parts != NULL (first pass of the depth sort): workgroup 0 also folds the per-workgroup maxima of the keys
-// (maxkey[1 + i], left by the kernel that produced them) into maxkey[0] -- the later passes test it -- and into
-// up to two more places (mk_out: next to P in device memory; mk_host: the page-locked mailbox slot).  The first
-// pass itself never consults maxkey: with shift 0 it could only detect "every key is 0", where the pass is the
-// identity anyway.  (A separate one-workgroup reduce kernel used to sit in front of the sort: 5 us of launch.)
-__global__ __launch_bounds__(256) void k_radix_rowscan(uint32_t* __restrict__ hist, int nblocks,
-                                                       uint32_t* __restrict__ totals, int shift,
-                                                       const uint32_t* __restrict__ maxkey,
-                                                       uint32_t* __restrict__ mk_parts, int nparts,
-                                                       uint32_t* __restrict__ mk_out,
-                                                       uint32_t* __restrict__ mk_host) {
-  __shared__ uint32_t sm[4];
-  if (mk_parts && blockIdx.x == 0) {
-    uint32_t mk = 0u;
-    for (int i = threadIdx.x; i < nparts; i += 256) mk = max(mk, mk_parts[1 + i]);
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) mk = max(mk, (uint32_t)__shfl_xor((int)mk, d, 64));
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = mk;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const uint32_t m = max(max(sm[0], sm[1]), max(sm[2], sm[3]));
-      mk_parts[0] = m;
-      if (mk_out) *mk_out = m;
-      if (mk_host) *mk_host = m;
-    }
-    __syncthreads();
-  }
-  if (!mk_parts && maxkey && ((*maxkey >> shift) == 0u)) return;
-  uint32_t* row = hist + (size_t)blockIdx.x * nblocks;
-  uint32_t carry = 0;
-  for (int base = 0; base < nblocks; base += 256) {
-    const int i = base + threadIdx.x;
-    const uint32_t v = (i < nblocks) ? row[i] : 0u;
-    uint32_t tot;
-    const uint32_t ex = block256_exclusive_scan(v, sm, &tot);
-    if (i < nblocks) row[i] = carry + ex;
-    carry += tot;
-  }
-  if (threadIdx.x == 0) totals[blockIdx.x] = carry;
+  const uint32_t c = h[tid];
+  hist[(size_t)blockIdx.x * 256 + tid] = c;          // block-major: row = workgroup
+  if (c) atomicAdd(&sup[(size_t)(blockIdx.x / RS_SB) * 256 + tid], c);
 }
 
 // Scatter with local reordering: every item's stable rank inside the workgroup's 4096-item tile
@@ -135,7 +124,7 @@ template <int RS_IPT, int EXTRA>
 __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
-    int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals,
+    int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ sup,
     const uint32_t* __restrict__ maxkey, const uint32_t* __restrict__ n_dev,
     const uint4* __restrict__ gsrc, uint4* __restrict__ gdst, uint32_t* __restrict__ cdst,
     int32_t* __restrict__ ranges_out) {
@@ -175,9 +164,30 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
   __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
 #pragma unroll
   for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
-  // global base of digit `tid` = (sum of totals of smaller digits) + (same digit in earlier blocks)
-  const uint32_t dig_ex = block256_exclusive_scan(totals[tid], sm, nullptr);
-  const uint32_t gbase = dig_ex + hist[(size_t)tid * nblocks + blockIdx.x];
+  // global base of digit `tid` = (sum of the totals of smaller digits) + (same digit in earlier workgroups):
+  // superblock sums for the total and for the superblocks before this workgroup's, hist rows inside it
+  // (the loads of a group of 16 rows in flight at once: the rows are 1-KB lines out of L2, what counts is latency;
+  // 32 at once cost the kernel a resident wave per SIMD)
+  uint32_t dtotal = 0u, before = 0u;
+  {
+    const int sb = blockIdx.x / RS_SB, nsb = (nblocks + RS_SB - 1) / RS_SB;
+    for (int q0 = 0; q0 < nsb; q0 += 16) {
+      uint32_t v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = (q0 + r < nsb) ? sup[(size_t)(q0 + r) * 256 + tid] : 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { dtotal += v[r]; if (q0 + r < sb) before += v[r]; }
+    }
+    for (int q0 = sb * RS_SB; q0 < (int)blockIdx.x; q0 += 16) {
+      uint32_t w[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) w[r] = (q0 + r < (int)blockIdx.x) ? hist[(size_t)(q0 + r) * 256 + tid] : 0u;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) before += w[r];
+    }
+  }
+  const uint32_t dig_ex = block256_exclusive_scan(dtotal, sm, nullptr);
+  const uint32_t gbase = dig_ex + before;
 
   const int64_t base = blockbase + (int64_t)wave * RS_WAVE_ITEMS;
   uint32_t key[RS_IPT], val[RS_IPT], rank[RS_IPT];
@@ -261,18 +271,24 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
 }
 
 struct SortWs {
-  uint32_t* hist;
-  uint32_t* totals;
+  uint32_t* hist;      // [workgroup][digit]
+  uint32_t* sup;       // [pass (<= 4)][superblock][digit]: must be ZERO when the sort's first kernel starts
+  size_t sup_words;    // words of `sup` (what the caller zeroes)
   int nblocks;
 };
-static size_t sort_ws_bytes(int64_t n) {
+static size_t sort_sup_words(int64_t n) {
   const int nb = n > 0 ? div_up(n, RS_THREADS * 8) : 1;   // sized for the smaller tile
-  return align_up((size_t)256 * nb * 4, 256) + 256 * 4 + 512;
+  return (size_t)4 * div_up(nb, RS_SB) * 256;
+}
+static size_t sort_ws_bytes(int64_t n) {
+  const int nb = n > 0 ? div_up(n, RS_THREADS * 8) : 1;
+  return align_up((size_t)256 * nb * 4, 256) + align_up(sort_sup_words(n) * 4, 256) + 512;
 }
 static bool sort_ws_carve(Carver& cv, int64_t n, SortWs* w) {
   w->nblocks = n > 0 ? div_up(n, RS_THREADS * rs_ipt(n)) : 1;
   w->hist = cv.take<uint32_t>((size_t)256 * w->nblocks);
-  w->totals = cv.take<uint32_t>(256);
+  w->sup_words = sort_sup_words(n);
+  w->sup = cv.take<uint32_t>(w->sup_words);
   return cv.ok();
 }
 static int sort_passes(int begin_bit, int end_bit) { return (end_bit - begin_bit + 7) / 8; }
@@ -291,6 +307,7 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
   // mean longer coalesced runs out of every tile
   const int passes = sort_passes(begin_bit, end_bit);
   const int width = (end_bit - begin_bit + passes - 1) / passes;
+  int pass = 0;
   for (int shift = begin_bit; shift < end_bit; shift += width) {
     const int nb = end_bit - shift < width ? end_bit - shift : width;  // the last digit may be narrower
     const uint32_t dmask = (1u << nb) - 1u;
@@ -298,18 +315,19 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
     const uint32_t* mk = first ? nullptr : maxkey;
     const bool last = shift + width >= end_bit;
     const uint4* gs = last ? gsrc : nullptr;
+    uint32_t* sup = w.sup + (size_t)pass * div_up(w.nblocks, RS_SB) * 256;    // this pass's (zeroed) superblock sums
+    uint32_t* mkp = first ? mk_parts : (uint32_t*)nullptr;
     if (rs_ipt(n) == 8)
       EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
-                 w.nblocks, w.hist, mk, n_dev);
+                 w.nblocks, w.hist, sup, mk, n_dev, mkp, nparts, mk_out, mk_host);
     else
       EGS_LAUNCH("k_radix_hist", k_radix_hist<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
-                 w.nblocks, w.hist, mk, n_dev);
-    EGS_LAUNCH("k_radix_rowscan", k_radix_rowscan, dim3(256), dim3(256), s, w.hist, w.nblocks, w.totals, shift,
-               mk, first ? mk_parts : (uint32_t*)nullptr, nparts, mk_out, mk_host);
+                 w.nblocks, w.hist, sup, mk, n_dev, mkp, nparts, mk_out, mk_host);
+    ++pass;
     int32_t* ro = last ? ranges_out : (int32_t*)nullptr;
 #define EGS_SCATTER(IPT, EXTRA)                                                                                     \
   EGS_LAUNCH("k_radix_scatter", (k_radix_scatter<IPT, EXTRA>), dim3(w.nblocks), dim3(RS_THREADS), s, ki, vi, ko, vo, n, \
-             shift, dmask, w.nblocks, w.hist, w.totals, mk, n_dev, gs, gdst, cdst, ro)
+             shift, dmask, w.nblocks, w.hist, sup, mk, n_dev, gs, gdst, cdst, ro)
     if (rs_ipt(n) == 8) {
       if (gs) EGS_SCATTER(8, 1); else if (ro) EGS_SCATTER(8, 2); else EGS_SCATTER(8, 0);
     } else {
@@ -406,8 +424,10 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
                                                    int32_t* __restrict__ areas, float* __restrict__ depths,
                                                    uint4* __restrict__ cr,
                                                    uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
-                                                   uint32_t* __restrict__ maxkey) {
+                                                   uint32_t* __restrict__ maxkey, uint32_t* __restrict__ sort_sup,
+                                                   uint32_t sort_sup_words) {
   const int i = blockIdx.x * 256 + threadIdx.x;
+  for (uint32_t z = (uint32_t)i; z < sort_sup_words; z += gridDim.x * 256u) sort_sup[z] = 0u;   // for the depth sort
   uint32_t key = 0u;
   if (i < n) {
     uint4 rect;
@@ -531,7 +551,8 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
                                                   const BinRec* __restrict__ br,
                                                   uint32_t* __restrict__ tkeys, uint32_t* __restrict__ gsid,
                                                   uint32_t cap, int32_t* __restrict__ ranges, int n_ranges,
-                                                  int with_masks) {
+                                                  int with_masks, uint32_t* __restrict__ sort_sup,
+                                                  uint32_t sort_sup_words) {
   __shared__ uint32_t s_off[257];   // offsets relative to the workgroup's first one; [256] = span length
   __shared__ uint32_t s_g[256];
   __shared__ uint4 s_cr[256];
@@ -539,6 +560,7 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
   const int j = blockIdx.x * 256 + tid;
   // (INT_MAX, 0) = "no patches yet": the last scatter pass of the tile sort lowers / raises them (getRanges folded in)
   for (int i = j; i < n_ranges; i += gridDim.x * 256) ranges[i] = ((i & 1) || !EGS_RANGES_FOLD) ? 0 : 0x7fffffff;
+  for (uint32_t z = (uint32_t)j; z < sort_sup_words; z += gridDim.x * 256u) sort_sup[z] = 0u;   // for the tile sort
   uint32_t off = 0, g = 0;
   uint4 c = make_uint4(0u, 0u, 0u, 0u);
   if (j < n) {
@@ -1661,6 +1683,7 @@ extern "C" int egs_sort_pairs(int64_t n, uint32_t* keys, uint32_t* vals, uint32_
     set_error(EGS_ERR_WORKSPACE, "sort workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
   }
+  EGS_HIP(hipMemsetAsync(w.sup, 0, w.sup_words * 4, (hipStream_t)stream));   // (the binning kernels zero theirs on the side)
   return radix_sort(n, keys, vals, keys_alt, vals_alt, begin_bit, end_bit, w, (hipStream_t)stream);
 }
 
@@ -1725,7 +1748,7 @@ static int splat_bin_impl(int n, int width, int height, const float* us, int32_t
   }
   const BinParams p = make_bin_params(width, height, pol);
   EGS_LAUNCH("k_bin_count", k_bin_count, dim3(div_up(n, 256)), dim3(256), s, n, p, us, areas, depths, L.cr,
-             L.dkeys, L.ids, L.maxkey);
+             L.dkeys, L.ids, L.maxkey, L.sort.sup, (uint32_t)L.sort.sup_words);
   EGS_LAUNCH_OK();
   return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, host_totals);
 }
@@ -1746,6 +1769,7 @@ bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* ou
   BinLayout L;
   if (!bin_carve(ws_bin, ws_bin_bytes, n, &L)) return false;
   out->cr = L.cr; out->br = L.br; out->dkeys = L.dkeys; out->ids = L.ids; out->maxkey = L.maxkey;
+  out->sort_sup = L.sort.sup; out->sort_sup_words = (uint32_t)L.sort.sup_words;
   return true;
 }
 
@@ -1845,7 +1869,8 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   uint32_t* v0 = (passes & 1) ? D.gsid_alt : gs_primary;
   uint32_t* v1 = (passes & 1) ? gs_primary : D.gsid_alt;
   EGS_LAUNCH("k_bin_emit", k_bin_emit, dim3(div_up(n, 256)), dim3(256), s, n, dp.gx, B.ids, B.offsets, B.cr_sorted,
-             B.br, k0, v0, (uint32_t)patches, patch_range_per_tile, 2 * dp.T, dp.masked);
+             B.br, k0, v0, (uint32_t)patches, patch_range_per_tile, 2 * dp.T, dp.masked, D.sort.sup,
+             (uint32_t)D.sort.sup_words);
   const float4* rec = rec_in ? rec_in : D.rec;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
