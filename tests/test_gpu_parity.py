@@ -514,6 +514,60 @@ def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
     assert not g_f["pws"][:40].any() and not g_f["shs"][:40].any()          # culled Gaussians get zero gradients
 
 
+def test_fused_culled_lists_all_rect_sizes_vs_oracle(gsc):
+    """The footprint-culled lists of the fused path through EVERY form of the compact bin record on one image:
+    rects of <= 4x4 tiles (block bitmap), <= 8x8 tiles (tile bitmap + the two slabs of the emitted tile), larger ones
+    (row walk), Gaussians that never blend (alpha < alpha_skip: no patches at all), alpha barely above the threshold
+    (a footprint of a pixel or two), Gaussians cut by the image border.  Whole image and all parameter gradients
+    against the oracle's full pipeline (which draws the reference's UNCULLED lists), ``check_culled_lists`` on every
+    tile that has patches."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    gsc.set_policy("gsplatcu")
+    GSFunction.mode = "fused"
+    W, H = 320, 240                                     # 20 x 15 tiles
+    sc = S.small_scene(2500, W, H, 12, seed=77)
+    u = S.uniform01(9, 1, (sc.n,))
+    sc.scales[:60] *= 6.0                               # rects of 5..8 tiles
+    sc.scales[60:90] *= 25.0                            # rects beyond 8 x 8 tiles (some cover the whole image)
+    sc.scales[90:140, 0] *= 12.0                        # long needles: large rects, thin footprints
+    sc.alphas[140:200] = 0.0015                         # below alpha_skip: never blend
+    sc.alphas[200:260] = (0.002 + 0.0004 * u[200:260]).astype(np.float32)   # barely above it
+    sc.alphas[:140] = np.minimum(sc.alphas[:140], 0.25) # keep the giants from saturating every pixel
+    cam = Camera.from_scene(sc.cam)
+    dl = S.normal(3, 19, (3, H, W)).astype(np.float32) / (3 * H * W)
+    o_img, o_mask, o_g = _oracle_param_grads(sc, sc.cam, dl.astype(np.float64))
+    P = dict(pws=dev(sc.pws), shs=dev(sc.shs), alphas=dev(sc.alphas).reshape(-1, 1), scales=dev(sc.scales),
+             rots=dev(sc.rots))
+    img_t, mask_t, st = fused.forward(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam, need_grad=True)
+    assert st.culled
+    for p in P.values():
+        p.requires_grad_(True)
+    us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+    image, mask = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+    image.backward(dev(dl))
+    assert torch.equal(image, img_t)
+    assert np.array_equal(host(mask), o_mask)
+    d = np.abs(host(image) - o_img).max(0)
+    assert (d >= 1e-4).sum() <= 6 and d.max() < 5e-3, ((d >= 1e-4).sum(), d.max())        # threshold flips, counted
+    got = {k: host(v.grad) for k, v in P.items()} | {"us": host(us0.grad)}
+    for k in ("pws", "shs", "alphas", "scales", "rots", "us"):
+        assert close(got[k], o_g[k], 3e-4), (k, np.abs(got[k] - o_g[k]).max(), np.abs(o_g[k]).max())
+    # the lists themselves: every form of the record is in use, nothing that blends is missing
+    o_us, o_ci, o_col, o_depths, o_areas = _oracle_2d(sc, sc.cam)
+    d_marked = o_depths.astype(np.float32).copy()
+    o_rects, o_counts = O.get_rects(o_us.astype(np.float32), o_areas.copy(), d_marked, W, H, O.POLICY_G)
+    wh = (o_rects[:, 2:4].astype(np.int64) - o_rects[:, 0:2].astype(np.int64))[o_counts > 0]
+    assert (wh.max(1) <= 4).any() and ((wh.max(1) > 4) & (wh.max(1) <= 8)).any() and (wh.max(1) > 8).any()
+    rg = host(st.ranges)
+    tiles = np.nonzero(rg[:, 1] > rg[:, 0])[0]
+    dropped, kept, bdev, btrue = check_culled_lists(st, tiles, o_us, o_ci, sc.alphas.astype(np.float64),
+                                                    host(st.depths), o_rects.astype(np.int64), W)
+    assert dropped > 0.1 * kept and btrue <= bdev <= 1.6 * btrue, (dropped, kept, bdev, btrue)
+    ids = host(st.gaussian_ids())
+    assert not np.isin(ids, np.arange(140, 200)).any()       # alpha < alpha_skip: emitted for no tile
+
+
 def test_nan_conic_is_skipped_not_blended(gsc):
     """Fixture G10 (tests/golden/make_golden_nan.py): Gaussians whose conic holds inf / NaN -- every Mahalanobis term
     they produce is NaN.  The CUDA extension's ``max(0.0f, NaN) == 0`` makes them blend at min(0.99, alpha)
