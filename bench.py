@@ -16,7 +16,7 @@ With N > 1 every rank renders its own camera view of the same scene (one view pe
 step ends with an RCCL all-reduce of the parameter gradients (236 MB at 1 M Gaussians); `value` is the
 whole-job rate: N * W*H / t_step.
 
-Order of a run: ``--ramp-steps`` (default 150) untimed steps that take the GPU off its idle clocks, the W warm-up
+Order of a run: ``--ramp-steps`` (default 400, ~0.4 s) untimed steps that take the GPU off its idle clocks, the W warm-up
 steps, an untimed pre-pass with every launch bracketed by HIP events (per-kernel table), then EXACTLY K timed
 steps between barrier + synchronize pairs -- back to back, the garbage collector parked, so that the timed
 region sees the steady state of a training run and not the clock ramp (measured: 20 steps timed cold 1.03-1.04
@@ -143,7 +143,7 @@ def main():
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--sh-dim", type=int, default=48)
-    ap.add_argument("--ramp-steps", type=int, default=150,
+    ap.add_argument("--ramp-steps", type=int, default=400,
                     help="untimed render steps BEFORE the warm-up steps (~0.15 s): the GPU leaves its idle clocks "
                          "(20 steps measured cold are ~7 %% slower than the steady state a training run sees); "
                          "a count, not a duration, so that all ranks issue the same collectives")

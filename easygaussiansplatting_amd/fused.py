@@ -437,26 +437,26 @@ class accumulate_in_kernel:
     fire for the views accumulated this way."""
 
     def __enter__(self):
-        self._prev = getattr(_tls_acc, "on", False)
-        _tls_acc.on = True
+        self._prev = getattr(_acc_flag, "on", False)
+        _acc_flag.on = True
         return self
 
     def __exit__(self, et, ev, tb):
-        _tls_acc.on = self._prev
+        _acc_flag.on = self._prev
         return False
 
 
-class _AccFlag:          # process-wide (autograd runs backward on its own thread)
+class _AccFlag:          # process-wide, not thread-local: autograd runs backward on its own thread
     on = False
 
 
-_tls_acc = _AccFlag()
+_acc_flag = _AccFlag()
 
 
 def accumulation_targets(leaves):
     """The ``.grad`` tensors of ``leaves`` when the coming backward may add to them in place (see
     ``accumulate_in_kernel``), else None."""
-    if not getattr(_tls_acc, "on", False) or _exchange_hook is not None:
+    if not getattr(_acc_flag, "on", False) or _exchange_hook is not None:
         return None
     grads = []
     for t in leaves:

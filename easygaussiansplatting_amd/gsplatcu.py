@@ -33,7 +33,7 @@ from . import _lib
 from ._lib import EgsPolicy
 
 __all__ = ["project", "computeCov3D", "computeCov2D", "sh2Color", "inverseCov2D", "splat", "splatB",
-           "set_policy", "get_policy", "chain_rule"]
+           "set_policy", "get_policy", "chain_rule", "clear_memo"]
 
 _policy_name = "gsplatcu"
 _policy = None
@@ -275,6 +275,12 @@ def _alphas(alphas, n):
 # handed to another tensor while the entry lives; an entry is used only when every input is the same memory at the
 # same version (torch's in-place counter) under the same policy -- anything else repacks, exactly as before.
 _splat_memo = {}
+
+
+def clear_memo() -> None:
+    """Drop what ``splat`` keeps for the next ``splatB`` (per device and stream: the four input tensors it packed, the
+    48-B records built from them and the dispatch-order buffer -- ~84 MB at 1 M Gaussians until the next ``splat``)."""
+    _splat_memo.clear()
 
 
 def _memo_sig(tensors):
