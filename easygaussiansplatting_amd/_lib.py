@@ -64,7 +64,7 @@ SIGNATURES = {
     "egs_splat_bwd": (_i, [_i, _i64, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P, _P, _P, _P, _P, _sz,
                            _P, _P, _P, _P, _P]),
     "egs_pack_records": (_i, [_i, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P]),
-    "egs_splat_bwd_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P, _P, _P, _P, _P]),
+    "egs_splat_bwd_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P]),
     "egs_sort_pairs_ws_bytes": (_sz, [_i64]),
     "egs_sort_pairs": (_i, [_i64, _P, _P, _P, _P, _i, _i, _P, _sz, C.POINTER(C.c_int), _P]),
     "egs_scan_ws_bytes": (_sz, [_i64]),

@@ -186,8 +186,11 @@ __global__ __launch_bounds__(256) void k_cov2d(int n, const float* __restrict__ 
 }
 
 // ---- sh2color                                         (reference kernel.cu:619-807)
+#ifndef EGS_SH2COLOR_WAVES     // A/B knob: minimum waves per SIMD of k_sh2color (106 VGPRs = 4 as compiled freely)
+#define EGS_SH2COLOR_WAVES 1
+#endif
 template <int NC>
-__global__ __launch_bounds__(256) void k_sh2color(int n, const float* __restrict__ shs,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EGS_SH2COLOR_WAVES, 8))) void k_sh2color(int n, const float* __restrict__ shs,
                                                   const float* __restrict__ pws,
                                                   const float* __restrict__ twc,
                                                   float* __restrict__ colors,

@@ -2100,8 +2100,10 @@ extern "C" int egs_pack_records(int n, int width, int height, const float* us, c
 extern "C" int egs_splat_bwd_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                                  const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                                  const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                                 const int32_t* tile_order, float* dloss_dus, float* dloss_dcinv2ds,
-                                 float* dloss_dalphas, float* dloss_dcolors, void* stream) {
+                                 const int32_t* tile_order, float* grad_records, float* dloss_dus,
+                                 float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors, void* stream) {
+  // grad_records (nullable, [N][12] floats): the packed gradient records, ALREADY ZERO (the forward draw cleared
+  // them on the side, egs_splat_draw_rec*'s grad_records): no 48 N-byte fill in front of the backward draw
   EGS_CHECK_ARG(n >= 0 && patches >= 0 && width > 0 && height > 0 && pol);
   if (n == 0) return 0;
   EGS_CHECK_ARG(rec && ws && dloss_dus && dloss_dcinv2ds && dloss_dalphas && dloss_dcolors);
@@ -2112,7 +2114,7 @@ extern "C" int egs_splat_bwd_rec(int n, int64_t patches, int width, int height, 
   float* gpack = nullptr;
   int rc = splat_bwd_packed(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, contrib,
                             final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream,
-                            rec, tile_order, nullptr);
+                            rec, tile_order, grad_records);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,

@@ -279,7 +279,8 @@ _splat_memo = {}
 
 def clear_memo() -> None:
     """Drop what ``splat`` keeps for the next ``splatB`` (per device and stream: the four input tensors it packed, the
-    48-B records built from them and the dispatch-order buffer -- ~84 MB at 1 M Gaussians until the next ``splat``)."""
+    48-B records built from them, the dispatch-order buffer and the cleared gradient records -- ~130 MB at 1 M Gaussians
+    until the next ``splat``)."""
     _splat_memo.clear()
 
 
@@ -287,17 +288,20 @@ def _memo_sig(tensors):
     return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
 
 
-def _memo_store(dev, st, tensors, width, height, rec, order):
-    _splat_memo[(dev.index, int(st.value or 0))] = (tensors, _memo_sig(tensors), width, height, _policy_name, rec, order)
+def _memo_store(dev, st, tensors, width, height, rec, order, gpack):
+    _splat_memo[(dev.index, int(st.value or 0))] = [tensors, _memo_sig(tensors), width, height, _policy_name, rec,
+                                                    order, gpack]
 
 
 def _memo_lookup(dev, st, tensors, width, height):
+    """-> (rec, order, gpack); gpack (zeroed by the forward draw) is handed out ONCE."""
     m = _splat_memo.get((dev.index, int(st.value or 0)))
     if m is None or m[2] != width or m[3] != height or m[4] != _policy_name:
-        return None, None
+        return None, None, None
     if m[1] != _memo_sig(tensors) or _memo_sig(m[0]) != m[1]:   # other tensors, or the remembered ones changed since
-        return None, None
-    return m[5], m[6]
+        return None, None, None
+    gpack, m[7] = m[7], None
+    return m[5], m[6], gpack
 
 
 def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
@@ -331,11 +335,15 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     # surface otherwise packs the same records twice per training step and rebuilds the per-tile work from `contrib`.
     rec = torch.empty((max(n, 1), 12), dtype=torch.float32, device=dev)
     order = torch.empty(lib.egs_tile_order_len(width, height), dtype=torch.int32, device=dev)
+    gpack = None
     if n > 0:
         _lib.check(lib.egs_pack_records(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
                                         _ptr(areas), pol, _ptr(rec), st))
         if _pol().footprint != 1:      # (pixel-box records also depend on `areas`, which this op mutates)
-            _memo_store(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order)
+            # the packed gradient records of a splatB that may follow: cleared on the side by the draw kernel (it is
+            # VALU-bound, the memory system idles), good for ONE backward pass
+            gpack = torch.empty((n, 12), dtype=torch.float32, device=dev)
+            _memo_store(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack)
 
     def draw_exact(patches):
         gsid = torch.empty(patches, dtype=torch.int32, device=dev)
@@ -343,7 +351,7 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges),
-                                          _ptr(gsid), _ptr(order), None, None, 0, 0, st))
+                                          _ptr(gsid), _ptr(order), _ptr(gpack), None, 0, 0, st))
         return gsid
 
     def render_exact():
@@ -385,8 +393,8 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, width, height, _ptr(rec), pol, _ptr(ws_bin),
                                               _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
-                                              _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), _ptr(order), None, None,
-                                              0, 0, st))
+                                              _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), _ptr(order), _ptr(gpack),
+                                              None, 0, 0, st))
     except BaseException:
         with ctx.lock:                       # the slot goes back: nothing will ever fetch it
             t.status = _fused._Ticket.FAILED
@@ -434,13 +442,14 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
     ws_bytes = lib.egs_splat_bwd_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     st = _stream()
-    rec, order = (None, None)
+    rec, order, gpack = (None, None, None)
     if n > 0 and pol.footprint != 1:   # (the pixel-box policy's records also depend on `areas`, which splat mutates)
-        rec, order = _memo_lookup(dev, st, (us, cinv2ds, alphas, colors), width, height)
+        rec, order, gpack = _memo_lookup(dev, st, (us, cinv2ds, alphas, colors), width, height)
     if rec is not None:     # the records (and the measured per-tile work) of the splat call these tensors came from
         _lib.check(lib.egs_splat_bwd_rec(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
                                          _ptr(final_tau), _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes,
-                                         _ptr(order), _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha), _ptr(d_color), st))
+                                         _ptr(order), _ptr(gpack), _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha),
+                                         _ptr(d_color), st))
     else:
         _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
                                      _ptr(colors), _ptr(areas), C.byref(pol), _ptr(contrib), _ptr(final_tau),

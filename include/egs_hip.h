@@ -161,8 +161,9 @@ int egs_pack_records(int n, int width, int height, const float* us, const float*
 int egs_splat_bwd_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                       const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                       const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
-                      const int32_t* tile_order /*nullable*/, float* dloss_dus, float* dloss_dcinv2ds,
-                      float* dloss_dalphas, float* dloss_dcolors, void* stream);
+                      const int32_t* tile_order /*nullable*/, float* grad_records /*nullable: zeroed by that draw*/,
+                      float* dloss_dus, float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors,
+                      void* stream);
 
 /* gsplatcu.splatB  (ext.cpp:20-32, gausplat.cu:114-159, kernel.cu:809-950).
  * Gradient outputs (fully written): dloss_dus[N,2], dloss_dcinv2ds[N,3],
