@@ -51,7 +51,10 @@ namespace egs {
 constexpr int RS_THREADS = 256;
 // items per thread: 16 (4096-item tiles) for long arrays; 8 for short ones, where 4096-item tiles would
 // leave fewer workgroups than there are CUs (1 M depth keys = 245 tiles)
-constexpr int64_t RS_SHORT = 5 << 19;              // <= 2.6 M items: 2048-item tiles (measured: 4 M patches prefer 4096)
+#ifndef EGS_RS_SHORT           // A/B knob
+#define EGS_RS_SHORT (5 << 19)
+#endif
+constexpr int64_t RS_SHORT = EGS_RS_SHORT;         // <= 2.6 M items: 2048-item tiles (measured: 4 M patches prefer 4096)
 static int rs_ipt(int64_t n) { return n <= RS_SHORT ? 8 : 16; }
 
 // `maxkey` (nullable, device): upper bound of all keys.  A pass whose digit is 0 for every key
@@ -121,7 +124,7 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
 // of 3 / 5 with the code below merely present): 1 = gather records on the way out (last pass of the depth sort),
 // 2 = write the tile ranges (last pass of the tile sort, EGS_RANGES_FOLD)
 template <int RS_IPT, int EXTRA>
-__global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
+__global__ __launch_bounds__(RS_THREADS) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_radix_scatter(
     const uint32_t* __restrict__ keys_in, const uint32_t* __restrict__ vals_in,
     uint32_t* __restrict__ keys_out, uint32_t* __restrict__ vals_out, int64_t n, int shift, uint32_t dmask,
     int nblocks, const uint32_t* __restrict__ hist, const uint32_t* __restrict__ sup,
@@ -142,8 +145,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
   if (n_dev) n = min(n, (int64_t)*n_dev);
   constexpr int RS_TILE = RS_THREADS * RS_IPT;       // items per workgroup
   constexpr int RS_WAVE_ITEMS = EGS_WAVE * RS_IPT;   // contiguous items per wave
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;   // (wave: a scalar)
   const int64_t blockbase = (int64_t)blockIdx.x * RS_TILE;
+  if (blockbase >= n) return;                  // (the launch covers the capacity of the list)
   if (maxkey && ((*maxkey >> shift) == 0u)) {  // identity pass: plain copy
 #pragma unroll
     for (int r = 0; r < RS_IPT; ++r) {
@@ -164,55 +168,102 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
   __shared__ uint32_t skey[RS_TILE], sval[RS_TILE];
 #pragma unroll
   for (int w = 0; w < 4; ++w) wcount[w][tid] = 0;
-  // global base of digit `tid` = (sum of the totals of smaller digits) + (same digit in earlier workgroups):
-  // superblock sums for the total and for the superblocks before this workgroup's, hist rows inside it
-  // (the loads of a group of 16 rows in flight at once: the rows are 1-KB lines out of L2, what counts is latency;
-  // 32 at once cost the kernel a resident wave per SIMD)
-  uint32_t dtotal = 0u, before = 0u;
+  const int64_t base = blockbase + (int64_t)wave * RS_WAVE_ITEMS;
+  uint32_t key[RS_IPT], val[RS_IPT], rank[RS_IPT];
+  // Global base of digit d = (sum of the totals of smaller digits) + (digit d in earlier workgroups): superblock sums
+  // for the total and for the superblocks before this workgroup's, hist rows inside its superblock.  Wave w takes
+  // rows w, w + 4, ... and every lane four digits (one dwordx4 per 1-KB row): for up to 32 superblocks the whole
+  // prefix is ONE group of loads, issued before the keys -- the counter the waits use retires loads in order, so a
+  // second dependent group behind the keys would wait for all of them.
+  // All addresses are clamped instead of guarded: without branches the compiler counts the loads in flight exactly
+  // and the ranking loop waits for key r only.
+  uint4 tot = make_uint4(0u, 0u, 0u, 0u), bef = tot;
   {
     const int sb = blockIdx.x / RS_SB, nsb = (nblocks + RS_SB - 1) / RS_SB;
-    for (int q0 = 0; q0 < nsb; q0 += 16) {
-      uint32_t v[16];
+    const uint4* sup4 = reinterpret_cast<const uint4*>(sup) + lane;
+    const uint4* hist4 = reinterpret_cast<const uint4*>(hist) + lane;
+    uint4 v[8], w[8];
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-      for (int r = 0; r < 16; ++r) v[r] = (q0 + r < nsb) ? sup[(size_t)(q0 + r) * 256 + tid] : 0u;
+    for (int r = 0; r < 8; ++r) v[r] = sup4[(size_t)min(wave + 4 * r, nsb - 1) * 64];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { dtotal += v[r]; if (q0 + r < sb) before += v[r]; }
+    for (int r = 0; r < 8; ++r) w[r] = hist4[(size_t)min(sb * RS_SB + wave + 4 * r, (int)blockIdx.x) * 64];
+    // ALL of the workgroup's keys and values are requested before anything waits.  (The ranking loop below goes
+    // through LDS every round; with the loads inside that loop each of its 16 rounds waited for its own global
+    // round trip.)
+    // (32-bit offsets from the workgroup's scalar base: one address register per round, shared by keys and values)
+    const uint32_t* kb = keys_in + blockbase;
+    const uint32_t* vb = vals_in + blockbase;
+    const uint32_t rlast = (uint32_t)min(n - blockbase, (int64_t)RS_TILE) - 1u;
+    uint32_t off[RS_IPT];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) off[r] = min((uint32_t)(wave * RS_WAVE_ITEMS + r * EGS_WAVE + lane), rlast);
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) key[r] = kb[off[r]];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) val[r] = vb[off[r]];   // (not waited for by the ranking)
+    __builtin_amdgcn_sched_barrier(0);   // (the instruction scheduler keeps this order)
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const int q = wave + 4 * r;
+      const uint32_t mt = q < nsb ? ~0u : 0u, mb = q < sb ? ~0u : 0u;
+      tot.x += v[r].x & mt; tot.y += v[r].y & mt; tot.z += v[r].z & mt; tot.w += v[r].w & mt;
+      bef.x += v[r].x & mb; bef.y += v[r].y & mb; bef.z += v[r].z & mb; bef.w += v[r].w & mb;
     }
-    for (int q0 = sb * RS_SB; q0 < (int)blockIdx.x; q0 += 16) {
-      uint32_t w[16];
 #pragma unroll
-      for (int r = 0; r < 16; ++r) w[r] = (q0 + r < (int)blockIdx.x) ? hist[(size_t)(q0 + r) * 256 + tid] : 0u;
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t mb = (sb * RS_SB + wave + 4 * r < (int)blockIdx.x) ? ~0u : 0u;
+      bef.x += w[r].x & mb; bef.y += w[r].y & mb; bef.z += w[r].z & mb; bef.w += w[r].w & mb;
+    }
+    for (int q0 = wave + 32; q0 < nsb; q0 += 32) {   // more than 32 superblocks (lists beyond 4 M patches)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) before += w[r];
+      for (int r = 0; r < 8; ++r) v[r] = sup4[(size_t)min(q0 + 4 * r, nsb - 1) * 64];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        const int q = q0 + 4 * r;
+        const uint32_t mt = q < nsb ? ~0u : 0u, mb = q < sb ? ~0u : 0u;
+        tot.x += v[r].x & mt; tot.y += v[r].y & mt; tot.z += v[r].z & mt; tot.w += v[r].w & mt;
+        bef.x += v[r].x & mb; bef.y += v[r].y & mb; bef.z += v[r].z & mb; bef.w += v[r].w & mb;
+      }
     }
   }
+  // the four waves' shares meet in LDS (skey / sval are free until the tile is reordered)
+  reinterpret_cast<uint4*>(skey)[wave * 64 + lane] = tot;
+  reinterpret_cast<uint4*>(sval)[wave * 64 + lane] = bef;
+  __syncthreads();
+  const uint32_t dtotal = skey[tid] + skey[256 + tid] + skey[512 + tid] + skey[768 + tid];
+  const uint32_t before = sval[tid] + sval[256 + tid] + sval[512 + tid] + sval[768 + tid];
   const uint32_t dig_ex = block256_exclusive_scan(dtotal, sm, nullptr);
   const uint32_t gbase = dig_ex + before;
 
-  const int64_t base = blockbase + (int64_t)wave * RS_WAVE_ITEMS;
-  uint32_t key[RS_IPT], val[RS_IPT], rank[RS_IPT];
-  volatile uint32_t* wc = wcount[wave];
-  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  // Ranking inside the wave.  peers = lanes of this wave holding the same digit (multi-split: one ballot per digit
+  // bit); the lane's rank among them comes from mbcnt, the lowest peer moves the wave's counter of that digit.
+  // The counters are read and written with wavefront-scope relaxed atomics: plain ds_read / ds_write, which one
+  // wave issues in order -- a `volatile` pointer here turned them into flat loads and stores with system-scope
+  // cache bits and a full wait after each, two LDS round trips through the flat path per round.
+  uint32_t* wc = wcount[wave];
+  const int nbits = __popc(dmask);
 #pragma unroll
   for (int r = 0; r < RS_IPT; ++r) {
     const int64_t idx = base + r * EGS_WAVE + lane;
     const bool valid = idx < n;
-    const uint32_t k = valid ? keys_in[idx] : 0u;
-    val[r] = valid ? vals_in[idx] : 0u;
-    const uint32_t d = (k >> shift) & dmask;
-    // peers = lanes of this wave holding the same digit (multi-split by ballots)
-    uint64_t peers = __ballot(valid);
+    const uint32_t d = (key[r] >> shift) & dmask;
+    const uint64_t vb = __ballot(valid);
+    uint32_t plo = (uint32_t)vb, phi = (uint32_t)(vb >> 32);
 #pragma unroll
     for (int b = 0; b < 8; ++b) {
-      const bool bit = (d >> b) & 1u;
-      const uint64_t bal = __ballot(bit);
-      peers &= bit ? bal : ~bal;
+      if (b >= nbits) break;                                           // (uniform: 13 tile bits are 7 + 6)
+      const uint32_t m = (uint32_t)((int32_t)(d << (31 - b)) >> 31);   // 0 or ~0: this lane's bit b
+      const uint64_t bal = __ballot(m != 0u);
+      plo &= ~((uint32_t)bal ^ m);            // bit set: keep the lanes in bal, clear: keep the others
+      phi &= ~((uint32_t)(bal >> 32) ^ m);
     }
+    const uint32_t below = __builtin_amdgcn_mbcnt_hi(phi, __builtin_amdgcn_mbcnt_lo(plo, 0u));
     uint32_t prev = 0;
-    if (valid) prev = wc[d];
-    const uint32_t below = (uint32_t)__popcll(peers & lt_mask);
-    if (valid && below == 0) wc[d] = prev + (uint32_t)__popcll(peers);  // lowest peer updates
-    key[r] = k;
+    if (valid) prev = __hip_atomic_load(&wc[d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    if (valid && below == 0)   // lowest peer updates
+      __hip_atomic_store(&wc[d], prev + (uint32_t)(__popc(plo) + __popc(phi)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
     rank[r] = prev + below;
   }
   __syncthreads();
@@ -256,16 +307,48 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_scatter(
   }
   const int64_t rem = n - blockbase;
   const int nvalid = rem < RS_TILE ? (int)rem : RS_TILE;
+  if constexpr (EXTRA == 1) {   // eight rounds of gathers in flight before their first store
+    constexpr int G = 8;
 #pragma unroll
-  for (int r = 0; r < RS_IPT; ++r) {
-    const int slot = r * RS_THREADS + tid;
-    if (slot < nvalid) {
-      const uint32_t k = skey[slot];
-      const uint32_t pos = gadj[(k >> shift) & dmask] + (uint32_t)slot;
-      const uint32_t v = sval[slot];
-      keys_out[pos] = k;
-      vals_out[pos] = v;
-      if constexpr (EXTRA == 1) { const uint4 c = gsrc[v]; gdst[pos] = c; cdst[pos] = cr_count(c); }
+    for (int r0 = 0; r0 < RS_IPT; r0 += G) {
+      uint32_t ok[G], ov[G], op[G];
+      uint4 oc[G];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const int slot = (r0 + r) * RS_THREADS + tid;
+        ok[r] = 0u; ov[r] = 0u; op[r] = 0u; oc[r] = make_uint4(0u, 0u, 0u, 0u);
+        if (slot < nvalid) {
+          ok[r] = skey[slot];
+          op[r] = gadj[(ok[r] >> shift) & dmask] + (uint32_t)slot;
+          ov[r] = sval[slot];
+          oc[r] = gsrc[ov[r]];
+        }
+      }
+      // (one wait for all eight here; otherwise the compiler, which counts loads and stores on the same in-order
+      // counter and gives up at the branches, waits for the previous round's STORES before each round)
+#pragma unroll
+      for (int r = 0; r < G; ++r) asm volatile("" ::"v"(oc[r].x), "v"(oc[r].y), "v"(oc[r].z), "v"(oc[r].w));
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const int slot = (r0 + r) * RS_THREADS + tid;
+        if (slot < nvalid) {
+          keys_out[op[r]] = ok[r];
+          vals_out[op[r]] = ov[r];
+          gdst[op[r]] = oc[r];
+          cdst[op[r]] = cr_count(oc[r]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r) {
+      const int slot = r * RS_THREADS + tid;
+      if (slot < nvalid) {
+        const uint32_t k = skey[slot];
+        const uint32_t pos = gadj[(k >> shift) & dmask] + (uint32_t)slot;
+        keys_out[pos] = k;
+        vals_out[pos] = sval[slot];
+      }
     }
   }
 }
