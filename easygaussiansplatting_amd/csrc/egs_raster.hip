@@ -67,7 +67,7 @@ static int rs_ipt(int64_t n) { return n <= RS_SHORT ? 8 : 16; }
 // RS_SB - 1 hist rows of its superblock and the <= 32 superblock rows: no row-scan launch in between (it was a
 // 256-workgroup kernel over <= 1 MB, 5-6 us of launch and drain four times per step).
 //
-// mk_parts != NULL (first pass of the depth sort): workgroup 0 also folds the per-workgroup maxima of the keys
+// mk_parts != NULL (first pass of the depth sort): one extra workgroup folds the per-workgroup maxima of the keys
 // (maxkey[1 + i], left by the kernel that produced them) into maxkey[0] -- the later passes test it -- and into
 // up to two more places (mk_out: next to P in device memory; mk_host: the page-locked mailbox slot).  The first
 // pass itself never consults maxkey: with shift 0 it could only detect "every key is 0", where the pass is the
@@ -86,6 +86,9 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
   __shared__ uint32_t h[256];
   __shared__ uint32_t sm[4];
   const int tid = threadIdx.x;
+  // (mk_parts: the launch has ONE MORE workgroup, the first; it does the fold and nothing else -- as a side job of
+  // a counting workgroup the 3906 partial maxima made that workgroup the last to finish, 2.5 us after the others)
+  const int blk = mk_parts ? (int)blockIdx.x - 1 : (int)blockIdx.x;
   if (mk_parts && blockIdx.x == 0) {
     uint32_t mk = 0u;
     for (int i = tid; i < nparts; i += 256) mk = max(mk, mk_parts[1 + i]);
@@ -99,12 +102,13 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
       if (mk_out) *mk_out = m;
       if (mk_host) *mk_host = m;
     }
+    return;
   }
   if (!mk_parts && maxkey && ((*maxkey >> shift) == 0u)) return;
   if (n_dev) n = min(n, (int64_t)*n_dev);   // `n` is a capacity: the real count is on the device
   h[tid] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * RS_TILE;
+  const int64_t base = (int64_t)blk * RS_TILE;
 #pragma unroll
   for (int r = 0; r < RS_IPT; ++r) {
     const int64_t idx = base + r * RS_THREADS + tid;
@@ -112,8 +116,8 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
   }
   __syncthreads();
   const uint32_t c = h[tid];
-  hist[(size_t)blockIdx.x * 256 + tid] = c;          // block-major: row = workgroup
-  if (c) atomicAdd(&sup[(size_t)(blockIdx.x / RS_SB) * 256 + tid], c);
+  hist[(size_t)blk * 256 + tid] = c;          // block-major: row = workgroup
+  if (c) atomicAdd(&sup[(size_t)(blk / RS_SB) * 256 + tid], c);
 }
 
 // Scatter with local reordering: every item's stable rank inside the workgroup's 4096-item tile
@@ -401,10 +405,10 @@ static int radix_sort(int64_t n, uint32_t* keys, uint32_t* vals, uint32_t* keys_
     uint32_t* sup = w.sup + (size_t)pass * div_up(w.nblocks, RS_SB) * 256;    // this pass's (zeroed) superblock sums
     uint32_t* mkp = first ? mk_parts : (uint32_t*)nullptr;
     if (rs_ipt(n) == 8)
-      EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
+      EGS_LAUNCH("k_radix_hist", k_radix_hist<8>, dim3(w.nblocks + (mkp ? 1 : 0)), dim3(RS_THREADS), s, ki, n, shift, dmask,
                  w.nblocks, w.hist, sup, mk, n_dev, mkp, nparts, mk_out, mk_host);
     else
-      EGS_LAUNCH("k_radix_hist", k_radix_hist<16>, dim3(w.nblocks), dim3(RS_THREADS), s, ki, n, shift, dmask,
+      EGS_LAUNCH("k_radix_hist", k_radix_hist<16>, dim3(w.nblocks + (mkp ? 1 : 0)), dim3(RS_THREADS), s, ki, n, shift, dmask,
                  w.nblocks, w.hist, sup, mk, n_dev, mkp, nparts, mk_out, mk_host);
     ++pass;
     int32_t* ro = last ? ranges_out : (int32_t*)nullptr;
@@ -759,18 +763,30 @@ __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* 
                                                      int32_t* __restrict__ ranges,
                                                      const uint32_t* __restrict__ n_dev) {
   if (n_dev) P = min(P, (int64_t)*n_dev);
-  const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (p >= P) return;
-  const uint32_t cur = tkeys[p];
-  if (p == 0) ranges[2 * (size_t)cur] = 0;
-  else {
-    const uint32_t prv = tkeys[p - 1];
-    if (prv != cur) {
-      ranges[2 * (size_t)prv + 1] = (int32_t)p;
-      ranges[2 * (size_t)cur] = (int32_t)p;
+  const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // four keys per thread: one dwordx4
+  if (p0 >= P) return;
+  uint32_t k[5];
+  k[0] = p0 > 0 ? tkeys[p0 - 1] : 0u;
+  if (p0 + 4 <= P) {
+    const uint4 v = *reinterpret_cast<const uint4*>(tkeys + p0);
+    k[1] = v.x; k[2] = v.y; k[3] = v.z; k[4] = v.w;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) k[1 + i] = (p0 + i < P) ? tkeys[p0 + i] : 0u;
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int64_t p = p0 + i;
+    if (p < P) {
+      const uint32_t cur = k[1 + i];
+      if (p == 0) ranges[2 * (size_t)cur] = 0;
+      else if (k[i] != cur) {
+        ranges[2 * (size_t)k[i] + 1] = (int32_t)p;
+        ranges[2 * (size_t)cur] = (int32_t)p;
+      }
+      if (p == P - 1) ranges[2 * (size_t)cur + 1] = (int32_t)P;
     }
   }
-  if (p == P - 1) ranges[2 * (size_t)cur + 1] = (int32_t)P;
 }
 
 // Longest-list-first dispatch order of the tiles for the two draw kernels.  A tile is one wave whose run
@@ -1964,7 +1980,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                       EGS_RANGES_FOLD ? patch_range_per_tile : (int32_t*)nullptr);
   if (rc) return rc;
   if (!EGS_RANGES_FOLD)
-    EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 256)), dim3(256), s, patches, D.tkeys,
+    EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 1024)), dim3(256), s, patches, D.tkeys,
                patch_range_per_tile, patches_dev);
   if (order_ready && tile_order && tile_order_mode(0) > 0 && dp.T <= TILE_ORDER_MAX_T) {
     dp.order = tile_order;
