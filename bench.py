@@ -154,6 +154,10 @@ def main():
                     help="camera views every rank renders per step (forward + backward each, gradients accumulated; "
                          "ONE gradient exchange per step): 8 on one GPU = BASELINE configs[3]'s eight ring views; on N "
                          "GPUs it amortises the 236-MB all-reduce over V renders")
+    ap.add_argument("--view-streams", type=int, default=2,
+                    help="with --views-per-rank > 1: HIP streams the views of a rank are dealt to (1 = one after the "
+                         "other on the caller's stream); every stream accumulates its own gradient buffer, added at the "
+                         "end of the step")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
     ap.add_argument("--extras", action="store_true",
@@ -234,11 +238,26 @@ def main():
     deferred = a.mode == "fused" and not a.immediate and overlap is None
     ev_render, ev_done = [], []
     redone = [0]
+    # V > 1: the views of a rank go round-robin to --view-streams HIP streams (dist_views.ViewStreams: a view is a
+    # chain of dependent kernels, a quarter of it latency-bound; two views on two streams fill each other's gaps)
+    n_lanes = min(V, max(1, a.view_streams)) if (a.mode == "fused" and V > 1) else 1
+    vs = DV.ViewStreams([params[k] for k in order], n_lanes) if n_lanes > 1 else None
+    us_lane = [us0] + [torch.zeros((sc.n, 2), device=dev, requires_grad=True) for _ in range(n_lanes - 1)]
 
     def render_step():
         for p in params.values():
             p.grad = None
-        us0.grad = None
+        for u in us_lane:
+            u.grad = None
+        if vs is not None:
+            vs.begin()
+            with fused_path.accumulate_in_kernel():
+                for i, c in enumerate(my_cams):
+                    with vs.lane(i) as lv:
+                        image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_lane[vs.lane_index(i)], c)
+                        image.backward(dl)
+            vs.finish()
+            return image
         # V views: forward + backward each; from the second view on the chain-rule kernel adds this view's gradients
         # to the leaves' .grad itself (fused.accumulate_in_kernel) instead of autograd accumulating fresh tensors
         with (fused_path.accumulate_in_kernel() if (V > 1 and a.mode == "fused") else contextlib.nullcontext()):
@@ -558,7 +577,7 @@ def main():
                                       sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim], a.mode,
                                       ", RCCL all-reduce of 59 fp32 grads/Gaussian" if world > 1 else ""),
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
-                       "views_per_step": world * V, "views_per_rank": V, "policy": "gsplatcu", "mode": a.mode,
+                       "views_per_step": world * V, "views_per_rank": V, "view_streams": n_lanes, "policy": "gsplatcu", "mode": a.mode,
                        "validation": "deferred (commit per step)" if deferred else "immediate",
                        "preconditioning": "%d untimed steps before the warm-up steps (clock ramp)" % max(0, a.ramp_steps),
                        "tile_dispatch": "forward: by the work measured at this camera's previous render (list "

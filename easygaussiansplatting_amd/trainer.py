@@ -22,6 +22,7 @@ What is new (the reference renders one view per optimizer step on one GPU)
 """
 from __future__ import annotations
 
+import contextlib
 import math
 from typing import Dict, List, Sequence
 
@@ -75,8 +76,12 @@ def make_optimizer(p, fused=True):
 class Trainer:
     def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
                  scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0,
-                 fused_activations: bool = True):
+                 fused_activations: bool = True, view_streams: int = 2):
         self.device = device
+        # a rank's views of a step go round-robin to this many HIP streams (dist_views.ViewStreams); 1 = one after
+        # the other on the caller's stream
+        self.view_streams = max(1, int(view_streams))
+        self._vs = None
         # True: GSRawFunction (activations inside the HIP kernels); False: torch activations + GSFunction,
         # the reference's structure (gsmodel.py:198-210)
         self.fused_activations = fused_activations
@@ -95,28 +100,51 @@ class Trainer:
         self.vis_count = torch.zeros(n, dtype=torch.int32, device=device)
         self.redone_steps = 0        # steps rendered twice because a view outgrew the enqueue-ahead buffers
 
+    _KEYS = ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")
+
     def _render_views(self, mine, n_views):
-        """forward + loss + backward of this rank's views; leaves accumulate the mean over ALL views of the step."""
+        """forward + loss + backward of this rank's views; leaves accumulate the mean over ALL views of the step.
+        Two or more views: dealt to ``view_streams`` HIP streams (one gradient accumulator and one set of
+        statistics per stream, added up at the end)."""
         n = self.params["pws"].shape[0]
-        loss_sum = torch.zeros((), device=self.device)
-        gnorm = torch.zeros(n, device=self.device)
-        count = torch.zeros(n, dtype=torch.int32, device=self.device)
-        for v in mine:
-            us = torch.zeros((n, 2), device=self.device, requires_grad=True)     # gsmodel.py:198-199
-            if self.fused_activations:
-                p = self.params
-                image, mask = GSRawFunction.apply(p["pws"], p["low_shs"], p["high_shs"], p["alphas_raw"],
-                                                  p["scales_raw"], p["rots_raw"], us, self.cams[v])
-            else:
-                image, mask = GSFunction.apply(*activate(self.params), us, self.cams[v])
-            loss = gau_loss(image, self.gts[v])
-            (loss / n_views).backward()
-            loss_sum += loss.detach()
-            with torch.no_grad():                       # per-view ||dL/du|| (undo the 1/len scaling)
-                g = torch.norm(us.grad * n_views, dim=-1)
-                gnorm += torch.where(mask, g, torch.zeros_like(g))
-                count += mask.to(torch.int32)
-        return loss_sum, gnorm, count
+        lanes = min(self.view_streams, len(mine)) if str(self.device).startswith("cuda") else 1
+        vs = None
+        if lanes > 1:
+            if self._vs is None or self._vs.n != lanes or \
+                    any(a is not self.params[k] for a, k in zip(self._vs.params, self._KEYS)):
+                self._vs = DV.ViewStreams([self.params[k] for k in self._KEYS], lanes)
+            vs = self._vs
+            vs.begin()
+        loss_sum = [torch.zeros((), device=self.device) for _ in range(lanes)]
+        gnorm = [torch.zeros(n, device=self.device) for _ in range(lanes)]
+        count = [torch.zeros(n, dtype=torch.int32, device=self.device) for _ in range(lanes)]
+        if vs is not None:      # the accumulators above were zeroed on the caller's stream: the lanes start after that
+            for s in vs.streams:
+                s.wait_stream(torch.cuda.current_stream())
+        for i, v in enumerate(mine):
+            k = i % lanes
+            with (vs.lane(i) if vs is not None else contextlib.nullcontext(None)) as lv:
+                p = dict(zip(self._KEYS, lv)) if lv is not None else self.params
+                us = torch.zeros((n, 2), device=self.device, requires_grad=True)     # gsmodel.py:198-199
+                if self.fused_activations:
+                    image, mask = GSRawFunction.apply(p["pws"], p["low_shs"], p["high_shs"], p["alphas_raw"],
+                                                      p["scales_raw"], p["rots_raw"], us, self.cams[v])
+                else:
+                    image, mask = GSFunction.apply(*activate(p), us, self.cams[v])
+                loss = gau_loss(image, self.gts[v])
+                (loss / n_views).backward()
+                loss_sum[k] += loss.detach()
+                with torch.no_grad():                       # per-view ||dL/du|| (undo the 1/len scaling)
+                    g = torch.norm(us.grad * n_views, dim=-1)
+                    gnorm[k] += torch.where(mask, g, torch.zeros_like(g))
+                    count[k] += mask.to(torch.int32)
+        if vs is not None:
+            vs.finish()                                    # the caller's stream now follows every lane
+            for k in range(1, lanes):
+                for t in (loss_sum[k], gnorm[k], count[k]):
+                    t.record_stream(torch.cuda.current_stream())
+                loss_sum[0] += loss_sum[k]; gnorm[0] += gnorm[k]; count[0] += count[k]
+        return loss_sum[0], gnorm[0], count[0]
 
     def step(self, view_ids: Sequence[int], sync: bool = True):
         """One optimizer step on the mean gradient over ``view_ids`` (all ranks pass the same list, which must

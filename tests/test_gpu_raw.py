@@ -158,3 +158,65 @@ def test_accumulate_in_kernel_equals_autograd_accumulation(raw):
         scale = float(x.abs().max())
         assert scale > 0 and float((x - y).abs().max()) <= 2e-5 * scale     # atomics order of k_draw_bwd only
     assert not a[0][:30].any() and not b[0][:30].any()
+
+
+@pytest.mark.parametrize("n_streams", [2, 3])
+@pytest.mark.parametrize("raw", [False, True])
+def test_view_streams_equal_sequential_views(raw, n_streams):
+    """``dist_views.ViewStreams``: the views of a step dealt to 2 / 3 HIP streams (each with its own leaf aliases and
+    gradient accumulator, added by ``finish()``) give the gradients of the same views rendered one after another --
+    up to the order of the float sums -- and every view's image bit for bit; twice in a row through the SAME object
+    (the second step must not see the first one's accumulators)."""
+    import numpy as np
+    from easygaussiansplatting_amd import dist_views as DV, fused, scene as S
+    from easygaussiansplatting_amd.function import Camera, GSFunction, GSRawFunction
+    from easygaussiansplatting_amd.trainer import raw_params_from_scene
+    GSFunction.mode = "fused"
+    H, W, V = 96, 160, 5
+    sc = S.small_scene(6000, W, H, 48, seed=37)
+    sc.pws[:20, 2] = -9.0                                  # (culled in some of the views)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, V, radius=5.0)]
+    dls = [torch.from_numpy(S.normal(8, v, (3, H, W)).astype(np.float32)).cuda() / (3 * H * W) for v in range(V)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    F = GSRawFunction if raw else GSFunction
+
+    def leaves():
+        if raw:
+            p = raw_params_from_scene(sc, "cuda")
+            return [p[k] for k in ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")]
+        return [dev(a).requires_grad_(True) for a in (sc.pws, sc.shs, sc.alphas.reshape(-1, 1), sc.scales, sc.rots)]
+
+    L = leaves()
+    us = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+    ref_imgs = []
+    with fused.accumulate_in_kernel():
+        for cam, dl in zip(cams, dls):
+            img, _ = F.apply(*L, us, cam)
+            img.backward(dl)
+            ref_imgs.append(img.detach().clone())
+    torch.cuda.synchronize()
+    ref = [t.grad.clone() for t in L]
+
+    M = leaves()
+    vs = DV.ViewStreams(M, n_streams)
+    for rep in range(2):
+        for t in M:
+            t.grad = None
+        uss = [torch.zeros((sc.n, 2), device="cuda", requires_grad=True) for _ in range(n_streams)]
+        imgs = [None] * V
+        vs.begin()
+        with fused.accumulate_in_kernel():
+            for i, (cam, dl) in enumerate(zip(cams, dls)):
+                with vs.lane(i) as lv:
+                    img, _ = F.apply(*lv, uss[vs.lane_index(i)], cam)
+                    img.backward(dl)
+                    imgs[i] = img.detach()
+        vs.finish()
+        torch.cuda.synchronize()
+        for a, b in zip(ref_imgs, imgs):
+            assert torch.equal(a, b)
+        for x, t in zip(ref, M):
+            scale = float(x.abs().max())
+            assert scale > 0 and float((x - t.grad).abs().max()) <= 3e-5 * scale, (rep, float((x - t.grad).abs().max()), scale)
+        dus = sum(u.grad for u in uss if u.grad is not None)
+        assert float((dus - us.grad).abs().max()) <= 3e-5 * float(us.grad.abs().max())
