@@ -438,13 +438,21 @@ __device__ __forceinline__ void stage_rows_out(const float* row, float* __restri
           make_float4(row[4 * j], row[4 * j + 1], row[4 * j + 2], row[4 * j + 3]);
     __syncthreads();
     float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + (size_t)K * base);
+    // accum: the old values of all the thread's pieces are requested first (clamped addresses, no branches) -- read
+    // at its use inside the loop below, each piece waited for its own load AND for the previous piece's store
+    float4 o[RS::Q];
+    if (accum) {
+      const int flast = rows * RS::Q - 1;
+#pragma unroll
+      for (int j = 0; j < RS::Q; ++j) o[j] = d4[min(tid + 256 * j, flast)];
+    }
 #pragma unroll
     for (int j = 0; j < RS::Q; ++j) {
       const int f = tid + 256 * j;
       const int r = f / RS::Q, c = f - r * RS::Q;
       if (r < rows) {
         float4 v = *reinterpret_cast<const float4*>(lds + r * RS::STRIDE + 4 * c);
-        if (accum) { const float4 o = d4[f]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+        if (accum) { v.x += o[j].x; v.y += o[j].y; v.z += o[j].z; v.w += o[j].w; }
         d4[f] = v;
       }
     }
@@ -490,10 +498,20 @@ __device__ __forceinline__ void stage_span_out(const float* row, float* __restri
   __syncthreads();
   const int total = rows * K, nq = total >> 2;
   float4* __restrict__ d4 = reinterpret_cast<float4*>(dst + (size_t)K * base);
-  for (int f = tid; f < nq; f += 256) {
-    float4 v = reinterpret_cast<const float4*>(lds)[f];
-    if (accum) { const float4 o = d4[f]; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
-    d4[f] = v;
+  constexpr int NI = (K + 3) / 4;            // pieces per thread: 256 K / 4 float4 over 256 threads
+  float4 o[NI];
+  if (accum && nq > 0) {                     // (old values first, as in stage_rows_out)
+#pragma unroll
+    for (int j = 0; j < NI; ++j) o[j] = d4[min(tid + 256 * j, nq - 1)];
+  }
+#pragma unroll
+  for (int j = 0; j < NI; ++j) {
+    const int f = tid + 256 * j;
+    if (f < nq) {
+      float4 v = reinterpret_cast<const float4*>(lds)[f];
+      if (accum) { v.x += o[j].x; v.y += o[j].y; v.z += o[j].z; v.w += o[j].w; }
+      d4[f] = v;
+    }
   }
   for (int f = 4 * nq + tid; f < total; f += 256)
     dst[(size_t)K * base + f] = lds[f] + (accum ? dst[(size_t)K * base + f] : 0.f);
@@ -674,27 +692,44 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
 #pragma unroll
   for (int k = 0; k < K; ++k) gsh[k] = 0.f;
   if (i < n) {
+    // Every input of the row is requested here, before anything is used: with the parameter loads behind the depth
+    // test, the Jacobian row at its use and the old gradients (accum) at theirs, a row went through four dependent
+    // round trips to memory (the ISA had a full wait after each group).
     const float4 ga = gpack[3 * (size_t)i], gb = gpack[3 * (size_t)i + 1], gc = gpack[3 * (size_t)i + 2];
+    const float depth_i = depths[i];
+    const f3 pw = ld3(pws + 3 * (size_t)i);
+    float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+    f3 s = ld3(scales + 3 * (size_t)i);
+    float W[9];
+    if constexpr (JW) load_row<9>(dcolor_dpws + 9 * (size_t)i, W);
+    float al_raw = 0.f;
+    if constexpr (RAW) al_raw = alphas[i];
+    float4 o_rot = make_float4(0.f, 0.f, 0.f, 0.f);
+    f3 o_scale = {0.f, 0.f, 0.f}, o_pw = {0.f, 0.f, 0.f};
+    float o_alpha = 0.f;
+    if (accum) {
+      o_rot = *reinterpret_cast<const float4*>(dL_drot + 4 * (size_t)i);
+      o_scale = ld3(dL_dscale + 3 * (size_t)i);
+      o_pw = ld3(dL_dpw + 3 * (size_t)i);
+      o_alpha = dL_dalpha[i];
+    }
     const f3 gcol = {ga.y, ga.z, ga.w};
     const float gu0 = gb.x, gu1 = gb.y;
     const f3 gci = {gb.z, gb.w, gc.x};
     if constexpr (RAW) {
-      const float al = act_alpha(alphas[i]);
-      dL_dalpha[i] = ga.x * al * (1.f - al) + (accum ? dL_dalpha[i] : 0.f);   // sigmoid'
+      const float al = act_alpha(al_raw);
+      dL_dalpha[i] = ga.x * al * (1.f - al) + o_alpha;   // sigmoid'
     } else {
-      dL_dalpha[i] = ga.x + (accum ? dL_dalpha[i] : 0.f);
+      dL_dalpha[i] = ga.x + o_alpha;
     }
     dL_du[2 * (size_t)i] = gu0; dL_du[2 * (size_t)i + 1] = gu1;
-    if (pp.near_cull && depths[i] < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
+    if (pp.near_cull && depth_i < EGS_MIN_DEPTH) {  // culled: never drawn, all gradients are zero
       if (!accum) {
         st3(dL_dpw + 3 * (size_t)i, {0.f, 0.f, 0.f});
         st3(dL_dscale + 3 * (size_t)i, {0.f, 0.f, 0.f});
         st4(dL_drot + 4 * (size_t)i, {0.f, 0.f, 0.f, 0.f});
       }
     } else {
-      const f3 pw = ld3(pws + 3 * (size_t)i);
-      float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
-      f3 s = ld3(scales + 3 * (size_t)i);
       float qnorm = 1.f;
       if constexpr (RAW) { q = act_rot(q, qnorm); s = act_scale(s); }
       const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
@@ -722,10 +757,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         gs = {gs.x * s.x, gs.y * s.y, gs.z * s.z};
       }
       if (accum) {
-        const float4 o = *reinterpret_cast<const float4*>(dL_drot + 4 * (size_t)i);
-        gq = {gq.w + o.x, gq.x + o.y, gq.y + o.z, gq.z + o.w};
-        const f3 os = ld3(dL_dscale + 3 * (size_t)i);
-        gs = {gs.x + os.x, gs.y + os.y, gs.z + os.z};
+        gq = {gq.w + o_rot.x, gq.x + o_rot.y, gq.y + o_rot.z, gq.z + o_rot.w};
+        gs = {gs.x + o_scale.x, gs.y + o_scale.y, gs.z + o_scale.z};
       }
       st4(dL_drot + 4 * (size_t)i, gq);      // eq (3)
       st3(dL_dscale + 3 * (size_t)i, gs);    // eq (4)
@@ -740,14 +773,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
       for (int c = 0; c < NC; ++c) {
         gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
       }
-      float W[9];
-      if constexpr (JW) load_row<9>(dcolor_dpws + 9 * (size_t)i, W);
-      else sh_jac_dpw<NC>(d, sh, W);
+      if constexpr (!JW) sh_jac_dpw<NC>(d, sh, W);
       float* opw = dL_dpw + 3 * (size_t)i;  // eq (7)
+      const float opw_old[3] = {o_pw.x, o_pw.y, o_pw.z};
 #pragma unroll
       for (int k = 0; k < 3; ++k)
         opw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
-                 gcol.z * W[6 + k] + (accum ? opw[k] : 0.f);
+                 gcol.z * W[6 + k] + opw_old[k];
     }
   }
   if constexpr (RAW) {

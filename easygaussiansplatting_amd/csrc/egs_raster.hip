@@ -109,10 +109,17 @@ __global__ __launch_bounds__(RS_THREADS) void k_radix_hist(const uint32_t* __res
   h[tid] = 0;
   __syncthreads();
   const int64_t base = (int64_t)blk * RS_TILE;
+  if (base < n) {
+    // all keys of the thread requested before the first LDS atomic (clamped addresses, no branches: with the load
+    // inside the guarded loop every one of the 16 rounds waited for its own round trip to memory)
+    const uint32_t* kb = keys + base;
+    const uint32_t rlast = (uint32_t)min(n - base, (int64_t)RS_TILE) - 1u;
+    uint32_t k[RS_IPT];
 #pragma unroll
-  for (int r = 0; r < RS_IPT; ++r) {
-    const int64_t idx = base + r * RS_THREADS + tid;
-    if (idx < n) atomicAdd(&h[(keys[idx] >> shift) & dmask], 1u);
+    for (int r = 0; r < RS_IPT; ++r) k[r] = kb[min((uint32_t)(r * RS_THREADS + tid), rlast)];
+#pragma unroll
+    for (int r = 0; r < RS_IPT; ++r)
+      if ((uint32_t)(r * RS_THREADS + tid) <= rlast) atomicAdd(&h[(k[r] >> shift) & dmask], 1u);
   }
   __syncthreads();
   const uint32_t c = h[tid];
