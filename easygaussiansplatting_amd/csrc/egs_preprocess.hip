@@ -525,6 +525,13 @@ __device__ __forceinline__ void stage_span_out(const float* row, float* __restri
 // RAW: rots/scales/alphas are the un-activated tensors, shs = low_shs [N,3], shs_high = high_shs [N,K-3]
 // JW: also write dcolor/dpw (dcolor_dpws) for the backward pass -- a training render; the SH Jacobian keeps ~40 more
 // registers alive, so these instances are not pinned to 8 waves per SIMD
+// A/B knob: rotation / scale / opacity requested together with the position.  The unpinned JW instance then also
+// hoists all twelve SH loads (101 VGPRs, 5 waves per SIMD, ONE round trip per row instead of six): measured equal
+// to the 58-register form within the noise of three same-box pairs (0.860-0.868 ms per step either way) -- the
+// kernel is bound by the memory system's queues, not by the latency of a row.  Off.
+#ifndef EGS_PRE_EARLY_LOADS
+#define EGS_PRE_EARLY_LOADS 0
+#endif
 template <int NC, bool RAW, bool JW>
 #ifndef EGS_PRE_JW_WAVES       // A/B knob: minimum waves per SIMD of the JW instances (register cap 512 / waves)
 #define EGS_PRE_JW_WAVES 1
@@ -569,6 +576,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (
   uint4 crec = make_uint4(0u, 0u, 0u, 0u);
   if (i < n) {
     const f3 pw = ld3(pws + 3 * (size_t)i);
+#if EGS_PRE_EARLY_LOADS
+    // (requested with the position, not after the colour: one dependent round trip less per row)
+    float4 q_in = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
+    f3 sc_in = ld3(scales + 3 * (size_t)i);
+    const float alpha_in = (rec || bo.br) ? alphas[i] : 0.f;
+#endif
     float col[3];
     {  // colour has no depth test in the reference (kernel.cu:619-725)
       if constexpr (RAW) {
@@ -586,8 +599,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (
     int rx = 0, ry = 0;
     if (!(pp.near_cull && P.pc.z < EGS_MIN_DEPTH)) {
       u0 = P.u0; u1 = P.u1; depth = P.pc.z;
+#if EGS_PRE_EARLY_LOADS
+      float4 q = q_in;
+      f3 sc = sc_in;
+#else
       float4 q = *reinterpret_cast<const float4*>(rots + 4 * (size_t)i);
       f3 sc = ld3(scales + 3 * (size_t)i);
+#endif
       if constexpr (RAW) { float nrm; q = act_rot(q, nrm); sc = act_scale(sc); }
       const Cov3 c3 = cov3d_f(q, sc);
       const Cov2 c2 = cov2d_f(c3.c, P.pc, Rcw, pp.fx, pp.fy, pp.limx, pp.limy, pp.clamp_fov);
@@ -598,7 +616,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (
         radius_f(c2.c, pp.radius_mode, rx, ry);
       }
     }
+#if EGS_PRE_EARLY_LOADS
+    const float alpha_act = (rec || bo.br) ? (RAW ? act_alpha(alpha_in) : alpha_in) : 0.f;
+#else
     const float alpha_act = (rec || bo.br) ? (RAW ? act_alpha(alphas[i]) : alphas[i]) : 0.f;
+#endif
     if (bo.br) {  // getRects + depth key of the binning stage, straight from registers (no k_bin_count pass)
       uint4 rect;
       bool cull;

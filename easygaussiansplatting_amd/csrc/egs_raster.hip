@@ -1433,16 +1433,21 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
   int cont[4];
   int bmax[4];  // wave-uniform: largest contrib of block k -> entries >= bmax[k] are inert for it
   int maxcont = 0;
+  // (all twenty loads requested first, from clamped addresses: guarded and inside the loop below, every block's
+  // five waited for their own round trip before the next block's were issued)
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int px = pxb[k & 1], py = pyb[k >> 1];
-    tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f; lq[k] = 0.f;
-    if (px < p.W && py < p.H) {
-      const size_t pix = (size_t)py * p.W + px;
-      tau[k] = final_tau[pix];
-      cont[k] = contrib[pix];
-      lr[k] = dLdg[pix]; lg[k] = dLdg[HW + pix]; lb[k] = dLdg[2 * HW + pix];
-    }
+    const size_t pix = (size_t)min(py, p.H - 1) * p.W + min(px, p.W - 1);
+    tau[k] = final_tau[pix];
+    cont[k] = contrib[pix];
+    lr[k] = dLdg[pix]; lg[k] = dLdg[HW + pix]; lb[k] = dLdg[2 * HW + pix];
+    lq[k] = 0.f;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = pxb[k & 1], py = pyb[k >> 1];
+    if (!(px < p.W && py < p.H)) { tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f; }
     int mx = cont[k];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
