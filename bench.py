@@ -160,6 +160,7 @@ def main():
                          "end of the step")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
+    ap.add_argument("--no-ring8", action="store_true", help="skip the extra eight-ring-views step (configs[3])")
     ap.add_argument("--extras", action="store_true",
                     help="also time render+loss+backward and the whole optimizer step (other dL/dimage, so their "
                          "kernel launches would blur a rocprofv3 summary of the headline step)")
@@ -244,20 +245,28 @@ def main():
     vs = DV.ViewStreams([params[k] for k in order], n_lanes) if n_lanes > 1 else None
     us_lane = [us0] + [torch.zeros((sc.n, 2), device=dev, requires_grad=True) for _ in range(n_lanes - 1)]
 
+    def render_views(cams_v, vs_v, us_v, dl_v):
+        """forward + backward of the given views on the lanes of ``vs_v``; the parameters' .grad = sum over the views"""
+        for p in params.values():
+            p.grad = None
+        for u in us_v:
+            u.grad = None
+        vs_v.begin()
+        with fused_path.accumulate_in_kernel():
+            for i, c in enumerate(cams_v):
+                with vs_v.lane(i) as lv:
+                    image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_v[vs_v.lane_index(i)], c)
+                    image.backward(dl_v)
+        vs_v.finish()
+        return image
+
     def render_step():
+        if vs is not None:
+            return render_views(my_cams, vs, us_lane, dl)
         for p in params.values():
             p.grad = None
         for u in us_lane:
             u.grad = None
-        if vs is not None:
-            vs.begin()
-            with fused_path.accumulate_in_kernel():
-                for i, c in enumerate(my_cams):
-                    with vs.lane(i) as lv:
-                        image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_lane[vs.lane_index(i)], c)
-                        image.backward(dl)
-            vs.finish()
-            return image
         # V views: forward + backward each; from the second view on the chain-rule kernel adds this view's gradients
         # to the leaves' .grad itself (fused.accumulate_in_kernel) instead of autograd accumulating fresh tensors
         with (fused_path.accumulate_in_kernel() if (V > 1 and a.mode == "fused") else contextlib.nullcontext()):
@@ -440,6 +449,38 @@ def main():
             p.grad = None
         torch.cuda.empty_cache()
 
+    # BASELINE configs[3] on this one GPU: the eight ring views as ONE step (views on --view-streams streams, gradients
+    # accumulated, no exchange) -- an extra, outside the timed region
+    ring8 = None
+    if a.mode == "fused" and not a.no_ring8 and rank == 0 and world == 1 and V == 1 and not a.immediate:
+        cams8 = [Camera.from_scene(c, dev) for c in S.ring_cameras(sc.cam, 8)]
+        lanes8 = max(1, min(8, a.view_streams))
+        vs8 = DV.ViewStreams([params[k] for k in order], lanes8)
+        us8 = [torch.zeros((sc.n, 2), device=dev, requires_grad=True) for _ in range(lanes8)]
+        dl8 = dl / 8
+
+        def step8():
+            with fused_path.deferred() as d8:
+                render_views(cams8, vs8, us8, dl8)
+                if d8.commit():          # (a view outgrew the buffers learnt so far: exact redo)
+                    render_views(cams8, vs8, us8, dl8)
+        for _ in range(6):
+            step8()
+        torch.cuda.synchronize()
+        t80 = time.perf_counter()
+        for _ in range(12):
+            step8()
+        torch.cuda.synchronize()
+        ms8 = (time.perf_counter() - t80) / 12 * 1e3
+        ring8 = {"views": 8, "view_streams": lanes8, "ms_per_step": round(ms8, 4),
+                 "Mpix/s": round(8 * HW / (ms8 * 1e-3) / 1e6, 2),
+                 "what": "forward + backward of the 8 ring cameras of BASELINE configs[3] as one step on this GPU "
+                         "(12 steps after 6 untimed; host clock around a synchronize)"}
+        del vs8, us8
+        for p in params.values():
+            p.grad = None
+        torch.cuda.empty_cache()
+
     # achievable HBM bandwidth on THIS box: a device-to-device float4 copy ("confirm on the box
     # with a device-to-device copy kernel and report both")
     peak_measured = None
@@ -594,6 +635,7 @@ def main():
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
             "ops_ms_per_step": None if ops_ms is None else round(ops_ms, 4),
             "ops_kernels": ops_kernels,
+            "ring_views_8": ring8,
             "fwd_loss_bwd": None if loss_step_ms is None else {
                 "ms": round(loss_step_ms, 4), "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
             "train_step": train_extra, "exchange": exch,

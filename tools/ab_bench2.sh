@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out; export PYTHONDONTWRITEBYTECODE=1
 cp easygaussiansplatting_amd/libegs_hip.so /tmp/libegs_keep.so
 for r in $(seq 1 "$rounds"); do for so in ab/*.so; do
   cp "$so" easygaussiansplatting_amd/libegs_hip.so
-  timeout 200 python bench.py --cpu-sample 0 --steps 30 --no-ops 2>/dev/null | tail -1 > /tmp/ab.json
+  timeout 200 python bench.py --cpu-sample 0 --steps 30 --no-ops --no-ring8 2>/dev/null | tail -1 > /tmp/ab.json
   python - "$so" "$r" <<'PY'
 import json, sys
 d = json.load(open("/tmp/ab.json"))

@@ -9,6 +9,8 @@ export PYTHONDONTWRITEBYTECODE=1
 python $R/bench.py > $O/bench.json 2> $O/bench.err
 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/bench_20_5.json 2>> $O/bench.err
 python $R/bench.py --views-per-rank 8 --steps 10 --warmup 3 --ramp-steps 20 --cpu-sample 0 --no-ops > $O/bench_v8.json 2>> $O/bench.err
+python $R/bench.py --views-per-rank 8 --view-streams 1 --steps 10 --warmup 3 --ramp-steps 20 --cpu-sample 0 --no-ops > $O/bench_v8_one_stream.json 2>> $O/bench.err
+EGS_FORCE_EXCHANGE=1 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-ops --no-ring8 > $O/bench_forced_exchange.json 2>> $O/bench.err
 # the same command under rocprofv3 kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --cpu-sample 0 --no-ops > $O/bench_under_rocprof.json 2>/tmp/ks.err
 find /tmp/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
@@ -41,6 +43,8 @@ python tools/make_pmc_traffic.py $O/ops_pmc_fetch_write.json - - $O/ops_pmc_traf
 tail -1 $O/bench.json | cut -c1-400
 tail -1 $O/bench_20_5.json | cut -c1-200
 tail -1 $O/bench_v8.json | cut -c1-200
+tail -1 $O/bench_v8_one_stream.json | cut -c1-200
+tail -1 $O/bench_forced_exchange.json | cut -c1-200
 head -14 $O/kernel_stats.csv | cut -c1-200
 tail -3 $O/step_timeline.txt
 tail -3 $O/ops_step_timeline.txt
