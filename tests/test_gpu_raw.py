@@ -220,3 +220,42 @@ def test_view_streams_equal_sequential_views(raw, n_streams):
             assert scale > 0 and float((x - t.grad).abs().max()) <= 3e-5 * scale, (rep, float((x - t.grad).abs().max()), scale)
         dus = sum(u.grad for u in uss if u.grad is not None)
         assert float((dus - us.grad).abs().max()) <= 3e-5 * float(us.grad.abs().max())
+
+
+@pytest.mark.parametrize("fused_act", [False, True])
+def test_trainer_view_streams_same_steps_as_one_stream(fused_act):
+    """``Trainer.step`` with a rank's views on three streams (one gradient accumulator and one set of densification
+    statistics per stream) takes the steps of the one-stream trainer: losses, statistics and parameters after three
+    optimizer steps over five views agree to the order of the float sums; densification then re-allocates the
+    parameters and the next step re-aliases the lanes."""
+    import numpy as np
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer
+    sc = S.small_scene(20000, 256, 144, 48, seed=4)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 5, radius=5.0)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    with torch.no_grad():
+        gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+    outs = []
+    for lanes in (1, 3):
+        start = S.small_scene(20000, 256, 144, 48, seed=4)
+        start.shs[:, :3] += 0.5
+        tr = Trainer(start, cams, gts, max_steps=100, scene_size=4.0, fused_activations=fused_act, view_streams=lanes)
+        losses = [tr.step([0, 1, 2, 3, 4]) for _ in range(3)]
+        stats = (tr.grad_accum.cpu().numpy(), tr.vis_count.cpu().numpy())
+        params = {k: v.detach().cpu().numpy() for k, v in tr.params.items()}
+        tr.density.grad_threshold = float(np.percentile(stats[0] / np.maximum(stats[1], 1), 80))
+        n0 = tr.params["pws"].shape[0]
+        tr.densify()
+        assert tr.params["pws"].shape[0] != n0
+        after = tr.step([4, 3, 2, 1, 0])
+        assert np.isfinite(after) and all(torch.isfinite(v).all() for v in tr.params.values())
+        outs.append((losses, stats, params, tr.params["pws"].shape[0]))
+    np.testing.assert_allclose(outs[0][0], outs[1][0], rtol=2e-5)
+    assert (outs[0][1][1] == outs[1][1][1]).all()                     # visibility counts: integers, exact
+    np.testing.assert_allclose(outs[0][1][0], outs[1][1][0], rtol=2e-4, atol=1e-9)
+    for k in outs[0][2]:
+        a, b = outs[0][2][k], outs[1][2][k]
+        assert np.abs(a - b).max() < 2e-4 * max(1e-3, np.abs(a).max()), k
+    assert outs[0][3] == outs[1][3]                                    # the same Gaussians were cloned / split / pruned

@@ -22,7 +22,7 @@ start.pws += 0.01 * S.normal(6, 4, (n, 3)).astype(np.float32)
 tr = Trainer(start, cams, gts, max_steps=2000, scene_size=4.0)
 tr.density.grad_threshold = 2e-7
 t0 = time.time()
-hist = tr.fit(epochs=24, views_per_step=1, densify_every=4, reset_alpha_every=12, densify_until=20)
+hist = tr.fit(epochs=24, views_per_step=int(os.environ.get("VPS", 1)), densify_every=4, reset_alpha_every=12, densify_until=20)
 torch.cuda.synchronize()
 print("epochs %d, %.1f s, loss %.4f -> %.4f, gaussians %d -> %d, densifications %d" % (
     len(hist), time.time() - t0, hist[0], hist[-1], n, tr.params["pws"].shape[0], tr.density.round))
