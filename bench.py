@@ -158,6 +158,9 @@ def main():
                     help="with --views-per-rank > 1: HIP streams the views of a rank are dealt to (1 = one after the "
                          "other on the caller's stream); every stream accumulates its own gradient buffer, added at the "
                          "end of the step")
+    ap.add_argument("--overlap-exchange", action="store_true",
+                    help="several ranks, one view each: start the all-reduce of the gradient chunks inside the backward "
+                         "pass (dist_views.ChunkedExchange) instead of one flat all-reduce after it")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
     ap.add_argument("--no-ring8", action="store_true", help="skip the extra eight-ring-views step (configs[3])")
@@ -232,7 +235,10 @@ def main():
     # (only with ONE backward pass per step: a second view's `.grad +=` would race the in-flight all-reduce of the
     # same storage, dist_views.ChunkedExchange; with V > 1 the views are accumulated first and exchanged as one
     # flat buffer -- one collective for V renders)
-    overlap = DV.ChunkedExchange(world) if exchange and a.mode == "fused" and V == 1 else None
+    # --overlap-exchange (off by default since the second half of round 3): the window it overlaps is the chain-rule
+    # kernel (61 us, three of four chunks), and the price is renders validated at once plus four under-filled
+    # launches: on one GPU the step reads 0.99 ms with it and 0.87 without
+    overlap = DV.ChunkedExchange(world) if (exchange and a.mode == "fused" and V == 1 and a.overlap_exchange) else None
     # deferred validation needs every rank to take the same decision about a redo BEFORE any collective is
     # issued; with the overlapped exchange the collectives start inside backward, so renders are then
     # validated at once (the step is exchange-bound there and the host has time to spare)
@@ -297,8 +303,15 @@ def main():
             else:
                 flat = fused_path.flat_grad_buffer([params[k] for k in order])
                 if flat is not None:      # the fused backward hands out slices of one buffer: ONE all-reduce
-                    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-                    flat.div_(float(world))
+                    if world > 1 and dist.get_backend() == "nccl":
+                        # RCCL scales inside the collective (ncclAvg): no separate 472-MB div_ pass (80 us per step
+                        # at N = 1 M).  Not with ONE rank (EGS_FORCE_EXCHANGE): there AVG runs a 0.39-ms copy kernel
+                        # where SUM is a no-op
+                        dist.all_reduce(flat, op=dist.ReduceOp.AVG)
+                    else:
+                        dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+                        if world > 1:
+                            flat.div_(float(world))
                 else:
                     grads = [params[k].grad for k in order]
                     hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]

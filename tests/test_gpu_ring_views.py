@@ -12,7 +12,7 @@ Per view:   * invariants of the tile lists (they tile the patch array, every lis
               ``O.draw_backward`` + ``O.chain_rule``.
 Then:       * gradients accumulated by autograd over the 8 views in one process == sum of the per-view gradients;
             * the same 8 views through the overlapped exchange path (``ChunkedExchange`` on a one-rank process group,
-              what ``EGS_FORCE_EXCHANGE=1 python bench.py`` runs; chunk counts 2, 4, 8 in turn) give the same mean.
+              what ``EGS_FORCE_EXCHANGE=1 python bench.py --overlap-exchange`` runs; chunk counts 2, 4, 8 in turn) give the same mean.
 """
 import os
 import socket
