@@ -178,9 +178,13 @@ def test_backward_gpu_script_equivalent(gsc):
 
 
 # --------------------------------------------------------------------------- building blocks (bit-exact)
-@pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 100_003, 1_500_000])
+# 2 621 440 / 2 621 441: the last array sorted in 2048-item tiles and the first in 4096-item ones; both and 5 000 000
+# have MORE than 32 superblocks of 32 workgroups (the scatter kernel's one-group prefix then takes a second round)
+@pytest.mark.parametrize("n", [1, 63, 64, 65, 4095, 4096, 4097, 100_003, 1_500_000, 2_621_440, 2_621_441, 5_000_000])
 @pytest.mark.parametrize("bits", [(0, 32), (0, 13), (8, 24), (0, 8)])
 def test_radix_sort_is_a_stable_sort(gsc, n, bits):
+    if n > 2_000_000 and bits not in ((0, 32), (0, 13)):
+        pytest.skip("the big arrays run two of the four digit layouts")
     import ctypes as C
     from easygaussiansplatting_amd import _lib
     lib = _lib.load()
