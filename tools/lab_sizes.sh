@@ -2,7 +2,7 @@
 # other problem sizes of the same synthetic scene (robustness + DESIGN 5 "other sizes")
 cd $GRAFT_REPO_ROOT
 O=$GRAFT_REPO_ROOT/gpurun_out/sizes; mkdir -p $O
-B="python bench.py --steps 20 --warmup 5 --ramp-steps 60 --cpu-sample 0 --no-ops"
+B="python bench.py --steps 20 --warmup 5 --ramp-steps 60 --cpu-sample 0 --no-ops --no-ring8"
 $B --gaussians 4000000 > $O/4m_1080.json 2>$O/4m.err
 $B --width 3840 --height 2160 > $O/1m_4k.json 2>$O/4k.err
 $B --gaussians 8000000 --width 3840 --height 2160 > $O/8m_4k.json 2>$O/8m.err
