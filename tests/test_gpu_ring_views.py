@@ -11,6 +11,7 @@ Per view:   * invariants of the tile lists (they tile the patch array, every lis
             * the five parameter gradients (+ dL/du) of the Gaussians complete inside sampled tiles against
               ``O.draw_backward`` + ``O.chain_rule``.
 Then:       * gradients accumulated by autograd over the 8 views in one process == sum of the per-view gradients;
+            * the 8 views dealt to three HIP streams (``ViewStreams``, deferred validation) give the same sum;
             * the same 8 views through the overlapped exchange path (``ChunkedExchange`` on a one-rank process group,
               what ``EGS_FORCE_EXCHANGE=1 python bench.py --overlap-exchange`` runs; chunk counts 2, 4, 8 in turn) give the same mean.
 """
@@ -162,6 +163,29 @@ def test_eight_ring_views_full_size():
         tot = sum(pv[k] for pv in per_view)
         scale = float(tot.abs().max())
         assert float((leaves[k].grad - tot).abs().max()) <= 1e-5 * scale, k      # atomics order only
+
+    # ---- the same 8 views dealt to three streams, deferred validation (what ``bench.py --views-per-rank 8`` and the
+    # ``ring_views_8`` leg of the default run time): the sum over the lanes' accumulators
+    vleaves = [P[k].detach().requires_grad_(True) for k in NAMES]
+    vs = DV.ViewStreams(vleaves, 3)
+    uss = [torch.zeros((sc.n, 2), device="cuda", requires_grad=True) for _ in range(3)]
+    for rep in range(2):                       # (the second step starts from empty accumulators, capacities learnt)
+        for t in vleaves:
+            t.grad = None
+        with fused.deferred() as d:
+            vs.begin()
+            with fused.accumulate_in_kernel():
+                for v in range(N_VIEWS):
+                    with vs.lane(v) as lv:
+                        image, _ = GSFunction.apply(*lv, uss[vs.lane_index(v)], cams[v])
+                        image.backward(dls[v])
+            vs.finish()
+            assert not d.commit()
+        torch.cuda.synchronize()
+        assert fused.flat_grad_buffer(vleaves) is not None
+        for k, t in zip(NAMES, vleaves):
+            ref = leaves[k].grad
+            assert float((t.grad - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (rep, k)
 
     # ---- the same views through the overlapped exchange (one-rank group: the collectives run, sums are unchanged)
     started = False
