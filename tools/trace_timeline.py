@@ -19,6 +19,9 @@ rows.sort()
 starts = [i for i, r in enumerate(rows) if "k_preprocess_fwd" in r[2] and ", 2>(" not in r[2]]
 if len(starts) < 2:      # the seven-op surface: a step starts with project
     starts = [i for i, r in enumerate(rows) if "k_project" in r[2]]
+if "--by-bwd" in sys.argv:   # (two-stream forward: k_preprocess_fwd runs twice per step) a step ends with the chain rule
+    ends = [i for i, r in enumerate(rows) if "k_preprocess_bwd" in r[2]]
+    starts = [ends[-3] + 1, ends[-2] + 1]
 i0, i1 = starts[-2], starts[-1]
 step = rows[i0:i1]
 t0 = step[0][0]
