@@ -151,3 +151,16 @@ def test_host_lr_schedule_matches_reference_samples():
     g = load_golden("g8_densify.npz")
     got = [expon_lr(int(s), 1e-4 * 2.5, 1e-6 * 2.5, 3000, delay_mult=0.01) for s in g["lr_steps"]]
     np.testing.assert_allclose(got, g["lr_values"], rtol=1e-12)
+
+
+def test_bench_flags_of_the_contract_and_of_this_build():
+    """``python bench.py --help`` runs without a GPU and lists the driver's flags (--gpus / --steps / --warmup) and the
+    ones DESIGN / profiles quote (--views-per-rank, --view-streams, --overlap-exchange, --no-ops, --no-ring8)."""
+    import subprocess
+    import sys
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--help"], capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    for flag in ("--gpus", "--steps", "--warmup", "--views-per-rank", "--view-streams", "--overlap-exchange",
+                 "--no-ops", "--no-ring8", "--cpu-sample", "--ramp-steps"):
+        assert flag in out.stdout, flag
