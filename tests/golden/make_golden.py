@@ -45,10 +45,10 @@ from oracle import gs_oracle as O  # noqa: E402
 from tests.golden.make_golden_scene import stage_scene  # noqa: E402
 
 
-def save(name, doc, **arrays):
-    path = os.path.join(HERE, name)
-    np.savez_compressed(path, __doc__=np.array(doc), **arrays)
-    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+from tests.golden import _recipe  # noqa: E402
+from tests.golden._recipe import save  # noqa: E402
+
+_recipe.assert_reference(ref_a, ref_b)      # NOT this repository's same-named modules
 
 
 def g1():
@@ -277,6 +277,7 @@ def g7():
     """gsplat/pytorch_ssim.py gau_loss + torch autograd gradient (CPU) on seeded image pairs."""
     import torch
     import gsplat.pytorch_ssim as ref_l
+    _recipe.assert_reference(ref_l)
     out = {}
     for tag, (H, W) in (("a", (37, 53)), ("b", (16, 64)), ("c", (9, 7))):
         x = (0.5 + 0.35 * S.normal(31, 1, (3, H, W))).astype(np.float32)
@@ -300,10 +301,14 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--g6", action="store_true", help="also run the 1M/1080p reference forward (~1 min)")
+    ap.add_argument("--check", action="store_true",
+                    help="regenerate into a temp dir and compare with the committed fixtures (exit 1 on a difference)")
     a = ap.parse_args()
+    _recipe.begin(a.check)
     todo = [g1, g2, g3, g4, g5, g7] + ([g6] if a.g6 else [])
     for fn in todo:
         if a.only and fn.__name__ not in a.only.split(","):
             continue
         print("==", fn.__name__)
         fn()
+    sys.exit(_recipe.finish())

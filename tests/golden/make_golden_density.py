@@ -36,6 +36,9 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 import gsplat.gsmodel as ref_m  # noqa: E402
+from tests.golden import _recipe  # noqa: E402
+
+_recipe.assert_reference(ref_m)             # NOT compat/gsplat/gsmodel.py (the code under test)
 
 NAMES = ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")
 LRS = (0.001, 0.001, 0.001 / 20, 0.05, 0.005, 0.001)      # gsmodel.py:114-127
@@ -165,12 +168,12 @@ def main():
     doc = ("G8: gsplat/gsmodel.py densification on %d Gaussians, CPU torch %s; thresholds of GSModel(1.0, .): "
            "alpha 0.005, big 0.1, scale 0.01, grad 4e-7.  torch.normal replaced by mean + std*unit_noise[orig_idx]."
            % (n, torch.__version__))
-    path = os.path.join(HERE, "g8_densify.npz")
-    np.savez_compressed(path, __doc__=np.array(doc), **out)
-    print("wrote %s (%.1f KB): remain %d clone %d split %d -> %d" % (
-        path, os.path.getsize(path) / 1024, int(out["expect_remain"].sum()), len(out["expect_clone"]),
-        len(out["expect_split"]), out["post_pws"].shape[0]))
+    _recipe.save("g8_densify.npz", doc, **out)
+    print("remain %d clone %d split %d -> %d" % (int(out["expect_remain"].sum()), len(out["expect_clone"]),
+                                                 len(out["expect_split"]), out["post_pws"].shape[0]))
 
 
 if __name__ == "__main__":
+    _recipe.begin("--check" in sys.argv[1:])
     main()
+    sys.exit(_recipe.finish())

@@ -88,6 +88,10 @@ sys.path.insert(0, REF)
 
 import gsplat.gau_io as ref_io  # noqa: E402
 import gsplat.read_write_model as ref_rw  # noqa: E402
+sys.path.insert(1, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from tests.golden import _recipe  # noqa: E402
+
+_recipe.assert_reference(ref_io, ref_rw)
 
 
 # ---- input files ---------------------------------------------------------------------------------
@@ -203,10 +207,10 @@ def main():
 
     doc = ("G9: reference gau_io.load_ply / matrix_to_quaternion / rotate_gaussian / get_example_gs and "
            "read_write_model.read_model / read_points_bin_as_gau on synthesised files (bytes included).")
-    path = os.path.join(HERE, "g9_io.npz")
-    np.savez_compressed(path, __doc__=np.array(doc), **out)
-    print("wrote %s (%.1f KB)" % (path, os.path.getsize(path) / 1024))
+    _recipe.save("g9_io.npz", doc, **out)
 
 
 if __name__ == "__main__":
+    _recipe.begin("--check" in sys.argv[1:])
     main()
+    sys.exit(_recipe.finish())

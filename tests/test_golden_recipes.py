@@ -1,0 +1,36 @@
+"""The parity pin must be reproducible from HEAD: every fixture recipe that imports the reference is re-run with
+``--check`` (regenerate into a temp dir, compare with the committed ``tests/golden/*.npz`` array by array) -- in the
+build container only, where ``/root/reference`` exists.  The recipes themselves assert that what they imported came
+from the reference checkout (``_recipe.assert_reference``), not from this repository's same-named modules."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+from tests.conftest import GOLDEN, REPO
+
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="reference checkout only exists in the build container")
+
+
+@pytest.mark.parametrize("recipe,args", [
+    ("make_golden.py", []),                                   # G1-G5, G7
+    ("make_golden.py", ["--g6", "--only", "g6"]),             # G6: the reference's forward_cpu pipeline at 1 M / 1080p
+    ("make_golden_density.py", []),                           # G8
+    ("make_golden_io.py", []),                                # G9
+])
+def test_recipe_regenerates_the_committed_fixture(recipe, args):
+    env = dict(os.environ, PYTHONDONTWRITEBYTECODE="1", MPLBACKEND="Agg")
+    env.pop("PYTHONPATH", None)
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, recipe), "--check"] + args, cwd=REPO, env=env,
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    assert "CHECK ok" in r.stdout
+
+
+def test_guard_rejects_a_module_that_is_not_the_reference():
+    from tests.golden import _recipe
+    import easygaussiansplatting_amd.scene as not_ref
+    with pytest.raises(RuntimeError, match="not from"):
+        _recipe.assert_reference(not_ref)

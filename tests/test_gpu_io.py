@@ -197,8 +197,16 @@ def test_forward_gpu_script_counterpart(tmp_path):
 def test_reference_module_names_carry_a_train_py_style_loop(tmp_path):
     """The loop of the reference's train.py:30-83 written against the reference's OWN module names
     (gsplat.gsmodel / gsplat.pytorch_ssim / gsplat.gau_io / gsplat.gausplat_dataset, torch.optim.Adam):
-    with this repository on the path those names resolve to the MI355X implementations."""
+    with ``<repo>/compat`` on the path (the opt-in of INTEGRATION.md 1b) those names resolve to the MI355X
+    implementations."""
+    import sys
     import torch.optim as optim
+    from tests.conftest import REPO
+    compat = os.path.join(REPO, "compat")
+    if compat not in sys.path:
+        sys.path.insert(0, compat)
+    for k in [k for k in sys.modules if k == "gsplat" or k.startswith("gsplat.")]:
+        del sys.modules[k]
     from easygaussiansplatting_amd import gsplatcu as gsc
     from easygaussiansplatting_amd import scene as S
     from easygaussiansplatting_amd.function import Camera, render

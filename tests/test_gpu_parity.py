@@ -1,14 +1,17 @@
 """GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on
 the same seeded inputs and against the golden fixtures generated from the
 reference.  Tolerances are the reference's own acceptance rule
-(backward_cpu.py:61-65: |a-b| < 1e-4 abs) for values, and
-|a-b| <= 1e-4*max(1,|ref|_max) for accumulated gradients."""
+(backward_cpu.py:61-65: |a-b| < 1e-4 abs) for values of O(1), and the RELATIVE rule of
+tests/gradcheck.py for accumulated gradients (max error <= 2e-4 of the largest entry; on the
+entries above 1 % of it: median relative error <= 1e-4, none beyond 5e-3 except counted
+threshold-flip Gaussians) -- an absolute bound says nothing about gradients of O(1e-5)."""
 import numpy as np
 import pytest
 
 from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
 from tests.conftest import load_golden, ref_check
+from tests.gradcheck import assert_grad_close
 
 pytestmark = pytest.mark.gpu
 
@@ -31,11 +34,6 @@ def dev(a, dtype=np.float32):
 
 def host(t):
     return t.detach().cpu().numpy()
-
-
-def close(a, b, tol=1e-4):
-    a = np.asarray(a, np.float64); b = np.asarray(b, np.float64)
-    return np.abs(a - b).max() <= tol * max(1.0, np.abs(b).max())
 
 
 def gpu_stages(gsc, sc, calc_J, policy):
@@ -175,6 +173,12 @@ def test_backward_gpu_script_equivalent(gsc):
     f_pw, f_sh, f_sc, f_rot = gsc.chain_rule(d_us, d_ci, d_co, Rcw, dci, d3, dq, ds, dsh, du, dpc, dpw)
     assert ref_check(host(f_rot)[:, None], g["dloss_drots"]) and ref_check(host(f_sc)[:, None], g["dloss_dscales"])
     assert ref_check(host(f_sh)[:, None], g["dloss_dshs"]) and ref_check(host(f_pw)[:, None], g["dloss_dpws"])
+    # the reference's absolute 1e-4 is AT the size of these gradients (4.5e-4 .. 9e-3): the relative rule on top
+    for got, k in ((d_us, "dloss_dus"), (d_ci, "dloss_dcinv2ds"), (d_al, "dloss_dalphas"), (d_co, "dloss_dcolors"),
+                   (drots, "dloss_drots"), (dscales, "dloss_dscales"), (dshs, "dloss_dshs"), (dpws, "dloss_dpws"),
+                   (f_rot[:, None], "dloss_drots"), (f_sc[:, None], "dloss_dscales"), (f_sh[:, None], "dloss_dshs"),
+                   (f_pw[:, None], "dloss_dpws")):
+        assert_grad_close(host(got), g[k], "g3:" + k)
 
 
 # --------------------------------------------------------------------------- building blocks (bit-exact)
@@ -238,7 +242,7 @@ def test_exclusive_scan(gsc, n, use_gather):
 
 
 # --------------------------------------------------------------------------- splat, policy G
-def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=True, seed=3):
+def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=True, seed=3, tag=None):
     cam = sc.cam
     g = gpu_stages(gsc, sc, False, policy)
     d_before = host(g["depths"]).copy(); a_before = host(g["areas"]).copy()
@@ -282,26 +286,25 @@ def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=
                           host(g["alphas"]), host(g["colors"]), host(contrib), host(tau), dl,
                           host(g["areas"]), opol)
     for a, b, nm in zip(o_g, grads, ("dus", "dcinv", "dalpha", "dcolor")):
-        b = host(b).reshape(a.shape)
-        assert close(b, a, 2e-4), (nm, np.abs(a - b).max(), np.abs(a).max())
+        assert_grad_close(host(b).reshape(a.shape), a, "%s:%s" % (tag or "splat", nm))
 
 
 def test_splat_10k_policy_g(gsc):
-    _splat_and_check(gsc, S.small_scene())
+    _splat_and_check(gsc, S.small_scene(), tag="10k")
 
 
 def test_splat_ragged_image_and_sh3(gsc):
     """Image size not a multiple of 16, SH degree 3, Gaussians partly off screen."""
-    _splat_and_check(gsc, S.small_scene(3000, 203, 117, 48, seed=5))
+    _splat_and_check(gsc, S.small_scene(3000, 203, 117, 48, seed=5), tag="ragged")
 
 
 def test_splat_dense_long_lists(gsc):
     """Few tiles, thousands of entries per tile: multi-chunk lists + early termination."""
-    _splat_and_check(gsc, S.small_scene(20000, 64, 48, 3, seed=9))
+    _splat_and_check(gsc, S.small_scene(20000, 64, 48, 3, seed=9), tag="dense")
 
 
 def test_splat_policy_a_tile_lists_and_blend(gsc):
-    _splat_and_check(gsc, S.small_scene(5000, 256, 256, 3, seed=2), "forward_cpu", O.POLICY_A)
+    _splat_and_check(gsc, S.small_scene(5000, 256, 256, 3, seed=2), "forward_cpu", O.POLICY_A, tag="policy_a")
 
 def _needles(n=6000, seed=33):
     """Long thin Gaussians at every angle: the level-set ellipse fills little of its bounding box."""
@@ -312,7 +315,7 @@ def _needles(n=6000, seed=33):
 
 
 def test_splat_needles(gsc):
-    _splat_and_check(gsc, _needles())
+    _splat_and_check(gsc, _needles(), tag="needles")
 
 
 @pytest.mark.parametrize("case", ["giants", "ties", "one_tile"])
@@ -329,7 +332,7 @@ def test_splat_adversarial_binning(gsc, case):
     else:
         sc.pws[:, :2] = sc.pws[:, :2] * 0.001                # all in front of the principal point
         sc.scales[:] = 0.002
-    _splat_and_check(gsc, sc)
+    _splat_and_check(gsc, sc, tag=case)
 
 
 
@@ -346,7 +349,7 @@ def test_g5_fixture_raster(gsc):
     assert (host(contrib) != g["contrib"]).mean() < 0.01
     grads = gsc.splatB(H, W, us, cinv, al, depths, col, contrib, tau, ranges, gsid, dev(g["dloss_dgammas"]))
     for b, k in zip(grads, ("dloss_dus", "dloss_dcinv2ds", "dloss_dalphas", "dloss_dcolors")):
-        assert close(host(b).reshape(g[k].shape), g[k], 2e-4), k
+        assert_grad_close(host(b).reshape(g[k].shape), g[k], "g5:" + k)
 
 
 # --------------------------------------------------------------------------- forward_cpu.py parity (G4)
@@ -474,7 +477,7 @@ def test_chain_rule_kernel_equals_batched_matmuls(gsc):
     got = gsc.chain_rule(gus, gci, gco, Rcw, *[g[k] for k in names])
     want = _bmm_chain(gus, gci, gco, Rcw, g)
     for a, b, nm in zip(got, want, ("dpws", "dshs", "dscales", "drots")):
-        assert close(host(a), host(b), 2e-5), nm
+        assert_grad_close(host(a), host(b), "chain_rule_vs_bmm:" + nm, tol_max=2e-5, med_rel=2e-6, max_rel=1e-3)
 
 
 @pytest.mark.parametrize("K", [48, 3])
@@ -511,10 +514,11 @@ def test_gsfunction_fused_equals_ops_equals_oracle(gsc, K):
         assert np.abs(img - img_f).max() < 2e-6 and np.array_equal(mask, mask_f)
         for k in g_f:
             assert g[k].shape == g_f[k].shape
-            assert close(g[k], g_f[k], 2e-5), (mode, k)                     # atomics order + fma contraction only
+            # atomics order + fma contraction only
+            assert_grad_close(g[k], g_f[k], "fused_vs_ops[%d]:%s" % (K, k), tol_max=2e-5, med_rel=1e-5, max_rel=1e-3)
     for k in ("pws", "shs", "alphas", "scales", "rots", "us"):
         assert g_f[k].shape == (sc.n,) + o_g[k].shape[1:]
-        assert close(g_f[k], o_g[k], 2e-4), (k, np.abs(g_f[k] - o_g[k]).max(), np.abs(o_g[k]).max())
+        assert_grad_close(g_f[k], o_g[k], "gsfunction[%d]:%s" % (K, k))
     assert not g_f["pws"][:40].any() and not g_f["shs"][:40].any()          # culled Gaussians get zero gradients
 
 
@@ -556,7 +560,7 @@ def test_fused_culled_lists_all_rect_sizes_vs_oracle(gsc):
     assert (d >= 1e-4).sum() <= 6 and d.max() < 5e-3, ((d >= 1e-4).sum(), d.max())        # threshold flips, counted
     got = {k: host(v.grad) for k, v in P.items()} | {"us": host(us0.grad)}
     for k in ("pws", "shs", "alphas", "scales", "rots", "us"):
-        assert close(got[k], o_g[k], 3e-4), (k, np.abs(got[k] - o_g[k]).max(), np.abs(o_g[k]).max())
+        assert_grad_close(got[k], o_g[k], "culled_lists:" + k)
     # the lists themselves: every form of the record is in use, nothing that blends is missing
     o_us, o_ci, o_col, o_depths, o_areas = _oracle_2d(sc, sc.cam)
     d_marked = o_depths.astype(np.float32).copy()
@@ -659,9 +663,9 @@ def test_full_size_policy_g_sampled_tiles_and_invariants(gsc, big):
         np.add.at(inp, gs[rg[t, 0]:rg[t, 1]], 1)
     full = ids_in[allp[ids_in] == inp[ids_in]]
     assert full.size > 20
-    for a, b in zip(o_g, grads):
+    for a, b, nm in zip(o_g, grads, ("dus", "dcinv", "dalpha", "dcolor")):
         b = host(b).reshape(a.shape)
-        assert close(b[full], a[full], 2e-4)
+        assert_grad_close(b[full], a[full], "full_size_ops:" + nm)
 
 
 def _oracle_2d(sc, cam, rows=None, calc_J=False):
@@ -795,8 +799,7 @@ def test_full_size_fused_and_raw_paths(gsc, big):
     got = {k: host(v.grad)[full] for k, v in P.items()} | {"us": host(us0.grad)[full]}
     for k in want:
         assert got[k].shape == want[k].shape, k
-        assert close(got[k], want[k], 2e-4), (k, np.abs(got[k] - want[k]).max(), np.abs(want[k]).max())
-        assert np.abs(want[k]).max() > 0, k
+        assert_grad_close(got[k], want[k], "full_size_fused:" + k)
     # --- raw path at the same size: activations inside the kernels == torch activations around the fused path
     a = torch.from_numpy(sc.alphas.astype(np.float32)).clamp(1e-4, 1 - 1e-4)
     raw = dict(pws=dev(sc.pws), low_shs=dev(sc.shs[:, :3]), high_shs=dev(sc.shs[:, 3:]),
@@ -824,10 +827,8 @@ def test_full_size_fused_and_raw_paths(gsc, big):
         d = np.abs(x - y).max(0)
         assert (d >= 2e-5).mean() < 2e-5 and d.max() < 5e-3, ((d >= 2e-5).sum(), d.max())
     for k in names:
-        scale = max(1.0, float(np.abs(ga[k]).max()))
-        assert np.abs(ga[k] - gb[k]).max() <= 2e-4 * scale, (k, np.abs(ga[k] - gb[k]).max(), scale)
-        bigm = np.abs(ga[k]) > 1e-3 * np.abs(ga[k]).max()
-        assert np.median(np.abs(ga[k][bigm] - gb[k][bigm]) / np.abs(ga[k][bigm])) < 1e-4, k
+        # (different activation code: inputs differ in the last bit, so threshold-flip Gaussians exist: counted)
+        assert_grad_close(gb[k], ga[k], "full_size_raw_vs_fused:" + k, outliers=max(4, ga[k].size // 100000))
 
 
 def test_full_size_forward_cpu_reference_digest(gsc, big):

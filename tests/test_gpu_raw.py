@@ -4,6 +4,8 @@ import numpy as np
 import pytest
 import torch
 
+from tests.gradcheck import assert_grad_close
+
 pytestmark = pytest.mark.gpu
 
 
@@ -55,12 +57,9 @@ def test_raw_function_matches_torch_activations(K):
         assert a.shape == b.shape, k
         if a.size == 0:          # K == 3: high_shs has no columns
             continue
-        scale = max(1.0, float(np.abs(a).max()))
-        assert np.abs(a - b).max() <= 2e-4 * scale, (k, np.abs(a - b).max(), scale)
-        # relative check on the bulk, so that a wrong factor cannot hide behind the absolute bound
-        big = np.abs(a) > 1e-3 * np.abs(a).max() if np.abs(a).max() > 0 else np.zeros_like(a, bool)
-        if big.any():
-            assert np.median(np.abs(a[big] - b[big]) / np.abs(a[big])) < 1e-4, k
+        # relative to the gradient's own magnitude (tests/gradcheck.py); the two paths feed the kernels inputs that
+        # differ in the last bit (sigmoid(logit), exp(log)), so a few threshold-flip Gaussians exist: counted
+        assert_grad_close(b, a, "raw_vs_fused[%d]:%s" % (K, k), outliers=4)
 
 
 def test_raw_function_trainer_equivalence_20k():

@@ -23,7 +23,8 @@ import pytest
 
 from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
-from tests.test_gpu_parity import _oracle_2d, check_culled_lists, close, dev, host
+from tests.gradcheck import assert_grad_close
+from tests.test_gpu_parity import _oracle_2d, check_culled_lists, dev, host
 
 pytestmark = pytest.mark.gpu
 
@@ -146,7 +147,7 @@ def test_eight_ring_views_full_size():
         got = {k: host(g[k])[full] for k in NAMES} | {"us": host(dus)[full]}
         for k in want:
             assert got[k].shape == want[k].shape, (v, k)
-            assert close(got[k], want[k], 2e-4), (v, k, np.abs(got[k] - want[k]).max(), np.abs(want[k]).max())
+            assert_grad_close(got[k], want[k], "ring_view%d:%s" % (v, k))
     # the views really are different workloads
     assert len({s[0] for s in stats}) == N_VIEWS, stats
     assert max(s[3] for s in stats) > stats[0][3], stats      # a ring view needs more depth-key bits than view 0
