@@ -60,7 +60,9 @@ class GSFunction(torch.autograd.Function):
             cov3ds, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, True)
         colors, dcolor_dshs, dcolor_dpws = gsc.sh2Color(shs, pws, cam.twc, True)
         cinv2ds, areas, dcinv2d_dcov2ds = gsc.inverseCov2D(cov2ds, depths, True)
-        image, contrib, final_tau, patch_range_per_tile, gsid_per_patch = gsc.splat(
+        # us / cinv2ds / colors are this node's own intermediates and never leave it: the packed records of the forward
+        # draw stay valid for the backward draw (gsplatcu.SplatRecords; `alphas` is checked by version in splatB)
+        (image, contrib, final_tau, patch_range_per_tile, gsid_per_patch), ctx.records = gsc.splat_with_records(
             cam.height, cam.width, us, cinv2ds, alphas, depths, colors, areas)
         ctx.cam = cam
         ctx.save_for_backward(us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
@@ -77,7 +79,7 @@ class GSFunction(torch.autograd.Function):
             return (None,) * 7
         if ctx.mode == "fused":
             pws, shs, alphas, scales, rots = ctx.saved_tensors
-            acc = _fused.accumulation_targets((pws, shs, alphas, scales, rots))
+            acc = _fused.accumulation_targets((pws, shs, alphas, scales, rots), ctx)
             dpws, dshs, dalphas, dscales, drots, dus = _fused.backward(
                 pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous(), accumulate=acc)
             if acc is not None:      # added to the leaves' .grad inside the kernel: nothing for autograd to accumulate
@@ -88,7 +90,7 @@ class GSFunction(torch.autograd.Function):
          dcolor_dpws) = ctx.saved_tensors
         dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors = gsc.splatB(
             cam.height, cam.width, us, cinv2ds, alphas, depths, colors, contrib, final_tau,
-            patch_range_per_tile, gsid_per_patch, dloss_dgammas.contiguous())
+            patch_range_per_tile, gsid_per_patch, dloss_dgammas.contiguous(), records=ctx.records)
         n = us.shape[0]
         dloss_dpws, dloss_dshs, dloss_dscales, dloss_drots = gsc.chain_rule(
             dloss_dus, dloss_dcinv2ds, dloss_dcolors, cam.Rcw, dcinv2d_dcov2ds, dcov2d_dcov3ds,
@@ -119,7 +121,7 @@ class GSRawFunction(torch.autograd.Function):
         if dloss_dgammas is None:
             return (None,) * 8
         pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw = ctx.saved_tensors
-        acc = _fused.accumulation_targets((pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw))
+        acc = _fused.accumulation_targets((pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw), ctx)
         dpws, dlow, dhigh, dalphas, dscales, drots, dus = _fused.backward(
             pws, low_shs, alphas_raw, scales_raw, rots_raw, ctx.cam, ctx.state, dloss_dgammas.contiguous(),
             high_shs=high_shs, accumulate=acc)

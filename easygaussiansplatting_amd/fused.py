@@ -397,7 +397,14 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                                               _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
                                               _ptr(S.gpack), prev_work, order_ready, 1 if S.culled else 0, st))
     except BaseException:
-        with ctx.lock:            # the slot of a render that never got on its way goes back to the free list
+        # Whatever was enqueued before the failure (the arm, the binning chain) still stores {P, max key} into the
+        # slot: it goes back on the free list only once those kernels have run -- otherwise a render on another
+        # ViewStreams lane could pick it up and settle on THEIR values.  Rare path: a stream wait is fine.
+        try:
+            torch.cuda.current_stream(dev).synchronize()
+        except Exception:
+            pass
+        with ctx.lock:
             t.status = _Ticket.FAILED
             ctx.free.append(t.slot)
         raise
@@ -424,6 +431,9 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         else:                                         # more patches than ever before: redo the draw stage
             draw_exact(t.patches)
     return image, mask, S
+
+
+_pad_index = {}    # (device, N, slice widths) -> positions of the alignment words of a flat gradient buffer
 
 
 class accumulate_in_kernel:
@@ -453,10 +463,25 @@ class _AccFlag:          # process-wide, not thread-local: autograd runs backwar
 _acc_flag = _AccFlag()
 
 
-def accumulation_targets(leaves):
+def _engine_accumulates_into(node_ctx, count):
+    """True when the running autograd pass will ACCUMULATE into ``.grad`` of the first ``count`` inputs of the node
+    ``node_ctx`` (a ``.backward()`` that reaches all of them); False under ``torch.autograd.grad`` (gradients are
+    captured and returned, ``.grad`` must stay untouched) or ``backward(inputs=[...])`` that leaves some out."""
+    try:
+        nodes = [fn for fn, _ in node_ctx.next_functions[:count]]
+        return all(fn is not None and torch._C._will_engine_execute_node(fn) for fn in nodes)
+    except Exception:      # "a leaf node was passed ... while running autograd.grad": captures, not accumulation
+        return False
+
+
+def accumulation_targets(leaves, node_ctx=None):
     """The ``.grad`` tensors of ``leaves`` when the coming backward may add to them in place (see
-    ``accumulate_in_kernel``), else None."""
+    ``accumulate_in_kernel``), else None.  ``node_ctx``: the autograd node whose backward is running -- the in-kernel
+    accumulation is only taken when the engine itself would accumulate into every leaf (never under
+    ``torch.autograd.grad``, whose callers expect returned tensors and an untouched ``.grad``)."""
     if not getattr(_acc_flag, "on", False) or _exchange_hook is not None:
+        return None
+    if node_ctx is not None and not _engine_accumulates_into(node_ctx, len(leaves)):
         return None
     grads = []
     for t in leaves:
@@ -506,6 +531,16 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
             starts.append(at)
             at += (n * w + 3) // 4 * 4
         flat = torch.empty(at, dtype=f32, device=dev)
+        # the <= 3 alignment words behind a slice belong to nobody: zero, not whatever the allocator left there --
+        # whole-buffer operations (ViewStreams.finish adds flat buffers, callers all-reduce / norm / isfinite them)
+        # must never meet NaN garbage.  No padding (and no kernel) when N is a multiple of four.
+        pad = [i for a, w in zip(starts, widths) for i in range(a + n * w, a + (n * w + 3) // 4 * 4)]
+        if pad:
+            pk = (dev, n, tuple(widths))
+            idx = _pad_index.get(pk)
+            if idx is None:
+                idx = _pad_index[pk] = torch.tensor(pad, dtype=torch.int64, device=dev)
+            flat.index_fill_(0, idx, 0.0)
         parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]
     if raw:
         dpws, dshs, dhigh, dalphas, dscales, drots = parts

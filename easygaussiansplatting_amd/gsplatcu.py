@@ -33,7 +33,7 @@ from . import _lib
 from ._lib import EgsPolicy
 
 __all__ = ["project", "computeCov3D", "computeCov2D", "sh2Color", "inverseCov2D", "splat", "splatB",
-           "set_policy", "get_policy", "chain_rule", "clear_memo"]
+           "set_policy", "get_policy", "chain_rule", "clear_memo", "set_memo", "splat_with_records", "SplatRecords"]
 
 _policy_name = "gsplatcu"
 _policy = None
@@ -269,39 +269,87 @@ def _alphas(alphas, n):
     return _chk(alphas.reshape(n), "alphas", torch.float32, (n,))
 
 
-# What the last `splat` of a device and stream left for the `splatB` that follows it (GSFunction.backward,
-# gsmodel.py:67-69, calls splatB with the very tensors its forward gave to splat): the packed records and the
-# [order | work] buffer.  The memo keeps STRONG references to the four input tensors the records are built from, so their memory cannot be
-# handed to another tensor while the entry lives; an entry is used only when every input is the same memory at the
-# same version (torch's in-place counter) under the same policy -- anything else repacks, exactly as before.
+# ---- what `splat` can keep for the `splatB` that follows it ---------------------------------------------------
+# GSFunction.backward (gsmodel.py:67-69) calls splatB with the very tensors its forward gave to splat; the packed 48-B
+# records built from them, the draw's [dispatch order | measured work] buffer and an [N][12] gradient-record buffer
+# the forward draw kernel cleared on the side can be reused instead of rebuilt (~45 us per step at 1 M Gaussians).
+# Reusing records is only correct if the four input tensors still hold what was packed.  That is knowable for
+#   * a caller that OWNS the tensors between the two calls: ``splat_with_records`` returns a ``SplatRecords`` handle
+#     and ``splatB(..., records=handle)`` takes it back -- what this package's GSFunction (mode "ops") does with its
+#     own intermediates (us / cinv2ds / colors never leave the autograd node);
+#   * nobody else: a write through ``tensor.data``, ``torch.as_strided`` aliases or another library's kernel leaves
+#     ``tensor._version`` untouched.  The PUBLIC ``splat`` / ``splatB`` pair therefore keeps NOTHING by default and
+#     ``splatB`` packs its records from the tensors it is given (what the reference does, gausplat.cu:114-159).
+#     ``set_memo(True)`` opts a process in to the implicit per-(device, stream) memo for unmodified reference
+#     callers (reference gsmodel.GSFunction): validated by (data_ptr, _version, shape) of the four inputs, policy,
+#     image size and stream -- in-place ops, other tensors, another policy or stream all fall back to packing; raw
+#     writes are the caller's responsibility in that mode.
+# A handle / memo entry keeps STRONG references to the four tensors (their memory cannot be handed to another tensor
+# while it lives) and is stored only after the draw stage was enqueued (the order buffer then holds a permutation,
+# the gradient records are cleared).
+_memo_enabled = False
 _splat_memo = {}
 
 
+class SplatRecords:
+    """Opaque: what one ``splat`` call left for the ``splatB`` of the same tensors (see above)."""
+    __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream")
+
+    def matches(self, dev, st, tensors, width, height):
+        if (self.dev_index != dev.index or self.stream != int(st.value or 0) or self.width != width
+                or self.height != height or self.policy != _policy_name):
+            return False
+        sig = _memo_sig(tensors)
+        return sig is not None and sig == self.sig and _memo_sig(self.tensors) == self.sig
+
+
+def set_memo(on: bool) -> None:
+    """Opt in (``True``) to / out of the implicit ``splat`` -> ``splatB`` memo of the public pair (default off)."""
+    global _memo_enabled
+    _memo_enabled = bool(on)
+    if not on:
+        _splat_memo.clear()
+
+
 def clear_memo() -> None:
-    """Drop what ``splat`` keeps for the next ``splatB`` (per device and stream: the four input tensors it packed, the
-    48-B records built from them, the dispatch-order buffer and the cleared gradient records -- ~130 MB at 1 M Gaussians
-    until the next ``splat``)."""
+    """Drop what ``splat`` keeps for the next ``splatB`` when ``set_memo(True)`` is in force (per device and stream:
+    the four input tensors it packed, the 48-B records built from them, the dispatch-order buffer and the cleared
+    gradient records -- ~130 MB at 1 M Gaussians until the next ``splat``)."""
     _splat_memo.clear()
 
 
 def _memo_sig(tensors):
-    return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    """(data_ptr, in-place version, shape) per tensor, or None where torch keeps no version counter (tensors created
+    under ``torch.inference_mode()``): no signature, nothing is kept, ``splat`` itself works as always."""
+    try:
+        return tuple((t.data_ptr(), t._version, tuple(t.shape)) for t in tensors)
+    except RuntimeError:
+        return None
 
 
-def _memo_store(dev, st, tensors, width, height, rec, order, gpack):
-    _splat_memo[(dev.index, int(st.value or 0))] = [tensors, _memo_sig(tensors), width, height, _policy_name, rec,
-                                                    order, gpack]
+def _make_records(dev, st, tensors, width, height, rec, order, gpack):
+    sig = _memo_sig(tensors)
+    if sig is None:
+        return None
+    h = SplatRecords()
+    h.tensors, h.sig, h.width, h.height, h.policy = tensors, sig, width, height, _policy_name
+    h.rec, h.order, h.gpack, h.dev_index, h.stream = rec, order, gpack, dev.index, int(st.value or 0)
+    return h
 
 
-def _memo_lookup(dev, st, tensors, width, height):
-    """-> (rec, order, gpack); gpack (zeroed by the forward draw) is handed out ONCE."""
-    m = _splat_memo.get((dev.index, int(st.value or 0)))
-    if m is None or m[2] != width or m[3] != height or m[4] != _policy_name:
+def _take_records(h, dev, st, tensors, width, height):
+    """-> (rec, order, gpack) of a handle that still describes ``tensors``; gpack (cleared by the forward draw) is
+    handed out ONCE."""
+    if h is None or not h.matches(dev, st, tensors, width, height):
         return None, None, None
-    if m[1] != _memo_sig(tensors) or _memo_sig(m[0]) != m[1]:   # other tensors, or the remembered ones changed since
-        return None, None, None
-    gpack, m[7] = m[7], None
-    return m[5], m[6], gpack
+    gpack, h.gpack = h.gpack, None
+    return h.rec, h.order, gpack
+
+
+def splat_with_records(height, width, us, cinv2ds, alphas, depths, colors, areas):
+    """``splat`` + a ``SplatRecords`` handle (or None) for ``splatB(..., records=handle)``.  For callers that own
+    the four input tensors until that ``splatB`` (see the note above ``SplatRecords``)."""
+    return _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep=True)
 
 
 def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
@@ -309,6 +357,14 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
            patch_range_per_tile[T,2] int32, gsid_per_patch[P] int32].
     ``depths`` and ``areas`` are updated IN PLACE for Gaussians whose tile rect is
     empty (kernel.cu:114-119).  Reference: ext.cpp:10-18, gausplat.cu:24-112."""
+    out, h = _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep=_memo_enabled)
+    if _memo_enabled and h is not None:
+        _splat_memo[(h.dev_index, h.stream)] = h
+    return out
+
+
+def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
+    """-> ([image, contrib, final_tau, patch_range_per_tile, gsid_per_patch], SplatRecords or None)."""
     height, width = int(height), int(width)
     if height <= 0 or width <= 0:
         raise ValueError("height and width must be positive")
@@ -330,20 +386,22 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     ws_bin = torch.empty(ws_bin_bytes, dtype=torch.uint8, device=dev)
     st = _stream()
     key = (n, width, height)
-    # The packed 48-B records the draw kernels gather are built ONCE here and kept, with the [dispatch order | measured
-    # work] buffer of the draw, for the splatB call that follows with the same tensors (_SplatMemo): the seven-op
-    # surface otherwise packs the same records twice per training step and rebuilds the per-tile work from `contrib`.
+    # The packed 48-B records the draw kernels gather are built ONCE here; with keep=True they stay, with the
+    # [dispatch order | measured work] buffer of the draw, for the splatB call of the same tensors (SplatRecords).
     rec = torch.empty((max(n, 1), 12), dtype=torch.float32, device=dev)
     order = torch.empty(lib.egs_tile_order_len(width, height), dtype=torch.int32, device=dev)
     gpack = None
+    keep = bool(keep) and n > 0 and _pol().footprint != 1   # (pixel-box records also depend on `areas`, which this op mutates)
     if n > 0:
         _lib.check(lib.egs_pack_records(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
                                         _ptr(areas), pol, _ptr(rec), st))
-        if _pol().footprint != 1:      # (pixel-box records also depend on `areas`, which this op mutates)
+        if keep:
             # the packed gradient records of a splatB that may follow: cleared on the side by the draw kernel (it is
             # VALU-bound, the memory system idles), good for ONE backward pass
             gpack = torch.empty((n, 12), dtype=torch.float32, device=dev)
-            _memo_store(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack)
+
+    def records():    # only once the draw stage is enqueued: the order buffer is written, the gradient records cleared
+        return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack) if keep else None
 
     def draw_exact(patches):
         gsid = torch.empty(patches, dtype=torch.int32, device=dev)
@@ -378,7 +436,7 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         if n > 0:
             with ctx.lock:
                 ctx.capacity[key] = max(ctx.capacity.get(key, 0), _fused._grow(patches))
-        return [image, contrib, final_tau, ranges, gsid]
+        return [image, contrib, final_tau, ranges, gsid], records()
     t = _fused._Ticket()
     t.ctx, t.key, t.cap, t.state, t.status, t.collected, t.slot = ctx, key, cap, None, _fused._Ticket.PENDING, True, slot
     t.hint = _get_key_bits(dev.index, key)
@@ -396,7 +454,14 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
                                               _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), _ptr(order), _ptr(gpack),
                                               None, 0, 0, st))
     except BaseException:
-        with ctx.lock:                       # the slot goes back: nothing will ever fetch it
+        # Kernels enqueued before the failure (the arm, the binning chain) still store {P, max key} into the slot:
+        # it may only go back on the free list once they have run, or a later render that picks it up could settle
+        # on THEIR values.  Rare path: a device-wide wait is fine.
+        try:
+            torch.cuda.current_stream(dev).synchronize()
+        except Exception:
+            pass
+        with ctx.lock:
             t.status = _fused._Ticket.FAILED
             ctx.free.append(slot)
         raise
@@ -407,16 +472,17 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         if t.patches >= 2**31:
             raise RuntimeError("splat: %d tile patches overflow int32 indexing" % t.patches)
         if t.hint < 32 and t.need > t.hint:  # stale depth-key hint: everything again (the stage is idempotent)
-            return [image, contrib, final_tau, ranges, render_exact()[1]]
-        return [image, contrib, final_tau, ranges, draw_exact(t.patches)]   # more patches than ever before
-    return [image, contrib, final_tau, ranges, gsid_full[:t.patches]]
+            return [image, contrib, final_tau, ranges, render_exact()[1]], records()
+        return [image, contrib, final_tau, ranges, draw_exact(t.patches)], records()   # more patches than ever before
+    return [image, contrib, final_tau, ranges, gsid_full[:t.patches]], records()
 
 
 def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
-           gsid_per_patch, dloss_dgammas, areas=None):
+           gsid_per_patch, dloss_dgammas, areas=None, records=None):
     """-> [dloss_dus[N,1,2], dloss_dcinv2ds[N,1,3], dloss_dalphas[N,1,1], dloss_dcolors[N,1,3]].
     Reference: ext.cpp:20-32, gausplat.cu:114-159, kernel.cu:809-950.  ``areas``
-    is an extension needed only under the forward_cpu policy (pixel boxes)."""
+    is an extension needed only under the forward_cpu policy (pixel boxes); ``records`` the handle of
+    ``splat_with_records`` (extension; ignored unless it still describes these tensors)."""
     height, width = int(height), int(width)
     us = _chk(us, "us", torch.float32, (None, 2))
     n = us.shape[0]
@@ -444,7 +510,8 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
     st = _stream()
     rec, order, gpack = (None, None, None)
     if n > 0 and pol.footprint != 1:   # (the pixel-box policy's records also depend on `areas`, which splat mutates)
-        rec, order, gpack = _memo_lookup(dev, st, (us, cinv2ds, alphas, colors), width, height)
+        h = records if records is not None else (_splat_memo.get((dev.index, int(st.value or 0))) if _memo_enabled else None)
+        rec, order, gpack = _take_records(h, dev, st, (us, cinv2ds, alphas, colors), width, height)
     if rec is not None:     # the records (and the measured per-tile work) of the splat call these tensors came from
         _lib.check(lib.egs_splat_bwd_rec(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
                                          _ptr(final_tau), _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes,

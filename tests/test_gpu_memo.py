@@ -1,0 +1,184 @@
+"""``splat`` -> ``splatB`` record reuse (easygaussiansplatting_amd/gsplatcu.py, ``SplatRecords``) can never hand
+``splatB`` records that no longer describe its input tensors.
+
+Ground truth of every case: ``splatB`` on CLONES of the (mutated) tensors -- fresh storage that no handle or memo entry
+can match, i.e. the pack-from-scratch path ``egs_splat_bwd`` (the reference's behaviour, gausplat.cu:114-159).
+
+* the PUBLIC pair keeps nothing by default: a write through ``.data`` (invisible to ``_version``), an in-place op,
+  a policy swap, another stream between the two calls -- gradients equal the ground truth;
+* ``set_memo(True)`` (opt-in implicit memo): in-place ops, other tensors, policy and stream changes are detected;
+* the explicit handle (``splat_with_records`` / ``records=``, what GSFunction mode "ops" uses): reused when nothing
+  changed, dropped when a tensor's version moved;
+* ``torch.inference_mode()``: ``splat`` works (inference tensors have no version counter; round 3 raised);
+* ``fused.accumulate_in_kernel``: ``torch.autograd.grad`` inside the block returns tensors and leaves ``.grad`` alone;
+* the alignment words of a flat gradient buffer are zero."""
+import numpy as np
+import pytest
+import torch
+
+from easygaussiansplatting_amd import scene as S
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def gsc():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from easygaussiansplatting_amd import gsplatcu
+    gsplatcu.set_policy("gsplatcu")
+    gsplatcu.set_memo(False)
+    yield gsplatcu
+    gsplatcu.set_memo(False)
+    gsplatcu.set_policy("gsplatcu")
+
+
+def _inputs(gsc, n=3000, w=160, h=96, seed=7):
+    sc = S.small_scene(n, w, h, 3, seed=seed)
+    cam = sc.cam
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    pws, rots, scales, alphas, shs = map(dev, (sc.pws, sc.rots, sc.scales, sc.alphas, sc.shs))
+    Rcw, tcw, twc = dev(cam.Rcw), dev(cam.tcw), dev(cam.twc)
+    us, pcs, depths = gsc.project(pws, Rcw, tcw, cam.fx, cam.fy, cam.cx, cam.cy, False)
+    cov3 = gsc.computeCov3D(rots, scales, depths, False)[0]
+    cov2 = gsc.computeCov2D(cov3, pcs, Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, False)[0]
+    col = gsc.sh2Color(shs, pws, twc, False)[0]
+    cinv, areas = gsc.inverseCov2D(cov2, depths, False)
+    dl = dev(S.normal(3, 1, (3, h, w)))
+    return dict(H=h, W=w, us=us, cinv=cinv, alphas=alphas, depths=depths, col=col, areas=areas, dl=dl)
+
+
+def _truth(gsc, d, out):
+    """splatB on clones: nothing kept anywhere can match their storage."""
+    c = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    g = gsc.splatB(c["H"], c["W"], c["us"], c["cinv"], c["alphas"], c["depths"], c["col"], out[1].clone(),
+                   out[2].clone(), out[3].clone(), out[4].clone(), c["dl"])
+    torch.cuda.synchronize()
+    return [x.clone() for x in g]
+
+
+def _same(a, b):
+    for x, y in zip(a, b):
+        scale = float(y.abs().max())
+        assert scale > 0
+        assert float((x - y).abs().max()) <= 2e-5 * scale        # order of the float atomics only
+
+
+def _splatB(gsc, d, out, **kw):
+    return gsc.splatB(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], out[1], out[2], out[3],
+                      out[4], d["dl"], **kw)
+
+
+MUTATIONS = ["none", "data_write", "inplace", "policy", "stream", "other_tensor"]
+
+
+@pytest.mark.parametrize("memo", [False, True])
+@pytest.mark.parametrize("what", MUTATIONS)
+def test_public_pair_never_differentiates_stale_records(gsc, what, memo):
+    if memo and what == "data_write":
+        pytest.skip("opt-in memo: raw writes are the caller's responsibility (documented); the default keeps nothing")
+    gsc.set_memo(memo)
+    d = _inputs(gsc)
+    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    stream = None
+    if what == "data_write":
+        d["us"].data.add_(0.75)                     # _version stays 0
+        assert d["us"]._version == 0
+    elif what == "inplace":
+        d["cinv"].mul_(1.1)
+    elif what == "policy":
+        gsc.set_policy("forward_cpu"); gsc.set_policy("gsplatcu")      # same policy again: still fine either way
+        d["alphas"].mul_(0.9)
+    elif what == "stream":
+        stream = torch.cuda.Stream()
+        stream.wait_stream(torch.cuda.current_stream())
+    elif what == "other_tensor":
+        d["col"] = d["col"] * 0.5 + 0.1
+    if stream is not None:
+        with torch.cuda.stream(stream):
+            got = _splatB(gsc, d, out)
+        stream.synchronize()
+    else:
+        got = _splatB(gsc, d, out)
+    torch.cuda.synchronize()
+    _same(got, _truth(gsc, d, out))
+    if what != "none":                              # and the mutation really changes the answer
+        d0 = _inputs(gsc)
+        ref0 = _truth(gsc, d0, out)
+        assert what == "stream" or any(float((a - b).abs().max()) > 1e-3 * float(b.abs().max())
+                                       for a, b in zip(got, ref0))
+
+
+def test_policy_swap_between_the_calls(gsc):
+    """Records packed under one policy are not used under another (forward_cpu needs areas=: checked separately)."""
+    gsc.set_memo(True)
+    d = _inputs(gsc)
+    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    h = gsc._splat_memo[(0, int(torch.cuda.current_stream().cuda_stream or 0))]
+    gsc.set_policy("forward_cpu")
+    assert not h.matches(d["us"].device, gsc._stream(), (d["us"], d["cinv"], d["alphas"], d["col"]), d["W"], d["H"])
+    gsc.set_policy("gsplatcu")
+    assert h.matches(d["us"].device, gsc._stream(), (d["us"], d["cinv"], d["alphas"], d["col"]), d["W"], d["H"])
+
+
+def test_explicit_handle_is_reused_and_dropped(gsc):
+    d = _inputs(gsc)
+    out, h = gsc.splat_with_records(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    assert h is not None and h.gpack is not None
+    got = _splatB(gsc, d, out, records=h)
+    assert h.gpack is None                           # the cleared gradient records were handed out (once)
+    _same(got, _truth(gsc, d, out))
+    got2 = _splatB(gsc, d, out, records=h)           # a second backward (retain_graph): own buffer, same result
+    _same(got2, _truth(gsc, d, out))
+    d["alphas"].mul_(0.8)                            # version moved: the handle no longer matches
+    assert not h.matches(d["us"].device, gsc._stream(), (d["us"], d["cinv"], d["alphas"], d["col"]), d["W"], d["H"])
+    _same(_splatB(gsc, d, out, records=h), _truth(gsc, d, out))
+
+
+@pytest.mark.parametrize("memo", [False, True])
+def test_splat_under_inference_mode(gsc, memo):
+    gsc.set_memo(memo)
+    with torch.inference_mode():
+        d = _inputs(gsc)
+        out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+        out2, h = gsc.splat_with_records(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"],
+                                         d["areas"])
+        assert h is None                             # no version counter -> nothing kept
+        got = _splatB(gsc, d, out)
+    torch.cuda.synchronize()
+    assert torch.equal(out[0], out2[0]) and float(out[0].abs().max()) > 0
+    assert all(torch.isfinite(g).all() for g in got)
+
+
+def test_autograd_grad_inside_accumulate_in_kernel_and_zero_padding(gsc):
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    GSFunction.mode = "fused"
+    n = 2501                                         # not a multiple of four: every slice of the flat buffer is padded
+    sc = S.small_scene(n, 128, 96, 12, seed=3)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    L = [dev(a).requires_grad_(True) for a in (sc.pws, sc.shs, sc.alphas.reshape(-1, 1), sc.scales, sc.rots)]
+    us = torch.zeros((n, 2), device="cuda", requires_grad=True)
+    cam = Camera.from_scene(sc.cam)
+    dl = dev(S.normal(2, 2, (3, 96, 128))) / (3 * 96 * 128)
+    with fused.accumulate_in_kernel():
+        img, _ = GSFunction.apply(*L, us, cam)
+        img.backward(dl)                                         # establishes the one-buffer .grad layout
+        flat = fused.flat_grad_buffer(L)
+        assert flat is not None and torch.isfinite(flat).all()
+        used = torch.zeros_like(flat, dtype=torch.bool)
+        for t in L:
+            off = (t.grad.data_ptr() - flat.data_ptr()) // 4
+            used[off:off + t.grad.numel()] = True
+        assert int((~used).sum()) > 0 and not flat[~used].any()  # the alignment words are zero, not allocator garbage
+        before = [t.grad.clone() for t in L]
+        img2, _ = GSFunction.apply(*L, us, cam)
+        gs = torch.autograd.grad(img2, L, dl)                    # must RETURN the gradients ...
+        assert all(g is not None for g in gs)
+        for g, b, t in zip(gs, before, L):
+            assert torch.equal(t.grad, b)                        # ... and leave .grad untouched
+            assert float((g - b).abs().max()) <= 2e-5 * float(b.abs().max())
+        img3, _ = GSFunction.apply(*L, us, cam)
+        img3.backward(dl)                                        # .backward(): accumulated in the kernel
+        for b, t in zip(before, L):
+            assert float((t.grad - 2 * b).abs().max()) <= 4e-5 * float(b.abs().max())

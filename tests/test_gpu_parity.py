@@ -11,7 +11,7 @@ import pytest
 from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
 from tests.conftest import load_golden, ref_check
-from tests.gradcheck import assert_grad_close
+from tests.gradcheck import assert_grad_close, assert_grad_close_flips
 
 pytestmark = pytest.mark.gpu
 
@@ -34,6 +34,32 @@ def dev(a, dtype=np.float32):
 
 def host(t):
     return t.detach().cpu().numpy()
+
+
+def window_tiles(gx, gy, cx, cy, w=6, h=4):
+    """The tiles of a w x h window around tile (cx, cy), clipped to the grid: a CONTIGUOUS patch, so that most of the
+    Gaussians it holds lie completely inside it (isolated sampled tiles hold a handful of complete Gaussians each)."""
+    x0 = int(np.clip(cx - w // 2, 0, gx - w)); y0 = int(np.clip(cy - h // 2, 0, gy - h))
+    return np.array([(y0 + dy) * gx + x0 + dx for dy in range(h) for dx in range(w)], np.int64)
+
+
+def gradient_windows(rg, gx, gy, count=3):
+    """Where the full-size tests compare gradients: a window in the image centre, one on the ragged bottom tile row
+    (1080 = 67.5 tiles) and one around the longest list."""
+    lens = rg[:, 1] - rg[:, 0]
+    tl = int(np.argmax(lens))
+    wins = [window_tiles(gx, gy, gx // 2, gy // 2), window_tiles(gx, gy, gx // 5, gy - 1),
+            window_tiles(gx, gy, tl % gx, tl // gx)]
+    return np.unique(np.concatenate(wins[:count]))
+
+
+def complete_inside(gs, rg, tiles, n):
+    """Gaussians whose EVERY patch lies inside ``tiles``: their gradient over these tiles is their whole gradient."""
+    allp = np.bincount(gs, minlength=n)
+    inp = np.zeros(n, np.int64)
+    for t in tiles:
+        np.add.at(inp, gs[rg[t, 0]:rg[t, 1]], 1)
+    return np.nonzero((inp > 0) & (allp == inp))[0]
 
 
 def gpu_stages(gsc, sc, calc_J, policy):
@@ -242,7 +268,8 @@ def test_exclusive_scan(gsc, n, use_gather):
 
 
 # --------------------------------------------------------------------------- splat, policy G
-def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=True, seed=3, tag=None):
+def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=True, seed=3, tag=None,
+                     near_margin=1e-4, **tol):
     cam = sc.cam
     g = gpu_stages(gsc, sc, False, policy)
     d_before = host(g["depths"]).copy(); a_before = host(g["areas"]).copy()
@@ -282,11 +309,12 @@ def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=
     grads = gsc.splatB(cam.height, cam.width, g["us"], g["cinv2ds"], g["alphas"], g["depths"], g["colors"],
                        contrib, tau, ranges, gsid, dev(dl), **kw)
     # oracle backward from the DEVICE's contrib/final_tau (isolates the backward kernel)
+    near = np.zeros(sc.n, bool)
     o_g = O.draw_backward(cam.width, cam.height, o_ranges, o_gsid, host(g["us"]), host(g["cinv2ds"]),
                           host(g["alphas"]), host(g["colors"]), host(contrib), host(tau), dl,
-                          host(g["areas"]), opol)
+                          host(g["areas"]), opol, near_out=near, near_margin=near_margin)
     for a, b, nm in zip(o_g, grads, ("dus", "dcinv", "dalpha", "dcolor")):
-        assert_grad_close(host(b).reshape(a.shape), a, "%s:%s" % (tag or "splat", nm))
+        assert_grad_close_flips(host(b).reshape(a.shape), a, near, "%s:%s" % (tag or "splat", nm), **tol)
 
 
 def test_splat_10k_policy_g(gsc):
@@ -315,7 +343,9 @@ def _needles(n=6000, seed=33):
 
 
 def test_splat_needles(gsc):
-    _splat_and_check(gsc, _needles(), tag="needles")
+    # sigma = 0.4 x 0.004: conic entries of 1e3..1e5 px^-2, the Mahalanobis form cancels three to four digits in
+    # float32 (both draw kernels; the reference's float32 CUDA kernels as much) -- looser, stated bounds
+    _splat_and_check(gsc, _needles(), tag="needles", near_margin=3e-3, tol_max=5e-4, med_rel=5e-5, max_rel=2e-2)
 
 
 @pytest.mark.parametrize("case", ["giants", "ties", "one_tile"])
@@ -652,20 +682,18 @@ def test_full_size_policy_g_sampled_tiles_and_invariants(gsc, big):
         nflip += int(flip.sum())
         assert d[~flip].max() < 1e-4 and d.max() < 5e-3
     assert nflip <= 8, nflip                                          # threshold flips, counted
-    # backward on the sampled tiles only: oracle gradients of those tiles' pixels <= device totals check
+    # backward: three contiguous windows of tiles (image centre, ragged bottom row, around the longest list); the
+    # Gaussians whose every patch lies inside them get their COMPLETE gradient there -- thousands of them
+    sub = gradient_windows(rg, gx, (cam.height + 15) // 16)
+    near = np.zeros(sc.n, bool)
     o_g = O.draw_backward(cam.width, cam.height, rg, gs, hu, hc, ha, hcol, hcont, htau, dl, None, O.POLICY_G,
-                          tiles=sel[:6])
-    # Gaussians whose every patch lies inside the sampled tiles get their complete gradient there
-    ids_in = np.unique(np.concatenate([gs[rg[t, 0]:rg[t, 1]] for t in sel[:6]]))
-    allp = np.zeros(sc.n, np.int64); np.add.at(allp, gs, 1)
-    inp = np.zeros(sc.n, np.int64)
-    for t in sel[:6]:
-        np.add.at(inp, gs[rg[t, 0]:rg[t, 1]], 1)
-    full = ids_in[allp[ids_in] == inp[ids_in]]
-    assert full.size > 20
+                          tiles=sub, near_out=near)
+    full = complete_inside(gs, rg, sub, sc.n)
+    assert full.size > 2000, full.size
     for a, b, nm in zip(o_g, grads, ("dus", "dcinv", "dalpha", "dcolor")):
         b = host(b).reshape(a.shape)
-        assert_grad_close(b[full], a[full], "full_size_ops:" + nm)
+        r = assert_grad_close_flips(b[full], a[full], near[full], "full_size_ops:" + nm)
+        assert r["n_big"] > 300, r
 
 
 def _oracle_2d(sc, cam, rows=None, calc_J=False):
@@ -782,16 +810,14 @@ def test_full_size_fused_and_raw_paths(gsc, big):
         nflip += int(flip.sum())
         assert d[~flip].max() < 1e-4 and d.max() < 5e-3
     assert nflip <= 12, nflip                                          # threshold flips (fp32 vs fp64 2D Gaussians)
-    # gradients: Gaussians complete inside six sampled tiles
-    sub = sel[:6]
+    # gradients: the Gaussians complete inside three contiguous windows of tiles (centre, ragged bottom row, longest
+    # list) -- thousands; the oracle's 2D Gaussians are float64, the device's float32: wider threshold margin
+    sub = gradient_windows(rg, gx, (H + 15) // 16)
+    near = np.zeros(sc.n, bool)
     o_g2 = O.draw_backward(W, H, rg, gs, o_us, o_ci, alphas64, o_col, hcont, htau, dl.astype(np.float64), None,
-                           O.POLICY_G, tiles=sub)
-    allp = np.zeros(sc.n, np.int64); np.add.at(allp, gs, 1)
-    inp = np.zeros(sc.n, np.int64)
-    for t in sub:
-        np.add.at(inp, gs[rg[t, 0]:rg[t, 1]], 1)
-    full = np.nonzero((inp > 0) & (allp == inp))[0]
-    assert full.size > 20
+                           O.POLICY_G, tiles=sub, near_out=near, near_margin=1e-3)
+    full = complete_inside(gs, rg, sub, sc.n)
+    assert full.size > 2000, full.size
     _, _, _, _, J = _oracle_2d(sc, sc.cam, full, True)
     g = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], sc.cam.Rcw, J)
     want = dict(pws=g["dpws"], shs=g["dshs"], alphas=g["dalphas"][:, None], scales=g["dscales"], rots=g["drots"],
@@ -799,7 +825,8 @@ def test_full_size_fused_and_raw_paths(gsc, big):
     got = {k: host(v.grad)[full] for k, v in P.items()} | {"us": host(us0.grad)[full]}
     for k in want:
         assert got[k].shape == want[k].shape, k
-        assert_grad_close(got[k], want[k], "full_size_fused:" + k)
+        r = assert_grad_close_flips(got[k], want[k], near[full], "full_size_fused:" + k)
+        assert r["n_big"] > 300, (k, r)
     # --- raw path at the same size: activations inside the kernels == torch activations around the fused path
     a = torch.from_numpy(sc.alphas.astype(np.float32)).clamp(1e-4, 1 - 1e-4)
     raw = dict(pws=dev(sc.pws), low_shs=dev(sc.shs[:, :3]), high_shs=dev(sc.shs[:, 3:]),
@@ -858,6 +885,97 @@ def test_full_size_forward_cpu_reference_digest(gsc, big):
         assert d.max() < 2e-2
     assert bad <= 64, bad                                             # depth-order swaps / box-edge flips (of 16384 px)
     assert abs(image.mean() - float(g6["image_mean"])) < 1e-6
+
+
+def tile_digest(image, tau, contrib, W, H):
+    """Per-tile mean RGB [T,3], mean tau [T], contrib sum [T], finished pixels [T] -- the layout of fixture G11
+    (ragged bottom tile row: means over its real pixels)."""
+    gy, gx = (H + 15) // 16, (W + 15) // 16
+    pad = np.zeros((3, gy * 16, gx * 16)); pad[:, :H, :W] = image
+    cnt = np.zeros((gy * 16, gx * 16)); cnt[:H, :W] = 1
+    npx = cnt.reshape(gy, 16, gx, 16).sum((1, 3))
+    tm = (pad.reshape(3, gy, 16, gx, 16).sum((2, 4)) / npx).transpose(1, 2, 0).reshape(-1, 3)
+    pt = np.zeros((gy * 16, gx * 16)); pt[:H, :W] = tau
+    tt = (pt.reshape(gy, 16, gx, 16).sum((1, 3)) / npx).reshape(-1)
+    done = np.zeros((gy * 16, gx * 16), np.int64); done[:H, :W] = tau < 1e-4
+    td = done.reshape(gy, 16, gx, 16).sum((1, 3)).reshape(-1)
+    tc = None
+    if contrib is not None:
+        pc = np.zeros((gy * 16, gx * 16), np.int64); pc[:H, :W] = contrib
+        tc = pc.reshape(gy, 16, gx, 16).sum((1, 3)).reshape(-1)
+    return dict(mean=tm, tau=tt, contrib=tc, done=td, pad=pad, pad_tau=pt)
+
+
+def check_against_g11(g11, view, image, tau, W, H, lens=None, contrib=None, full_tiles=True, label=""):
+    """All 8160 tiles of a 1 M / 1080p policy-G render against fixture G11 (the pinned float64 oracle, all tiles).
+    The device's 2D Gaussians are float32: a Gaussian whose depth sits on a millimetre boundary sorts one bucket
+    earlier or later than in float64 and one whose rect edge sits on a tile border gains / loses a tile -- order swaps
+    and list-length differences of +-1, counted and bounded, like the flips of the per-pixel checks."""
+    pre = "v%d_" % view
+    d = tile_digest(image, tau, contrib, W, H)
+    T = d["mean"].shape[0]
+    dm = np.abs(d["mean"] - g11[pre + "tile_mean"]).max(1)
+    dt = np.abs(d["tau"] - g11[pre + "tile_tau"])
+    stats = dict(view=view, med_mean=float(np.median(dm)), frac_mean_2e5=float((dm > 2e-5).mean()),
+                 max_mean=float(dm.max()), med_tau=float(np.median(dt)), frac_tau_2e5=float((dt > 2e-5).mean()),
+                 max_tau=float(dt.max()), done_diff=int(np.abs(d["done"] - g11[pre + "tile_done"]).sum()),
+                 image_mean_err=float(abs(image.mean() - float(g11[pre + "image_mean"]))))
+    if lens is not None:
+        dl = np.abs(np.asarray(lens, np.int64) - g11[pre + "tile_len"])
+        stats.update(len_diff_tiles=int((dl > 0).sum()), len_diff_max=int(dl.max()),
+                     P_diff=int(abs(int(np.sum(lens)) - int(g11[pre + "P"]))))
+        if contrib is not None:
+            same = dl == 0
+            stats["contrib_diff_tiles"] = int((d["contrib"][same] != g11[pre + "tile_contrib"][same]).sum())
+    if full_tiles and (pre + "tiles") in g11:
+        gx = (W + 15) // 16
+        bad = 0; worst = 0.0
+        for t, ref, rtau in zip(g11[pre + "tile_ids"], g11[pre + "tiles"], g11[pre + "tiles_tau"]):
+            ty, tx = divmod(int(t), gx)
+            hh = min(16, H - ty * 16)
+            e = np.abs(d["pad"][:, ty * 16:ty * 16 + hh, tx * 16:tx * 16 + 16] - ref[:, :hh]).max(0)
+            et = np.abs(d["pad_tau"][ty * 16:ty * 16 + hh, tx * 16:tx * 16 + 16] - rtau[:hh])
+            bad += int(((e >= 1e-4) | (et >= 1e-4)).sum()); worst = max(worst, float(e.max()))
+        stats.update(full_tile_bad_px=bad, full_tile_worst=worst)
+    import json, os
+    if os.environ.get("EGS_GRAD_STATS"):
+        with open(os.environ["EGS_GRAD_STATS"], "a") as f:
+            f.write(json.dumps(dict(name="g11:" + label, **stats)) + "\n")
+    # every tile: rounding-level agreement on the bulk, counted order swaps / threshold flips on the rest
+    assert stats["med_mean"] < 3e-6 and stats["frac_mean_2e5"] < 0.02 and stats["max_mean"] < 3e-3, stats
+    assert stats["med_tau"] < 3e-6 and stats["frac_tau_2e5"] < 0.02 and stats["max_tau"] < 3e-3, stats
+    assert stats["image_mean_err"] < 2e-6 and stats["done_diff"] <= 2000, stats
+    if lens is not None:
+        assert stats["len_diff_tiles"] <= 40 and stats["len_diff_max"] <= 2 and stats["P_diff"] <= 40, stats
+    if "full_tile_bad_px" in stats:
+        assert stats["full_tile_bad_px"] <= 64 and stats["full_tile_worst"] < 2e-2, stats
+    return stats
+
+
+def test_full_size_policy_g_all_tiles_digest(gsc, big):
+    """ALL 8160 tiles of the policy-G render at 1 M Gaussians / 1920x1080 (the policy bench.py times), on both product
+    paths -- the seven ops (reference's unculled lists: list lengths and contrib sums comparable too) and the fused
+    training op -- against fixture G11: per-tile mean RGB / mean tau / finished pixels, list lengths, and 64 full tiles
+    that include the ragged bottom tile row (1080 = 67.5 tiles), the image corners and the eight longest lists
+    (the 830-entry tile).  kernel.cu:152-271."""
+    from easygaussiansplatting_amd import fused
+    from easygaussiansplatting_amd.function import Camera
+    g11 = load_golden("g11_policy_g_1m_digest.npz")
+    sc = big
+    cam = sc.cam
+    W, H = cam.width, cam.height
+    g = gpu_stages(gsc, sc, False, "gsplatcu")
+    image, contrib, tau, ranges, gsid = gsc.splat(H, W, g["us"], g["cinv2ds"], g["alphas"], g["depths"], g["colors"],
+                                                  g["areas"])
+    rg = host(ranges)
+    s = check_against_g11(g11, 0, host(image), host(tau), W, H, lens=rg[:, 1] - rg[:, 0], contrib=host(contrib),
+                          label="seven_ops_v0")
+    assert s["contrib_diff_tiles"] <= 200, s                   # threshold flips move one pixel's last contributor
+    P = [dev(sc.pws), dev(sc.shs), dev(sc.alphas).reshape(-1, 1), dev(sc.scales), dev(sc.rots)]
+    with torch.no_grad():
+        for need_grad in (False, True):                        # the inference and the training instance of the kernels
+            img_f, _, st = fused.forward(*P, Camera.from_scene(cam), need_grad=need_grad)
+            check_against_g11(g11, 0, host(img_f), host(st.final_tau), W, H, label="fused_v0_grad%d" % need_grad)
 
 
 def test_depth_key_bit_hint_protocol(gsc):

@@ -23,8 +23,10 @@ import pytest
 
 from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
-from tests.gradcheck import assert_grad_close
-from tests.test_gpu_parity import _oracle_2d, check_culled_lists, dev, host
+from tests.conftest import load_golden
+from tests.gradcheck import assert_grad_close_flips
+from tests.test_gpu_parity import (_oracle_2d, check_against_g11, check_culled_lists, complete_inside, dev,
+                                   gradient_windows, host)
 
 pytestmark = pytest.mark.gpu
 
@@ -73,6 +75,7 @@ def test_eight_ring_views_full_size():
     alphas64 = sc.alphas.astype(np.float64)
     gx = (W + 15) // 16
     dls = [dev(S.normal(8, 10 + v, (3, H, W)).astype(np.float32) / (H * W)) for v in range(N_VIEWS)]
+    g11 = load_golden("g11_policy_g_1m_digest.npz")
     per_view = []          # per-view gradients (device tensors), for the accumulation checks below
     stats = []
     for v in range(N_VIEWS):
@@ -111,6 +114,8 @@ def test_eight_ring_views_full_size():
         assert torch.equal(image, img_t) and torch.equal(mask, mask_t)
         per_view.append({k: g[k].clone() for k in NAMES})
         him = host(image)
+        # ALL tiles of this view against the all-tile digest of the pinned oracle (fixture G11)
+        check_against_g11(g11, v, him, htau, W, H, label="ring_view%d" % v)
         sel = (S.uniform01(40 + v, 2, (8,)) * T).astype(np.int64)
         sel = np.array([t for t in sel if lens[t] > 0] or [int(np.argmax(lens))])
         dropped, kept, bdev, btrue = check_culled_lists(st, sel[:4], o_us, o_ci, alphas64, hdepth,
@@ -126,20 +131,17 @@ def test_eight_ring_views_full_size():
             nflip += int(flip.sum())
             assert d[~flip].max() < 1e-4 and d.max() < 5e-3, (v, int(t), d.max())
         assert nflip <= 8, (v, nflip)                     # alpha' >= 0.002 / tau < 1e-4 threshold flips, fp32 vs fp64
-        # ---- gradients of the Gaussians complete inside three sampled tiles
-        by_len = sel[np.argsort(-lens[sel], kind="stable")]
-        for ntile in range(3, len(by_len) + 1):      # the longest sampled lists first, until enough Gaussians are
-            sub = by_len[:ntile]                     # complete inside them (a ring view has sparse border tiles)
-            inp = np.zeros(sc.n, np.int64)
-            for t in sub:
-                np.add.at(inp, gs[rg[t, 0]:rg[t, 1]], 1)
-            full = np.nonzero((inp > 0) & (allp == inp))[0]
-            if full.size > 12:
-                break
-        assert full.size > 5, (v, full.size)
+        # ---- gradients of the Gaussians complete inside two contiguous windows of tiles (image centre and around the
+        # longest list): every one of them gets its whole gradient there -- a thousand or more per view, with a
+        # reference gradient that is not zero (view 2 looks along the scene's long axis: most of a random tile's
+        # Gaussians are hidden behind saturated pixels and receive none)
+        sub = gradient_windows(rg, gx, (H + 15) // 16, count=3)[:]
+        full = complete_inside(gs, rg, sub, sc.n)
+        assert full.size > 500, (v, full.size)
         dl64 = host(dls[v]).astype(np.float64)
+        near = np.zeros(sc.n, bool)
         o_g2 = O.draw_backward(W, H, rg, gs, o_us, o_ci, alphas64, o_col, hcont, htau, dl64, None, O.POLICY_G,
-                               tiles=sub)
+                               tiles=sub, near_out=near, near_margin=1e-3)
         _, _, _, _, J = _oracle_2d(sc, cnp, full, True)
         og = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], cnp.Rcw, J)
         want = dict(pws=og["dpws"], shs=og["dshs"], alphas=og["dalphas"][:, None], scales=og["dscales"],
@@ -147,7 +149,8 @@ def test_eight_ring_views_full_size():
         got = {k: host(g[k])[full] for k in NAMES} | {"us": host(dus)[full]}
         for k in want:
             assert got[k].shape == want[k].shape, (v, k)
-            assert_grad_close(got[k], want[k], "ring_view%d:%s" % (v, k))
+            r = assert_grad_close_flips(got[k], want[k], near[full], "ring_view%d:%s" % (v, k))
+            assert r["n_big"] > 50, (v, k, r)
     # the views really are different workloads
     assert len({s[0] for s in stats}) == N_VIEWS, stats
     assert max(s[3] for s in stats) > stats[0][3], stats      # a ring view needs more depth-key bits than view 0
