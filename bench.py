@@ -90,10 +90,12 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         "k_draw_bwd": 112 * P + 8 * T + 20 * HW,
         "k_chain_rule": N * (436 - 24 + 24 + 36 + 4 * (3 + 3 * nc + 3 + 4)),
         # fused path: parameters in (pw 12, rot 16, scale 12, sh 4K, alpha 4); out: depth 4, mask 1, the packed
-        # 48-B record, and the binning's packed rect 8 + depth key 4 + id 4          (= 305 N at K = 48)
-        "k_preprocess_fwd": N * (44 + 4 * K + 4 + 1 + 48 + 16),
-        # parameters + depth + packed gradient record in, 59 gradient floats + du out (= 528 N at K = 48)
-        "k_preprocess_bwd": N * (40 + 4 * K + 4 + 48 + 4 * (3 + K + 1 + 3 + 4 + 2)),
+        # 48-B record, the binning's compact record 16 -- and, in the training instance, dcolor/dpw 36 for the
+        # backward kernel                                                          (= 341 N at K = 48)
+        "k_preprocess_fwd": N * (44 + 4 * K + 4 + 1 + 48 + 16 + 36),
+        # pw 12, rot 16, scale 12, depth 4, packed gradient record 48, dcolor/dpw 36 in (the SH rows are NOT read:
+        # the forward kernel left dcolor/dpw); 59 gradient floats + du out        (= 372 N at K = 48)
+        "k_preprocess_bwd": N * (40 + 4 + 48 + 36 + 4 * (3 + K + 1 + 3 + 4 + 2)),
         "k_unpack_grads": N * (48 + 36),
     }
     return table.get(kernel)
@@ -132,6 +134,19 @@ def cpu_baseline(scene, sample_n):
                        "first %d of %d iid Gaussians at %dx%d, %.1f s measured, x%.0f linear extrapolation; "
                        % (sample_n, scene.n, cam.width, cam.height, dt, scene.n / sample_n)) +
                       "single-threaded NumPy patch loop == reference forward_cpu.py"}
+
+
+def relaunch_command(gpus, env, argv):
+    """``python bench.py --gpus N`` (N > 1) started WITHOUT a launcher (no WORLD_SIZE / RANK in the environment):
+    the argv of ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py <same flags>`` to exec instead -- one rank per GPU over RCCL, the very command the
+    driver's contract names -- so that either way of starting the multi-GPU bench yields the one JSON line.
+    None when no relaunch is due (N == 1, or already running under a launcher)."""
+    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+        return None
+    port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+            "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
 
 
 def main():
@@ -173,6 +188,10 @@ def main():
                     help="fused mode: validate the patch count inside forward (one host wait per render) instead of "
                          "at the step's commit()")
     a = ap.parse_args()
+    cmd = relaunch_command(a.gpus, os.environ, sys.argv[1:])
+    if cmd is not None:       # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU)
+        sys.stdout.flush()
+        os.execv(cmd[0], cmd)
 
     import torch
     import torch.distributed as dist
@@ -184,9 +203,9 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit("--gpus %d needs `python -m torch.distributed.run --nproc-per-node %d bench.py ...`"
-                             % (a.gpus, a.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ...` (or plain `python bench.py --gpus %d`, which "
+                         "re-executes itself that way)" % (a.gpus, world, a.gpus, a.gpus, a.gpus))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # EGS_FORCE_EXCHANGE=1 runs the RCCL gradient exchange even with one rank (a 1-GPU box can then
@@ -419,14 +438,23 @@ def main():
             else P_drawn
         max_len = int(lens.max().item())
         pairs = int(lens.sum().item()) * 256
-        # forward-only rate (BASELINE configs[1]), untimed by the headline
+        # forward-only rate (BASELINE configs[1]), untimed by the headline.  The statistics above went through host
+        # reads and a seven-op render: re-ramp the clocks first (as the headline does), then time.
+        nf = max(3, a.steps // 2)
+        for _ in range(min(max(0, a.ramp_steps), 200)):
+            forward_only()
         torch.cuda.synchronize()
         tf0 = time.perf_counter()
-        nf = max(3, a.steps // 2)
         for _ in range(nf):
             forward_only()
         torch.cuda.synchronize()
         fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
+    # per-kernel algorithmic rate of the headline step (each input read once, each output written once)
+    for k, row in kernels.items():
+        ab = algorithmic_bytes(k, sc.n, P, T, HW, a.sh_dim)
+        if ab and row.get("avg_us"):
+            row["algorithmic_GBs"] = round(ab / (row["avg_us"] * 1e-6) / 1e9, 1)
+            row["frac_of_hbm_peak"] = round(ab / (row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
 
     # the unmodified-caller surface: GSFunction over the seven ops (six with calc_J=True, splat, splatB and the
     # chain-rule kernel over the stored Jacobians) -- an extra, outside the timed region
@@ -456,6 +484,7 @@ def main():
                 ab = algorithmic_bytes(k, sc.n, P, T, HW, a.sh_dim)
                 if ab:
                     row["algorithmic_GBs"] = round(ab / (tot / c * 1e-3) / 1e9, 1)
+                    row["frac_of_hbm_peak"] = round(ab / (tot / c * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
                 ops_kernels[k] = row
         GSFunction.mode = a.mode
         for p in params.values():

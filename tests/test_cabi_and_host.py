@@ -172,3 +172,27 @@ def test_bench_flags_of_the_contract_and_of_this_build():
     for flag in ("--gpus", "--steps", "--warmup", "--views-per-rank", "--view-streams", "--overlap-exchange",
                  "--no-ops", "--no-ring8", "--cpu-sample", "--ramp-steps"):
         assert flag in out.stdout, flag
+
+
+def test_bench_relaunches_itself_under_the_launcher_for_several_gpus():
+    """``python bench.py --gpus N`` without WORLD_SIZE re-executes itself as the contract's command
+    ``python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py
+    --gpus N ...`` (one rank per GPU over RCCL); under a launcher, or with one GPU, it runs in place."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("egs_bench_module", os.path.join(REPO, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    argv = ["--gpus", "4", "--steps", "7", "--warmup", "2"]
+    cmd = bench.relaunch_command(4, {}, argv)
+    assert cmd[0] == sys.executable and cmd[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "4"
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and cmd[cmd.index("--master-port") + 1].isdigit()
+    i = cmd.index(os.path.join(REPO, "bench.py"))
+    assert cmd[i + 1:] == argv                                   # the flags travel unchanged
+    assert bench.relaunch_command(4, {"MASTER_PORT": "29611"}, argv)[cmd.index("--master-port") + 1] == "29611"
+    assert bench.relaunch_command(1, {}, ["--gpus", "1"]) is None
+    assert bench.relaunch_command(4, {"WORLD_SIZE": "4", "RANK": "0"}, argv) is None     # already launched
+    # and the launcher really accepts that command line (parse only: --help of torch.distributed.run)
+    out = subprocess.run(cmd[:3] + ["--help"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "--nproc-per-node" in out.stdout.replace("_", "-")
