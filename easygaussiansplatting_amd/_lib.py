@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegs_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 
 class EgsPolicy(C.Structure):
@@ -65,6 +65,11 @@ SIGNATURES = {
                            _P, _P, _P, _P, _P]),
     "egs_pack_records": (_i, [_i, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P]),
     "egs_splat_bwd_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P]),
+    "egs_splat_bwd_rec_lists": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _i,
+                                     _P]),
+    "egs_splat_bin_pack": (_i, [_i, _i, _i, _P, _P, _P, _P, _P, _P, _PP, _i, _P, _sz, _P, _P, _P, _P]),
+    "egs_strip_list_masks": (_i, [_i64, _P, _P, _P, _P]),
+    "egs_probe_set_hit_bits": (_i, [_P]),
     "egs_sort_pairs_ws_bytes": (_sz, [_i64]),
     "egs_sort_pairs": (_i, [_i64, _P, _P, _P, _P, _i, _i, _P, _sz, C.POINTER(C.c_int), _P]),
     "egs_scan_ws_bytes": (_sz, [_i64]),

@@ -114,9 +114,14 @@ static_assert(sizeof(BinRec) == 32, "BinRec is two dwordx4");
 //     a ring view of the 1 M scene sit in rects larger than 4 x 4 tiles, 0.3 % of view 0's).
 //   larger rect (EGS_CR_BIG):  b_lo = patch count, b_hi != 0: cullable -- k_bin_emit walks the rows of the rect with
 //     br[gaussian]; b_hi == 0: every tile of the rect.
+//   EGS_CR_ALLTILES (seven-op surface, k_pack_bin): the lists are the REFERENCE's -- every tile of the rect, row-major --
+//     and the footprint only supplies the block mask of each tile (possibly empty: the entry stays in the list and is
+//     never evaluated).  Rect of at most 4 x 4 tiles: b = the block bitmap as above; EGS_CR_BIG with b_hi == 2: every
+//     tile of the rect, masks from br[gaussian].
 #define EGS_CR_BIG 0x80000000u
 #define EGS_CR_TILEMAP 0x40000000u
-#define EGS_CR_WH_MASK 0x3FFFFFFFu
+#define EGS_CR_ALLTILES 0x20000000u
+#define EGS_CR_WH_MASK 0x1FFFFFFFu
 struct BinCountOut {  // where k_bin_count's results live inside the bin workspace
   uint4* cr;                       // compact bin record per Gaussian
   BinRec* br;                      // footprint record, written for the cullable Gaussians with a rect larger than 4 x 4 tiles only

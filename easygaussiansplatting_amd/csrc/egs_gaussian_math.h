@@ -519,6 +519,7 @@ __device__ __forceinline__ unsigned long long cr_tile_bits(unsigned long long bl
 }
 __device__ __forceinline__ uint32_t cr_count(const uint4& c) {
   if (c.y & EGS_CR_BIG) return c.z;
+  if (c.y & EGS_CR_ALLTILES) return (c.y & 0xFFFFu) * ((c.y & EGS_CR_WH_MASK) >> 16);   // the whole rect
   const unsigned long long b = ((unsigned long long)c.w << 32) | c.z;
   return (uint32_t)__popcll((c.y & EGS_CR_TILEMAP) ? b : cr_tile_bits(b));
 }

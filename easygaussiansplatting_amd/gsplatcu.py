@@ -289,11 +289,13 @@ def _alphas(alphas, n):
 # the gradient records are cleared).
 _memo_enabled = False
 _splat_memo = {}
+MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's list values (egs_splat_bin_pack)
 
 
 class SplatRecords:
     """Opaque: what one ``splat`` call left for the ``splatB`` of the same tensors (see above)."""
-    __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream")
+    __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream",
+                 "lists", "pair", "pair_sig")
 
     def matches(self, dev, st, tensors, width, height):
         if (self.dev_index != dev.index or self.stream != int(st.value or 0) or self.width != width
@@ -327,14 +329,28 @@ def _memo_sig(tensors):
         return None
 
 
-def _make_records(dev, st, tensors, width, height, rec, order, gpack):
+def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None, pair=None):
     sig = _memo_sig(tensors)
     if sig is None:
         return None
     h = SplatRecords()
     h.tensors, h.sig, h.width, h.height, h.policy = tensors, sig, width, height, _policy_name
     h.rec, h.order, h.gpack, h.dev_index, h.stream = rec, order, gpack, dev.index, int(st.value or 0)
+    # the list WITH block masks the forward draw walked, valid for the (gsid_per_patch, patch_range_per_tile) pair
+    # this splat returned -- and only for it
+    h.lists, h.pair, h.pair_sig = lists, pair, (_memo_sig(pair) if pair is not None else None)
+    if h.pair_sig is None:
+        h.lists = None
     return h
+
+
+def _walked_lists(h, gsid, ranges):
+    """The masked list of the handle if ``gsid`` / ``ranges`` are the pair its splat returned (same memory, same
+    version), else None: splatB then walks the caller's plain list with the per-entry box test."""
+    if h is None or h.lists is None:
+        return None
+    sig = _memo_sig((gsid, ranges))
+    return h.lists if (sig is not None and sig == h.pair_sig and _memo_sig(h.pair) == sig) else None
 
 
 def _take_records(h, dev, st, tensors, width, height):
@@ -392,31 +408,55 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
     order = torch.empty(lib.egs_tile_order_len(width, height), dtype=torch.int32, device=dev)
     gpack = None
     keep = bool(keep) and n > 0 and _pol().footprint != 1   # (pixel-box records also depend on `areas`, which this op mutates)
+    # Tile-footprint policies with a skip threshold: records and binning state in ONE pass (egs_splat_bin_pack); the
+    # lists are the reference's (gsid_per_patch bit-exact), their values carry exact 8x8-block masks the draw kernels
+    # take instead of testing a box per entry.  The masked list stays internal; the caller gets the stripped copy.
+    masks = MASKED_LISTS and n > 0 and _pol().footprint == 0 and _pol().alpha_skip > 0 and n < (1 << 28)
+    flags = 2 if masks else 0            # EGS_DRAW_MASKED_LISTS
     if n > 0:
-        _lib.check(lib.egs_pack_records(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
-                                        _ptr(areas), pol, _ptr(rec), st))
+        if not masks:
+            _lib.check(lib.egs_pack_records(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
+                                            _ptr(areas), pol, _ptr(rec), st))
         if keep:
             # the packed gradient records of a splatB that may follow: cleared on the side by the draw kernel (it is
             # VALU-bound, the memory system idles), good for ONE backward pass
             gpack = torch.empty((n, 12), dtype=torch.float32, device=dev)
+    lists = [None]     # the list the draw kernels walked (with masks), kept for the backward draw
 
-    def records():    # only once the draw stage is enqueued: the order buffer is written, the gradient records cleared
-        return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack) if keep else None
+    def records(gsid):    # only once the draw stage is enqueued: the order buffer is written, the gradient records cleared
+        if not keep:
+            return None
+        return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
+                             lists[0], (gsid, ranges) if lists[0] is not None else None)
+
+    def enqueue_bin(hint, total, host_slot=None):
+        if masks:
+            _lib.check(lib.egs_splat_bin_pack(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
+                                              _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
+                                              _ptr(total), host_slot, _ptr(rec), st))
+        elif host_slot is not None:
+            _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint,
+                                            _ptr(ws_bin), ws_bin_bytes, _ptr(total), host_slot, st))
+        else:
+            _lib.check(lib.egs_splat_bin(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint,
+                                         _ptr(ws_bin), ws_bin_bytes, _ptr(total), st))
 
     def draw_exact(patches):
         gsid = torch.empty(patches, dtype=torch.int32, device=dev)
+        walked = torch.empty(patches, dtype=torch.int32, device=dev) if masks else gsid
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges),
-                                          _ptr(gsid), _ptr(order), _ptr(gpack), None, 0, 0, st))
+                                          _ptr(walked), _ptr(order), _ptr(gpack), None, 0, flags, st))
+        if masks:
+            _lib.check(lib.egs_strip_list_masks(patches, None, _ptr(walked), _ptr(gsid), st))
+            lists[0] = walked
         return gsid
 
     def render_exact():
         """The reference's sequence (gausplat.cu:50-105): bin, read P back, draw -- the GPU idles around the read."""
-        patches = _bin_stage(lambda hint, total: _lib.check(lib.egs_splat_bin(
-            n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
-            _ptr(total), st)), dev, key)
+        patches = _bin_stage(enqueue_bin, dev, key)
         return patches, draw_exact(patches)
 
     # From the second call of a problem size on, the draw stage is enqueued BEHIND the binning stage before the
@@ -436,23 +476,24 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         if n > 0:
             with ctx.lock:
                 ctx.capacity[key] = max(ctx.capacity.get(key, 0), _fused._grow(patches))
-        return [image, contrib, final_tau, ranges, gsid], records()
+        return [image, contrib, final_tau, ranges, gsid], records(gsid)
     t = _fused._Ticket()
     t.ctx, t.key, t.cap, t.state, t.status, t.collected, t.slot = ctx, key, cap, None, _fused._Ticket.PENDING, True, slot
     t.hint = _get_key_bits(dev.index, key)
     try:
         total = torch.empty(2, dtype=torch.int32, device=dev)
         _lib.check(lib.egs_mailbox_arm(ctx.mb, slot, st))
-        _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, t.hint,
-                                        _ptr(ws_bin), ws_bin_bytes, _ptr(total),
-                                        C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot)), st))
+        enqueue_bin(t.hint, total, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot)))
         gsid_full = torch.empty(cap, dtype=torch.int32, device=dev)
+        walked_full = torch.empty(cap, dtype=torch.int32, device=dev) if masks else gsid_full
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
         _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, width, height, _ptr(rec), pol, _ptr(ws_bin),
                                               _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
-                                              _ptr(final_tau), _ptr(ranges), _ptr(gsid_full), _ptr(order), _ptr(gpack),
-                                              None, 0, 0, st))
+                                              _ptr(final_tau), _ptr(ranges), _ptr(walked_full), _ptr(order),
+                                              _ptr(gpack), None, 0, flags, st))
+        if masks:
+            _lib.check(lib.egs_strip_list_masks(cap, _ptr(total), _ptr(walked_full), _ptr(gsid_full), st))
     except BaseException:
         # Kernels enqueued before the failure (the arm, the binning chain) still store {P, max key} into the slot:
         # it may only go back on the free list once they have run, or a later render that picks it up could settle
@@ -472,9 +513,14 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         if t.patches >= 2**31:
             raise RuntimeError("splat: %d tile patches overflow int32 indexing" % t.patches)
         if t.hint < 32 and t.need > t.hint:  # stale depth-key hint: everything again (the stage is idempotent)
-            return [image, contrib, final_tau, ranges, render_exact()[1]], records()
-        return [image, contrib, final_tau, ranges, draw_exact(t.patches)], records()   # more patches than ever before
-    return [image, contrib, final_tau, ranges, gsid_full[:t.patches]], records()
+            gsid = render_exact()[1]
+        else:
+            gsid = draw_exact(t.patches)     # more patches than ever before
+        return [image, contrib, final_tau, ranges, gsid], records(gsid)
+    gsid = gsid_full[:t.patches]
+    if masks:
+        lists[0] = walked_full
+    return [image, contrib, final_tau, ranges, gsid], records(gsid)
 
 
 def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
@@ -508,15 +554,18 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
     ws_bytes = lib.egs_splat_bwd_ws_bytes(n)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     st = _stream()
-    rec, order, gpack = (None, None, None)
+    rec, order, gpack, walked = (None, None, None, None)
     if n > 0 and pol.footprint != 1:   # (the pixel-box policy's records also depend on `areas`, which splat mutates)
         h = records if records is not None else (_splat_memo.get((dev.index, int(st.value or 0))) if _memo_enabled else None)
         rec, order, gpack = _take_records(h, dev, st, (us, cinv2ds, alphas, colors), width, height)
+        if rec is not None:            # ... and the list with block masks, if gsid / ranges are that splat's own pair
+            walked = _walked_lists(h, gsid, ranges)
     if rec is not None:     # the records (and the measured per-tile work) of the splat call these tensors came from
-        _lib.check(lib.egs_splat_bwd_rec(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
-                                         _ptr(final_tau), _ptr(ranges), _ptr(gsid), _ptr(dl), _ptr(ws), ws_bytes,
-                                         _ptr(order), _ptr(gpack), _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha),
-                                         _ptr(d_color), st))
+        _lib.check(lib.egs_splat_bwd_rec_lists(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
+                                               _ptr(final_tau), _ptr(ranges), _ptr(gsid if walked is None else walked),
+                                               _ptr(dl), _ptr(ws), ws_bytes, _ptr(order), _ptr(gpack), _ptr(d_us),
+                                               _ptr(d_cinv), _ptr(d_alpha), _ptr(d_color), 0 if walked is None else 2,
+                                               st))
     else:
         _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
                                      _ptr(colors), _ptr(areas), C.byref(pol), _ptr(contrib), _ptr(final_tau),

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 4
+#define EGS_ABI_VERSION 5
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -158,6 +158,24 @@ int egs_splat_draw_dev(int n, int64_t patch_capacity, const uint32_t* total_patc
 int egs_pack_records(int n, int width, int height, const float* us, const float* cinv2ds, const float* alphas,
                      const float* colors, const int32_t* areas /*pixel-box policy only*/, const EgsPolicy* pol,
                      void* rec, void* stream);
+/* splat (ext.cpp:10-18, gausplat.cu:24-112), tile-footprint policies with a skip threshold (pol->footprint == 0,
+ * pol->alpha_skip > 0): egs_pack_records and egs_splat_bin(_mb) as ONE pass over the 2D Gaussians.  `rec` receives the
+ * packed records; the binning state left in ws_bin makes egs_splat_draw_rec* (flags = EGS_DRAW_MASKED_LISTS) emit the
+ * reference's lists with exact block masks in their values.  depths / areas are updated in place as by egs_splat_bin
+ * (kernel.cu:114-119).  host_totals nullable (page-locked mailbox slot, see egs_splat_bin_mb). */
+int egs_splat_bin_pack(int n, int width, int height, const float* us, const float* cinv2ds, const float* alphas,
+                       const float* colors, int32_t* areas, float* depths, const EgsPolicy* pol, int key_bits_hint,
+                       void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* rec,
+                       void* stream);
+/* plain[i] = masked[i] & 0x0FFFFFFF for i < min(count, *count_dev) (count_dev nullable: a device-side patch count
+ * the host has not read yet): gsid_per_patch as the reference returns it (gausplat.cu:108-111). */
+int egs_strip_list_masks(int64_t count, const uint32_t* count_dev, const void* masked, int32_t* plain, void* stream);
+/* egs_splat_bwd_rec with flags = EGS_DRAW_MASKED_LISTS: gsid_per_patch is the masked list the forward draw walked. */
+int egs_splat_bwd_rec_lists(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
+                            const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                            const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                            const int32_t* tile_order, float* grad_records, float* dloss_dus, float* dloss_dcinv2ds,
+                            float* dloss_dalphas, float* dloss_dcolors, int flags, void* stream);
 int egs_splat_bwd_rec(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
                       const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                       const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
@@ -267,6 +285,11 @@ int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_
 /* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
  * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
 int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
+/* Measurement helper (tools/bwd_hit_stats.py): one bit per list entry of the NEXT backward draws of this process
+ * (bit i = entry i of gsid_per_patch blended into some pixel of its tile; NULL switches the probe off).  Entries with
+ * a 0 bit are dropped by k_draw_bwd before staging.  Prices a "the forward draw leaves a hit bit per entry" design
+ * from the backward side alone; never set by the product path. */
+int egs_probe_set_hit_bits(const void* bits);
 /* Mailbox for that read-back: `slots` page-locked landing zones, each with a HIP event.  egs_mailbox_post
  * enqueues the asynchronous 8-byte copy of total_patches[0..1] into a slot on `stream` and records the
  * slot's event behind it; egs_mailbox_fetch returns 1 and the two words once the copy has landed, 0 when it
@@ -302,6 +325,13 @@ size_t egs_fused_backward_ws_bytes(int n);
  * accumulation kernels for a rank that renders several views per step (bench.py --views-per-rank, Trainer.step). */
 #define EGS_BWD_ACCUMULATE 64
 #define EGS_DRAW_CULLED_LISTS 1
+/* flags of egs_splat_draw_rec* / egs_splat_bwd_rec_lists: the lists are the REFERENCE's complete lists (every tile of
+ * every rect, kernel.cu:46-80) whose values carry the same 4-bit block masks above the Gaussian index -- what
+ * egs_splat_bin_pack prepares.  The draw kernels take the masks instead of testing the record's certain-miss box per
+ * entry (1.95 instead of 2.35 block evaluations per entry, entries with an empty mask cost a list read); images and
+ * gradients are unchanged (the pixels skipped are pixels the reference `continue`s on, kernel.cu:246).  The caller
+ * hands gsid_per_patch back to ITS caller through egs_strip_list_masks. */
+#define EGS_DRAW_MASKED_LISTS 2
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
  * phase 2: only the per-Gaussian chain rule for rows [row_begin, row_begin + row_count), row_begin a multiple
  * of 256, reading the records phase 1 left in the SAME ws: a data-parallel caller launches the rows in a few

@@ -45,4 +45,9 @@ out["ranges"] = ranges; out["gsid"] = gsid
 assert np.isfinite(out["image_skip"]).all() and np.isfinite(out["image_cuda"]).all()
 d = np.abs(out["image_skip"] - out["image_cuda"]).max(0)
 print("pixels that differ:", int((d > 1e-6).sum()), "of", W * H, "max", d.max())
-np.savez_compressed(os.path.join(os.path.dirname(os.path.abspath(__file__)), "g10_nan_conic.npz"), **out)
+O.NAN_MAHA = "cuda"
+from tests.golden import _recipe   # noqa: E402
+_recipe.begin("--check" in sys.argv[1:])
+_recipe.save("g10_nan_conic.npz", "G10: oracle/gs_oracle.py splat on four 2D Gaussians, two of them with a non-finite "
+             "conic: NAN_MAHA = 'skip' (this build) and 'cuda' (fmaxf(0, NaN) = 0, kernel.cu:243-246)", **out)
+sys.exit(_recipe.finish())

@@ -72,9 +72,14 @@ def assert_grad_close_flips(got, ref, near, name="", near_frac=0.02, near_tol=2e
     r = assert_grad_close(got[~near], ref[~near], name, **kw)
     has = np.abs(ref.reshape(ref.shape[0], -1)).max(1) > 0
     n_near = int((near & has).sum())
+    err = float(np.abs(got[near] - ref[near]).max() / np.abs(ref).max()) if n_near else 0.0
+    r["n_near"], r["n_rows"], r["near_err"] = n_near, int(has.sum()), err
+    path = os.environ.get("EGS_GRAD_STATS")
+    if path:
+        with open(path, "a") as f:
+            f.write(json.dumps(dict(name=str(name) + ":near", n_near=n_near, n_rows=int(has.sum()), near_err=err)) + "\n")
+        if os.environ.get("EGS_GRAD_STATS_ONLY"):
+            return r
     assert n_near <= max(3, near_frac * has.sum()), (name, "threshold-flip Gaussians", n_near, int(has.sum()))
-    if n_near:
-        err = np.abs(got[near] - ref[near]).max() / np.abs(ref).max()
-        assert err <= near_tol, (name, "threshold-flip Gaussians off by", err)
-    r["n_near"] = n_near
+    assert err <= near_tol, (name, "threshold-flip Gaussians off by", err)
     return r

@@ -29,6 +29,15 @@ def test_recipe_regenerates_the_committed_fixture(recipe, args):
     assert "CHECK ok" in r.stdout
 
 
+def test_oracle_generated_fixtures_regenerate_too():
+    """G10 (NaN conic) comes from the repository's oracle, not from the reference (no CUDA device exists to run
+    kernel.cu:243-246); its recipe has the same --check.  (G11's takes ~6 minutes of 8 cores: run by hand,
+    `python tests/golden/make_golden_g11.py --check`; tests/test_oracle_golden.py re-derives a sample of its tiles.)"""
+    r = subprocess.run([sys.executable, os.path.join(GOLDEN, "make_golden_nan.py"), "--check"], cwd=REPO,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "CHECK ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
 def test_guard_rejects_a_module_that_is_not_the_reference():
     from tests.golden import _recipe
     import easygaussiansplatting_amd.scene as not_ref

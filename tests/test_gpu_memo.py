@@ -33,8 +33,17 @@ def gsc():
     gsplatcu.set_policy("gsplatcu")
 
 
-def _inputs(gsc, n=3000, w=160, h=96, seed=7):
+def _inputs(gsc, n=3000, w=160, h=96, seed=7, mod=None):
     sc = S.small_scene(n, w, h, 3, seed=seed)
+    if mod == "giants":                   # rects far beyond 4 x 4 tiles, some covering the image
+        sc.scales[:40] *= 30.0
+        sc.alphas[:40] = np.minimum(sc.alphas[:40], 0.2)
+    elif mod == "needles":                # large rects, thin footprints: most tiles of a rect get an empty mask
+        sc.scales[:, 0] = 0.4
+        sc.scales[:, 1:] = 0.004
+    elif mod == "faint":                  # alpha below / barely above alpha_skip: empty and one-pixel footprints
+        sc.alphas[:1000] = 0.0015
+        sc.alphas[1000:2000] = 0.00205
     cam = sc.cam
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
     pws, rots, scales, alphas, shs = map(dev, (sc.pws, sc.rots, sc.scales, sc.alphas, sc.shs))
@@ -182,3 +191,40 @@ def test_autograd_grad_inside_accumulate_in_kernel_and_zero_padding(gsc):
         img3.backward(dl)                                        # .backward(): accumulated in the kernel
         for b, t in zip(before, L):
             assert float((t.grad - 2 * b).abs().max()) <= 4e-5 * float(b.abs().max())
+
+
+@pytest.mark.parametrize("mod", [None, "giants", "needles", "faint"])
+def test_masked_lists_of_the_seven_op_surface_change_no_output(gsc, mod, monkeypatch):
+    """Round 4: ``splat`` bins with exact 8x8-block masks in its list values (egs_splat_bin_pack, EGS_DRAW_MASKED_LISTS)
+    and returns the stripped list.  Every output is BIT-identical to the unmasked path (MASKED_LISTS = False: the
+    reference's lists + the per-entry box test) -- the masks only skip pixels the reference `continue`s on
+    (kernel.cu:246) -- and the backward draw over the masked list (handle path) gives the gradients of the plain one."""
+    d = _inputs(gsc, mod=mod)
+    args = lambda q: (q["H"], q["W"], q["us"], q["cinv"], q["alphas"], q["depths"].clone(), q["col"], q["areas"].clone())
+    monkeypatch.setattr(gsc, "MASKED_LISTS", False)
+    ref = gsc.splat(*args(d))
+    ref2, h0 = gsc.splat_with_records(*args(d))
+    assert h0 is not None and h0.lists is None
+    monkeypatch.setattr(gsc, "MASKED_LISTS", True)
+    for rep in range(3):                       # (exact sequence, then twice enqueue-ahead with the learnt capacity)
+        a = args(d)
+        out, h = gsc.splat_with_records(*a)
+        torch.cuda.synchronize()
+        assert h is not None and h.lists is not None
+        for x, y in zip(ref, out):
+            assert torch.equal(x, y)
+        # the walked list = the returned list + a 4-bit mask above bit 28
+        walked = h.lists[:out[4].shape[0]]
+        assert torch.equal(walked & 0x0FFFFFFF, out[4])
+        masks = (walked >> 28) & 0xF
+        if mod in ("needles", "faint"):
+            assert int((masks == 0).sum()) > 0.05 * masks.numel()      # entries that reach no block of their tile
+        q = dict(d); q["depths"], q["areas"] = a[5], a[7]
+        plain = _splatB(gsc, q, out)                                    # public path: box test on the plain list
+        masked = _splatB(gsc, q, out, records=h)                        # handle: the masked list
+        torch.cuda.synchronize()
+        _same(masked, plain)
+        # a DIFFERENT gsid tensor (a clone) must not pick the masked list up
+        assert gsc._walked_lists(h, out[4], out[3]) is not None
+        assert gsc._walked_lists(h, out[4].clone(), out[3]) is None and gsc._walked_lists(h, out[4], out[3].clone()) is None
+    _same(masked, _truth(gsc, q, out))

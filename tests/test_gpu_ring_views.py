@@ -25,8 +25,8 @@ from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
 from tests.conftest import load_golden
 from tests.gradcheck import assert_grad_close_flips
-from tests.test_gpu_parity import (_oracle_2d, check_against_g11, check_culled_lists, complete_inside, dev,
-                                   gradient_windows, host)
+from tests.test_gpu_parity import (FUSED_1M_TOL, _oracle_2d, check_against_g11, check_culled_lists, complete_inside,
+                                   dev, gradient_windows, host)
 
 pytestmark = pytest.mark.gpu
 
@@ -115,7 +115,7 @@ def test_eight_ring_views_full_size():
         per_view.append({k: g[k].clone() for k in NAMES})
         him = host(image)
         # ALL tiles of this view against the all-tile digest of the pinned oracle (fixture G11)
-        check_against_g11(g11, v, him, htau, W, H, label="ring_view%d" % v)
+        check_against_g11(g11, v, him, htau, W, H, label="ring_view%d" % v, culled_lens=lens)
         sel = (S.uniform01(40 + v, 2, (8,)) * T).astype(np.int64)
         sel = np.array([t for t in sel if lens[t] > 0] or [int(np.argmax(lens))])
         dropped, kept, bdev, btrue = check_culled_lists(st, sel[:4], o_us, o_ci, alphas64, hdepth,
@@ -141,7 +141,7 @@ def test_eight_ring_views_full_size():
         dl64 = host(dls[v]).astype(np.float64)
         near = np.zeros(sc.n, bool)
         o_g2 = O.draw_backward(W, H, rg, gs, o_us, o_ci, alphas64, o_col, hcont, htau, dl64, None, O.POLICY_G,
-                               tiles=sub, near_out=near, near_margin=1e-3)
+                               tiles=sub, near_out=near, near_margin=3e-4)
         _, _, _, _, J = _oracle_2d(sc, cnp, full, True)
         og = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], cnp.Rcw, J)
         want = dict(pws=og["dpws"], shs=og["dshs"], alphas=og["dalphas"][:, None], scales=og["dscales"],
@@ -149,7 +149,7 @@ def test_eight_ring_views_full_size():
         got = {k: host(g[k])[full] for k in NAMES} | {"us": host(dus)[full]}
         for k in want:
             assert got[k].shape == want[k].shape, (v, k)
-            r = assert_grad_close_flips(got[k], want[k], near[full], "ring_view%d:%s" % (v, k))
+            r = assert_grad_close_flips(got[k], want[k], near[full], "ring_view%d:%s" % (v, k), **FUSED_1M_TOL)
             assert r["n_big"] > 50, (v, k, r)
     # the views really are different workloads
     assert len({s[0] for s in stats}) == N_VIEWS, stats

@@ -36,6 +36,7 @@ cont_t = cont.reshape(gy, 16, gx, 16).permute(0, 2, 1, 3).reshape(T, 16, 16)   #
 bmax = torch.stack([cont_t[:, 8 * (k >> 1):8 * (k >> 1) + 8, 8 * (k & 1):8 * (k & 1) + 8].amax((1, 2))
                     for k in range(4)], 1)                                      # [T,4]
 n_reach = n_hit = n_blk_test = n_blk_hit = n_lane = 0
+hit_all = torch.zeros(P, dtype=torch.bool, device=dev)
 n_walk = int((idx < bmax.amax(1)[tile_of]).sum())
 CH = 1 << 18
 for a in range(0, P, CH):
@@ -56,9 +57,53 @@ for a in range(0, P, CH):
         n_blk_test += int(rk.sum()); n_blk_hit += int(hk_any.sum()); n_lane += int(hk[hk_any].sum())
         reach_e |= rk; hit_e |= hk_any
     n_reach += int(reach_e.sum()); n_hit += int(hit_e.sum())
+    hit_all[a:b] = hit_e
 print("P (list entries) %d; entries below the tile's largest contrib %d (%.3f)" % (P, n_walk, n_walk / P))
 print("reach (todo) %d = %.3f of P; hit %d = %.3f of reach  -> a forward hit bit removes %.1f %% of the walked entries"
       % (n_reach, n_reach / P, n_hit, n_hit / n_reach, 100 * (1 - n_hit / n_reach)))
 print("blocks tested %d (%.2f per reach entry), hit %d (%.2f per hit entry, %.3f of tested)"
       % (n_blk_test, n_blk_test / n_reach, n_blk_hit, n_blk_hit / max(n_hit, 1), n_blk_hit / n_blk_test))
 print("lanes passing inside a hit block: %.1f of 64 (%.3f)" % (n_lane / n_blk_hit, n_lane / n_blk_hit / 64))
+
+if "--time" in sys.argv:
+    # VERDICT r3 task 4(a), priced from the backward side: hand k_draw_bwd the per-entry hit bits a forward pass
+    # could leave behind (egs_probe_set_hit_bits) and time it against the same launch without them.
+    import ctypes as C
+    from easygaussiansplatting_amd import _lib
+    from easygaussiansplatting_amd.function import GSFunction
+    lib = _lib.load()
+    words = (P + 31) // 32
+    padded = torch.zeros(words * 32, dtype=torch.bool, device=dev); padded[:P] = hit_all
+    w = (padded.view(words, 32).to(torch.int64) << torch.arange(32, device=dev)).sum(1)
+    bits = (w & 0xFFFFFFFF).to(torch.int64)
+    bits = torch.where(bits >= 2**31, bits - 2**32, bits).to(torch.int32).contiguous()
+    GSFunction.mode = "fused"
+    L = [t(sc.pws), t(sc.shs), t(sc.alphas).reshape(-1, 1), t(sc.scales), t(sc.rots)]
+    for x in L:
+        x.requires_grad_(True)
+    us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+    dl = t(S.normal(1, 77, (3, H, W))) / (3 * H * W)
+
+    def run(probe, reps=40):
+        lib.egs_probe_set_hit_bits(C.c_void_p(bits.data_ptr()) if probe else None)
+        for r in range(reps + 10):
+            if r == 10:
+                lib.egs_prof_set_filter(b"k_draw_bwd"); lib.egs_prof_reset(); lib.egs_prof_enable(1)
+            for x in L:
+                x.grad = None
+            us0.grad = None
+            img, _ = GSFunction.apply(*L, us0, cam)
+            img.backward(dl)
+        torch.cuda.synchronize()
+        lib.egs_prof_enable(0)
+        need = lib.egs_prof_report(None, 0)
+        buf = C.create_string_buffer(need + 16); lib.egs_prof_report(buf, need + 16)
+        lib.egs_probe_set_hit_bits(None)
+        row = [ln.split() for ln in buf.value.decode().splitlines() if ln.startswith("k_draw_bwd")][0]
+        return float(row[2]) / int(row[1]) * 1e3, [x.grad.clone() for x in L]
+    for rnd in range(3):
+        t0, g0 = run(False)
+        t1, g1 = run(True)
+        worst = max(float((a - b).abs().max() / a.abs().max()) for a, b in zip(g0, g1))
+        print("round %d: k_draw_bwd %.1f us without the bits, %.1f us with them (%.1f %%); gradients differ by %.1e of their maximum"
+              % (rnd, t0, t1, 100 * (t1 / t0 - 1), worst))
