@@ -1,6 +1,6 @@
 #!/bin/bash
 # Collect the round's profile artefacts on the GPU box (run through gpurun); results land in gpurun_out/prof/.
-#   bash tools/collect_profiles.sh            then copy what should be judged into profiles/ (r3_* names)
+#   bash tools/collect_profiles.sh            then copy what should be judged into profiles/ (r4_* names)
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof; mkdir -p $O
