@@ -318,6 +318,96 @@ __device__ __forceinline__ void sh_jac_dpw(const ShDir<NC>& o, const float* sh, 
   }
 }
 
+// basis value of coefficient C from the direction alone, evaluated with NO contraction: the same bits in every
+// instantiation that inlines it (sh_color_and_jac_dpw<.., INLINE_B> with and without the Jacobian sums)
+#pragma clang fp contract(off)
+template <int C>
+__device__ __forceinline__ float sh_basis_term(float x, float y, float z) {
+  if constexpr (C == 0) return SH_C0_0;
+  else if constexpr (C == 1) return SH_C1_0 * y;
+  else if constexpr (C == 2) return SH_C1_1 * z;
+  else if constexpr (C == 3) return SH_C1_2 * x;
+  else if constexpr (C == 4) return SH_C2_0 * (x * y);
+  else if constexpr (C == 5) return SH_C2_1 * (y * z);
+  else if constexpr (C == 6) return SH_C2_2 * (2.0f * (z * z) - x * x - y * y);
+  else if constexpr (C == 7) return SH_C2_3 * (x * z);
+  else if constexpr (C == 8) return SH_C2_4 * (x * x - y * y);
+  else if constexpr (C == 9) return SH_C3_0 * y * (3.0f * (x * x) - y * y);
+  else if constexpr (C == 10) return SH_C3_1 * (x * y) * z;
+  else if constexpr (C == 11) return SH_C3_2 * y * (4.0f * (z * z) - x * x - y * y);
+  else if constexpr (C == 12) return SH_C3_3 * z * (2.0f * (z * z) - 3.0f * (x * x) - 3.0f * (y * y));
+  else if constexpr (C == 13) return SH_C3_4 * x * (4.0f * (z * z) - x * x - y * y);
+  else if constexpr (C == 14) return SH_C3_5 * z * (x * x - y * y);
+  else return SH_C3_6 * x * (x * x - 3.0f * (y * y));
+}
+#pragma clang fp contract(fast)
+// colour AND dcolor/dpw in ONE pass over the coefficients (round 4): every SH value is consumed by both sums the
+// moment it is first touched and its register is free afterwards -- with sh_color_f followed by sh_jac_dpw the whole
+// 4K-byte row stayed live through the first sum (k_preprocess_fwd<.., JW>: 100 VGPRs / 5 waves per SIMD, k_sh2color:
+// 106 / 4).  Same terms in the same order as the two functions it replaces (terms with a zero gradient are left out).
+// INLINE_B: the basis value of a term is re-evaluated from the direction where it is used instead of read from o.B --
+// for a caller that has already stored o.B (k_sh2color's dcolor_dshs output) and wants its 16 registers back.
+// JAC = false: the colour sum alone, through the SAME expressions (k_sh2color's calc_J = false path then rounds like its
+// calc_J = true path).
+template <int NC, bool INLINE_B = false, bool JAC = true>
+__device__ __forceinline__ void sh_color_and_jac_dpw(const ShDir<NC>& o, const float* sh, float* col, float* jp /*9*/) {
+  if constexpr (NC == 1) {
+    sh_color_f<NC>(o, sh, col);
+#pragma unroll
+    for (int j = 0; j < 9; ++j) jp[j] = 0.f;
+  } else {
+    const float x = o.x, y = o.y, z = o.z;
+    float cc[3] = {0.5f, 0.5f, 0.5f};
+    float dr[3][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+    // one coefficient: colour += B s, d colour / d dir += (gx, gy, gz) s  (compile-time flags drop the zero gradients)
+#define EGS_SH_TERM(c, BEXPR, HX, GX, HY, GY, HZ, GZ)                                   \
+    do {                                                                                \
+      const float b_ = INLINE_B ? sh_basis_term<c>(x, y, z) : o.B[c];                   \
+      _Pragma("unroll") for (int ch = 0; ch < 3; ++ch) {                                \
+        const float s_ = sh[3 * (c) + ch];                                              \
+        cc[ch] = __builtin_fmaf(b_, s_, cc[ch]);     /* (explicit: the same colour bits with and without JAC) */ \
+        if (JAC && (HX)) dr[ch][0] += (GX) * s_;                                        \
+        if (JAC && (HY)) dr[ch][1] += (GY) * s_;                                        \
+        if (JAC && (HZ)) dr[ch][2] += (GZ) * s_;                                        \
+      }                                                                                 \
+    } while (0)
+    EGS_SH_TERM(0, SH_C0_0, false, 0.f, false, 0.f, false, 0.f);
+    EGS_SH_TERM(1, SH_C1_0 * y, false, 0.f, true, SH_C1_0, false, 0.f);
+    EGS_SH_TERM(2, SH_C1_1 * z, false, 0.f, false, 0.f, true, SH_C1_1);
+    EGS_SH_TERM(3, SH_C1_2 * x, true, SH_C1_2, false, 0.f, false, 0.f);
+    if constexpr (NC > 4) {
+      EGS_SH_TERM(4, SH_C2_0 * (x * y), true, SH_C2_0 * y, true, SH_C2_0 * x, false, 0.f);
+      EGS_SH_TERM(5, SH_C2_1 * (y * z), false, 0.f, true, SH_C2_1 * z, true, SH_C2_1 * y);
+      EGS_SH_TERM(6, SH_C2_2 * (2.0f * (z * z) - x * x - y * y), true, -SH_C2_2 * 2 * x, true, -SH_C2_2 * 2 * y, true, SH_C2_2 * 4 * z);
+      EGS_SH_TERM(7, SH_C2_3 * (x * z), true, SH_C2_3 * z, false, 0.f, true, SH_C2_3 * x);
+      EGS_SH_TERM(8, SH_C2_4 * (x * x - y * y), true, SH_C2_4 * 2 * x, true, -SH_C2_4 * 2 * y, false, 0.f);
+    }
+    if constexpr (NC > 9) {
+      const float xx = x * x, yy = y * y, zz = z * z, xy = x * y, yz = y * z, xz = x * z;
+      EGS_SH_TERM(9, SH_C3_0 * y * (3.0f * xx - yy), true, 6.0f * SH_C3_0 * xy, true, SH_C3_0 * (3.0f * xx - 3.0f * yy), false, 0.f);
+      EGS_SH_TERM(10, SH_C3_1 * xy * z, true, SH_C3_1 * yz, true, SH_C3_1 * xz, true, SH_C3_1 * xy);
+      EGS_SH_TERM(11, SH_C3_2 * y * (4.0f * zz - xx - yy), true, -2 * SH_C3_2 * xy, true, SH_C3_2 * (-xx - 3.0f * yy + 4.0f * zz), true, 8.0f * SH_C3_2 * yz);
+      EGS_SH_TERM(12, SH_C3_3 * z * (2.0f * zz - 3.0f * xx - 3.0f * yy), true, -6.0f * SH_C3_3 * xz, true, -6.0f * SH_C3_3 * yz, true,
+                  SH_C3_3 * (-3.0f * xx - 3.0f * yy + 6.0f * zz));
+      EGS_SH_TERM(13, SH_C3_4 * x * (4.0f * zz - xx - yy), true, SH_C3_4 * (4.0f * zz - 3.0f * xx - yy), true, SH_C3_4 * (-2 * xy), true, 8.0f * SH_C3_4 * xz);
+      EGS_SH_TERM(14, SH_C3_5 * z * (xx - yy), true, 2 * SH_C3_5 * xz, true, -2 * SH_C3_5 * yz, true, SH_C3_5 * (xx - yy));
+      EGS_SH_TERM(15, SH_C3_6 * x * (xx - 3.0f * yy), true, SH_C3_6 * (3 * xx - 3 * yy), true, -6.0f * SH_C3_6 * xy, false, 0.f);
+    }
+#undef EGS_SH_TERM
+    col[0] = cc[0]; col[1] = cc[1]; col[2] = cc[2];
+    if constexpr (JAC) {
+      float p00, p11, p22, p01, p02, p12;
+      sh_ddir_dpw<NC>(o, p00, p11, p22, p01, p02, p12);
+#pragma unroll
+      for (int ch = 0; ch < 3; ++ch) {
+        jp[3 * ch + 0] = dr[ch][0] * p00 + dr[ch][1] * p01 + dr[ch][2] * p02;
+        jp[3 * ch + 1] = dr[ch][0] * p01 + dr[ch][1] * p11 + dr[ch][2] * p12;
+        jp[3 * ch + 2] = dr[ch][0] * p02 + dr[ch][1] * p12 + dr[ch][2] * p22;
+      }
+    }
+  }
+}
+
 #ifndef EGS_SH_NT_LOAD
 #define EGS_SH_NT_LOAD 0
 #endif

@@ -186,6 +186,17 @@ __global__ __launch_bounds__(256) void k_cov2d(int n, const float* __restrict__ 
 }
 
 // ---- sh2color                                         (reference kernel.cu:619-807)
+// A/B knobs: colour and dcolor/dpw in ONE pass over the SH row (sh_color_and_jac_dpw) in k_sh2color / in
+// k_preprocess_fwd<.., JW>.  Measured (round 4, same-box A/B): the training instance of k_preprocess_fwd drops from 82
+// to 60 VGPRs (5 -> 8 waves per SIMD) -- and gets SLOWER, 99 -> 110 us: more resident waves mean more SH rows competing
+// for the 32-KB L1 between the twelve row loads of a lane.  Off there.
+#ifndef EGS_SH_FUSED_JAC
+#define EGS_SH_FUSED_JAC 1
+#endif
+#ifndef EGS_SH_FUSED_JAC_PRE
+#define EGS_SH_FUSED_JAC_PRE 0
+#endif
+
 #ifndef EGS_SH2COLOR_WAVES     // A/B knob: minimum waves per SIMD of k_sh2color (106 VGPRs = 4 as compiled freely)
 #define EGS_SH2COLOR_WAVES 1
 #endif
@@ -200,11 +211,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EGS_SH2COLO
   const int base = blockIdx.x * 256, i = base + threadIdx.x;
   constexpr int K = 3 * NC;
   const bool jac = dcolor_dshs && dcolor_dpws;
-  float col[3] = {0.f, 0.f, 0.f}, B[NC], jp[9];
-#pragma unroll
-  for (int c = 0; c < NC; ++c) B[c] = 0.f;
+  float col[3] = {0.f, 0.f, 0.f}, jp[9];
 #pragma unroll
   for (int j = 0; j < 9; ++j) jp[j] = 0.f;
+#if EGS_SH_FUSED_JAC
+  // Round 4: the basis row leaves FIRST (it depends on the direction alone), then ONE pass over the coefficients sums
+  // colour and dcolor/ddir, re-evaluating each basis value where it is used: neither the 16 basis values nor the
+  // consumed part of the SH row stay in registers (110 -> see DESIGN 3.1).
+  float sh[K];
+  ShDir<NC> d;
+#pragma unroll
+  for (int c = 0; c < NC; ++c) d.B[c] = 0.f;
+  d.d0 = 0.f; d.d1 = 0.f; d.d2 = 0.f; d.ninv = 0.f; d.x = 0.f; d.y = 0.f; d.z = 0.f;
+  if (i < n) {   // colour has no depth test in the reference (kernel.cu:619-725)
+    load_sh_row<K>(shs + (size_t)K * i, sh);
+    d = sh_basis_f<NC>(ld3(pws + 3 * (size_t)i), twc);
+  }
+  if (jac) {
+    rows_out<NC>(d.B, dcolor_dshs, n, base, stage);
+    // (the direction is laundered: the compiler must not keep the 16 stored values alive for the pass below)
+    asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z));
+    if (i < n) sh_color_and_jac_dpw<NC, true, true>(d, sh, col, jp);
+  } else if (i < n) {
+    sh_color_and_jac_dpw<NC, true, false>(d, sh, col, jp);
+  }
+  rows_out<3>(col, colors, n, base, stage);
+  if (jac) rows_out<9>(jp, dcolor_dpws, n, base, stage);
+#else
+  float B[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) B[c] = 0.f;
   if (i < n) {   // colour has no depth test in the reference (kernel.cu:619-725)
     float sh[K];
     load_sh_row<K>(shs + (size_t)K * i, sh);
@@ -221,6 +257,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(EGS_SH2COLO
     rows_out<NC>(B, dcolor_dshs, n, base, stage);
     rows_out<9>(jp, dcolor_dpws, n, base, stage);
   }
+#endif
 }
 
 // ---- inverse_cov2d                                    (reference kernel.cu:274-324)
@@ -590,9 +627,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RAW ? 1 : (
         load_sh_row<K>(shs + (size_t)K * i, sh);
       }
       const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
+#if EGS_SH_FUSED_JAC_PRE
+      if constexpr (JW) sh_color_and_jac_dpw<NC>(d, sh, col, jw);
+      else sh_color_f<NC>(d, sh, col);
+      if (colors) st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
+#else
       sh_color_f<NC>(d, sh, col);
       if (colors) st3(colors + 3 * (size_t)i, {col[0], col[1], col[2]});
       if constexpr (JW) sh_jac_dpw<NC>(d, sh, jw);
+#endif
     }
     const Proj P = project_f(pw, Rcw, tcw, pp.fx, pp.fy, pp.cx, pp.cy);
     float u0 = 0.f, u1 = 0.f, depth = EGS_BAD_MARKER, ci[3] = {0.f, 0.f, 0.f};
@@ -995,14 +1038,16 @@ static int fused_forward_impl(bool raw, int n, int sh_dim, const float* pws, con
   const BinParams bp = make_bin_params(width, height, pol, cull_lists != 0);
   const PreParams pp = make_pre_params(pol, fx, fy, cx, cy, width, height);
   dim3 g(div_up(n, 256)), b(256);
+  // EGS_PRE_LDS_PAD (bytes of dynamic LDS, experiment knob): caps the resident workgroups per CU of this kernel
+  static const size_t lds_pad = [] { const char* e = getenv("EGS_PRE_LDS_PAD"); return e ? (size_t)atoi(e) : (size_t)0; }();
 #define EGS_PRE(NC, RAW)                                                                                        \
   do {                                                                                                          \
     if (dcolor_dpws)                                                                                            \
-      EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW, true>), g, b, s, n, pp, pws, rots, scales, shs, \
+      EGS_LAUNCH_LDS("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW, true>), g, b, lds_pad, s, n, pp, pws, rots, scales, shs, \
                  shs_high, alphas, Rcw, tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo,     \
                  visible, dcolor_dpws);                                                                         \
     else                                                                                                        \
-      EGS_LAUNCH("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW, false>), g, b, s, n, pp, pws, rots, scales, shs, \
+      EGS_LAUNCH_LDS("k_preprocess_fwd", (k_preprocess_fwd<NC, RAW, false>), g, b, lds_pad, s, n, pp, pws, rots, scales, shs, \
                  shs_high, alphas, Rcw, tcw, twc, us, depths, cinv2ds, colors, areas, (float4*)rec, bp, bo,     \
                  visible, dcolor_dpws);                                                                         \
   } while (0)

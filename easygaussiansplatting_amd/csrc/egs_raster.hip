@@ -573,12 +573,16 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
   const int i = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)i; z < sort_sup_words; z += gridDim.x * 256u) sort_sup[z] = 0u;   // for the depth sort
   uint32_t key = 0u;
+  // the 48-B records leave as full lines: deposited in LDS (row stride 5 x 16 B: conflict-free), stored as the
+  // workgroup's one contiguous span (lane-strided 16-B pieces cost three times the write requests)
+  __shared__ float4 st[256 * 5];
+  float4 r3[3] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
   if (i < n) {
     const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
     const float c0 = cinv[3 * (size_t)i], c1 = cinv[3 * (size_t)i + 1], c2 = cinv[3 * (size_t)i + 2];
     const float al = alphas[i];
     make_record(ux, uy, c0, c1, c2, al, colors[3 * (size_t)i], colors[3 * (size_t)i + 1], colors[3 * (size_t)i + 2],
-                0, 0, p.W, p.H, 0, alpha_skip, rec + 3 * (size_t)i);
+                0, 0, p.W, p.H, 0, alpha_skip, r3);
     uint4 rect;
     bool cull;
     const uint32_t cnt = bin_count_one(p, ux, uy, (float)areas[2 * (size_t)i], (float)areas[2 * (size_t)i + 1],
@@ -609,8 +613,19 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
     cr[i] = c;
     dkeys[i] = key;
   }
+#pragma unroll
+  for (int j = 0; j < 3; ++j) st[threadIdx.x * 5 + j] = r3[j];
   __shared__ uint32_t wm[4];
-  block_max_key(key, maxkey, wm);
+  block_max_key(key, maxkey, wm);     // (its barrier also orders the deposits above)
+  {
+    const int base = blockIdx.x * 256, rows = min(256, n - base);
+    float4* __restrict__ d4 = rec + 3 * (size_t)base;
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int f = (int)threadIdx.x + 256 * j;
+      if (f < 3 * rows) { const int rr = f / 3; d4[f] = st[rr * 5 + (f - 3 * rr)]; }
+    }
+  }
 }
 
 // ---- offsets of the Gaussians' patch runs, in depth order -------------------------------------------------
