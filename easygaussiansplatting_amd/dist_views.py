@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Dict, Iterable, List, Optional, Sequence
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -262,7 +264,16 @@ class ViewStreams:
         self.n = max(1, int(n_streams))
         dev = self.params[0].device
         self.cuda = dev.type == "cuda"
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n - 1)] if self.cuda else []
+        # experiment knobs: EGS_VIEW_STREAM_PRIO = 1: side lanes alternate high / low stream priority around
+        # the caller's (lane 0) normal one; EGS_VIEW_STAGGER_US = t: lane k of a step starts k * t microseconds late
+        # (a one-workgroup spin kernel), so that the lanes' latency-bound and issue-bound phases do not coincide
+        self._stagger = float(os.environ.get("EGS_VIEW_STAGGER_US", "0") or 0)
+        if self.cuda and os.environ.get("EGS_VIEW_STREAM_PRIO", "0") == "1":
+            least, greatest = torch.cuda.Stream.priority_range()
+            prios = [greatest if (k % 2 == 0) else least for k in range(self.n - 1)]
+            self.streams = [torch.cuda.Stream(device=dev, priority=pr) for pr in prios]
+        else:
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(self.n - 1)] if self.cuda else []
         # lane 0 = the caller's stream and the parameters themselves
         self.leaves = [self.params] + [[p.detach().requires_grad_(True) for p in self.params]
                                        for _ in range(self.n - 1)]
@@ -284,8 +295,11 @@ class ViewStreams:
                 q.grad = None
         if self.cuda:
             self._main = torch.cuda.current_stream(self.params[0].device)
-            for s in self.streams:
+            for k, s in enumerate(self.streams):
                 s.wait_stream(self._main)
+                if self._stagger > 0:
+                    with torch.cuda.stream(s):      # ~2.1 cycles per ns at the clocks a training run sees
+                        torch.cuda._sleep(int((k + 1) * self._stagger * 2100))
         self._open = True
 
     class _Lane:
