@@ -458,7 +458,7 @@ def main():
 
     # the unmodified-caller surface: GSFunction over the seven ops (six with calc_J=True, splat, splatB and the
     # chain-rule kernel over the stored Jacobians) -- an extra, outside the timed region
-    ops_ms, ops_kernels = None, None
+    ops_ms, ops_kernels, ops_public_ms = None, None, None
     if a.mode == "fused" and not a.no_ops and rank == 0 and world == 1:
         GSFunction.mode = "ops"
         for _ in range(8):        # (the first calls allocate the Jacobian tensors and learn the patch capacity)
@@ -469,6 +469,18 @@ def main():
             render_step()
         torch.cuda.synchronize()
         ops_ms = (time.perf_counter() - to0) / 40 * 1e3 / V      # per view
+        # the same step WITHOUT the records handle: the public splat / splatB pair as an unmodified reference
+        # GSFunction (gsmodel.py:6-93) calls it -- splatB packs its own records and walks the plain list
+        GSFunction.ops_use_records = False
+        for _ in range(4):
+            render_step()
+        torch.cuda.synchronize()
+        to0 = time.perf_counter()
+        for _ in range(40):
+            render_step()
+        torch.cuda.synchronize()
+        ops_public_ms = (time.perf_counter() - to0) / 40 * 1e3 / V
+        GSFunction.ops_use_records = True
         if prof:      # per-kernel table of the seven-op step (event-bracketed, outside the timing above)
             lib.egs_prof_set_filter(None); lib.egs_prof_reset(); lib.egs_prof_enable(1)
             for _ in range(3):
@@ -676,6 +688,7 @@ def main():
             "redone_steps": redone[0],
             "fwd_only": {"ms": round(fwd_ms, 4), "Mpix/s": round(HW / (fwd_ms * 1e-3) / 1e6, 2)},
             "ops_ms_per_step": None if ops_ms is None else round(ops_ms, 4),
+            "ops_public_pair_ms_per_step": None if ops_public_ms is None else round(ops_public_ms, 4),
             "ops_kernels": ops_kernels,
             "ring_views_8": ring8,
             "fwd_loss_bwd": None if loss_step_ms is None else {

@@ -40,6 +40,9 @@ class Camera:
 
 class GSFunction(torch.autograd.Function):
     mode = "fused"
+    # mode "ops": hand the forward's packed records / masked list to the backward's splatB (gsplatcu.SplatRecords).
+    # False = the plain public pair, what an UNMODIFIED reference GSFunction (gsmodel.py:6-93) gets by default.
+    ops_use_records = True
 
     @staticmethod
     def forward(ctx, pws, shs, alphas, scales, rots, us, cam):
@@ -62,8 +65,13 @@ class GSFunction(torch.autograd.Function):
         cinv2ds, areas, dcinv2d_dcov2ds = gsc.inverseCov2D(cov2ds, depths, True)
         # us / cinv2ds / colors are this node's own intermediates and never leave it: the packed records of the forward
         # draw stay valid for the backward draw (gsplatcu.SplatRecords; `alphas` is checked by version in splatB)
-        (image, contrib, final_tau, patch_range_per_tile, gsid_per_patch), ctx.records = gsc.splat_with_records(
-            cam.height, cam.width, us, cinv2ds, alphas, depths, colors, areas)
+        if GSFunction.ops_use_records:
+            (image, contrib, final_tau, patch_range_per_tile, gsid_per_patch), ctx.records = gsc.splat_with_records(
+                cam.height, cam.width, us, cinv2ds, alphas, depths, colors, areas)
+        else:
+            image, contrib, final_tau, patch_range_per_tile, gsid_per_patch = gsc.splat(
+                cam.height, cam.width, us, cinv2ds, alphas, depths, colors, areas)
+            ctx.records = None
         ctx.cam = cam
         ctx.save_for_backward(us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
                               gsid_per_patch, dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales,
