@@ -36,6 +36,9 @@
 // getRanges folded into the last scatter pass of the tile sort (one thread per digit run, atomicMin / Max at the run
 // ends): built, bit-identical, and measured 5 us SLOWER per step than the separate 8-us k_tile_ranges pass in three
 // same-box A/B pairs (0.9226 vs 0.9278 ms) -- the scatter kernel is latency-bound and pays for the extra tail.  Off.
+#ifndef EGS_PROBE_HIT_BITS     // 1: k_draw_bwd honours egs_probe_set_hit_bits (tools/bwd_hit_stats.py --time)
+#define EGS_PROBE_HIT_BITS 0
+#endif
 #ifndef EGS_RANGES_FOLD
 #define EGS_RANGES_FOLD 0
 #endif
@@ -556,6 +559,33 @@ __global__ __launch_bounds__(256) void k_bin_count(int n, BinParams p, const flo
   block_max_key(key, maxkey, wm);  // upper bound of the depth keys: lets the radix sort skip all-zero high digits
 }
 
+// (content stamps: see "content stamp of the 2D Gaussians" above k_pack_records)
+__device__ __forceinline__ uint32_t row_stamp(float ux, float uy, float c0, float c1, float c2, float al) {
+  uint32_t h = __float_as_uint(ux) * 0x9E3779B1u;
+  h = (h ^ (h >> 15)) + __float_as_uint(uy) * 0x85EBCA77u;
+  h = (h ^ (h >> 13)) + __float_as_uint(c0) * 0xC2B2AE3Du;
+  h = (h ^ (h >> 16)) + __float_as_uint(c1) * 0x27D4EB2Fu;
+  h = (h ^ (h >> 15)) + __float_as_uint(c2) * 0x165667B1u;
+  h = (h ^ (h >> 13)) + __float_as_uint(al) * 0x9E3779B1u;
+  return h ^ (h >> 16);
+}
+// all 256 threads call this; `red` = 8 words of LDS; stamp[2 wg], stamp[2 wg + 1] receive the workgroup's two sums;
+// ref / same (nullable): same[wg] = 1 iff they equal ref[2 wg], ref[2 wg + 1] (the stamps an earlier pass left)
+__device__ __forceinline__ void block_stamp(uint32_t h, uint32_t* __restrict__ stamp, uint32_t* red,
+                                            const uint32_t* __restrict__ ref = nullptr,
+                                            uint8_t* __restrict__ same = nullptr) {
+  uint32_t s1 = h, s2 = h * (2u * threadIdx.x + 1u);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { s1 += (uint32_t)__shfl_xor((int)s1, d, 64); s2 += (uint32_t)__shfl_xor((int)s2, d, 64); }
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = s1; red[4 + (threadIdx.x >> 6)] = s2; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const uint32_t a = red[0] + red[1] + red[2] + red[3], b = red[4] + 3u * red[5] + 5u * red[6] + 7u * red[7];
+    stamp[2 * (size_t)blockIdx.x] = a;
+    stamp[2 * (size_t)blockIdx.x + 1] = b;
+    if (ref && same) same[blockIdx.x] = (ref[2 * (size_t)blockIdx.x] == a && ref[2 * (size_t)blockIdx.x + 1] == b) ? 1 : 0;
+  }
+}
 // The seven-op surface's splat, tile-footprint policies: k_pack_records and k_bin_count as ONE pass over the 2D
 // Gaussians -- the packed 48-B record of the draw kernels, getRects + depth key (kernel.cu:82-122, :73), and, new in
 // round 4, the EXACT block masks of the fused path for the reference's UNCULLED lists: the Gaussian is emitted for
@@ -569,10 +599,10 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
                                                   uint4* __restrict__ cr, BinRec* __restrict__ br,
                                                   uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
                                                   uint32_t* __restrict__ maxkey, uint32_t* __restrict__ sort_sup,
-                                                  uint32_t sort_sup_words) {
+                                                  uint32_t sort_sup_words, uint32_t* __restrict__ stamp) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)i; z < sort_sup_words; z += gridDim.x * 256u) sort_sup[z] = 0u;   // for the depth sort
-  uint32_t key = 0u;
+  uint32_t key = 0u, hst = 0u;
   // the 48-B records leave as full lines: deposited in LDS (row stride 5 x 16 B: conflict-free), stored as the
   // workgroup's one contiguous span (lane-strided 16-B pieces cost three times the write requests)
   __shared__ float4 st[256 * 5];
@@ -583,6 +613,7 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
     const float al = alphas[i];
     make_record(ux, uy, c0, c1, c2, al, colors[3 * (size_t)i], colors[3 * (size_t)i + 1], colors[3 * (size_t)i + 2],
                 0, 0, p.W, p.H, 0, alpha_skip, r3);
+    hst = row_stamp(ux, uy, c0, c1, c2, al);
     uint4 rect;
     bool cull;
     const uint32_t cnt = bin_count_one(p, ux, uy, (float)areas[2 * (size_t)i], (float)areas[2 * (size_t)i + 1],
@@ -617,6 +648,10 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
   for (int j = 0; j < 3; ++j) st[threadIdx.x * 5 + j] = r3[j];
   __shared__ uint32_t wm[4];
   block_max_key(key, maxkey, wm);     // (its barrier also orders the deposits above)
+  if (stamp) {   // content stamps for the splatB that may follow (see row_stamp)
+    __shared__ uint32_t red[8];
+    block_stamp(hst, stamp, red);
+  }
   {
     const int base = blockIdx.x * 256, rows = min(256, n - base);
     float4* __restrict__ d4 = rec + 3 * (size_t)base;
@@ -1050,6 +1085,46 @@ __global__ __launch_bounds__(64) void k_tile_work(int W, int H, int gx, const in
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
 
+// ---- content stamp of the 2D Gaussians a masked list was built from ---------------------------------------------
+// splat and the splatB that follows it are two independent calls of the reference's API; what splat leaves for splatB
+// (the list with block masks) is valid only if splatB is given the SAME us / cinv2ds / alphas values.  No pointer or
+// version comparison can know that (tensor.data writes, other libraries' kernels), so both pack kernels -- which read
+// those values anyway -- leave a stamp per workgroup of 256 Gaussians: two position-dependent 32-bit sums over a hash of
+// the six floats' bits.  k_pair_validate compares the two stamp arrays (and the caller's list with the kept one) on
+// the device; k_draw_bwd takes the masks only if everything matched and otherwise walks the caller's own list with the
+// per-entry box test: the result never depends on what was kept.
+// kept[i] stays as it is iff it is the caller's entry plain[i] with a mask AND its Gaussian's block of 256 has the same
+// stamp now as in the forward pass (same[block], written by k_pack_records: a 4-KB table at 1 M Gaussians); otherwise it
+// becomes plain[i] with ALL four blocks set -- a mask that is valid for any data (the blocks are then decided by the
+// exponent test alone).  k_draw_bwd needs no flag: it walks `kept` either way, and what it walks is the caller's list.
+__global__ __launch_bounds__(256) void k_pair_fix(int64_t P, uint32_t* __restrict__ kept,
+                                                  const int32_t* __restrict__ plain,
+                                                  const uint8_t* __restrict__ same) {
+  const int64_t p0 = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
+  if (p0 >= P) return;
+  uint32_t k[4], q[4];
+  if (p0 + 4 <= P) {
+    const uint4 kv = *reinterpret_cast<const uint4*>(kept + p0);
+    const uint4 qv = *reinterpret_cast<const uint4*>(plain + p0);
+    k[0] = kv.x; k[1] = kv.y; k[2] = kv.z; k[3] = kv.w;
+    q[0] = qv.x; q[1] = qv.y; q[2] = qv.z; q[3] = qv.w;
+  } else {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) { k[t] = (p0 + t < P) ? kept[p0 + t] : 0u; q[t] = (p0 + t < P) ? (uint32_t)plain[p0 + t] : 0u; }
+  }
+  bool changed = false;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const bool good = (k[t] & EGS_GSID_MASK) == q[t] && same[(q[t] & EGS_GSID_MASK) >> 8] != 0;
+    if (!good) { k[t] = (q[t] & EGS_GSID_MASK) | (0xFu << EGS_GSID_BITS); changed = true; }
+  }
+  if (changed) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (p0 + t < P) kept[p0 + t] = k[t];
+  }
+}
+
 // 48-byte packed 2D record per Gaussian: one aligned gather (3 x dwordx4)
 // instead of the reference's four (fetch2shared, kernel.cu:13-44).
 //   A = {u.x, u.y, qxx, qxy}   B = {qyy, alpha, col.r, col.g}   C = {col.b, c1, c2, thr}
@@ -1072,13 +1147,24 @@ __global__ __launch_bounds__(256) void k_pack_records(int n, int W, int H, int f
                                                       const float* __restrict__ alphas,
                                                       const float* __restrict__ colors,
                                                       const int32_t* __restrict__ areas,
-                                                      float4* __restrict__ rec) {
+                                                      float4* __restrict__ rec, uint32_t* __restrict__ stamp,
+                                                      const uint32_t* __restrict__ stamp_ref, uint8_t* __restrict__ same) {
+  // stamp (nullable): content stamps per workgroup (see row_stamp); stamp_ref / same: compared on the spot
   const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  make_record(us[2 * (size_t)i], us[2 * (size_t)i + 1], cinv[3 * (size_t)i], cinv[3 * (size_t)i + 1],
-              cinv[3 * (size_t)i + 2], alphas[i], colors[3 * (size_t)i], colors[3 * (size_t)i + 1],
-              colors[3 * (size_t)i + 2], footprint == 1 ? areas[2 * (size_t)i] : 0,
-              footprint == 1 ? areas[2 * (size_t)i + 1] : 0, W, H, footprint, alpha_skip, rec + 3 * (size_t)i);
+  uint32_t h = 0u;
+  if (i < n) {
+    const float ux = us[2 * (size_t)i], uy = us[2 * (size_t)i + 1];
+    const float c0 = cinv[3 * (size_t)i], c1 = cinv[3 * (size_t)i + 1], c2 = cinv[3 * (size_t)i + 2];
+    const float al = alphas[i];
+    make_record(ux, uy, c0, c1, c2, al, colors[3 * (size_t)i], colors[3 * (size_t)i + 1],
+                colors[3 * (size_t)i + 2], footprint == 1 ? areas[2 * (size_t)i] : 0,
+                footprint == 1 ? areas[2 * (size_t)i + 1] : 0, W, H, footprint, alpha_skip, rec + 3 * (size_t)i);
+    h = row_stamp(ux, uy, c0, c1, c2, al);
+  }
+  if (stamp) {   // (kernel argument: uniform)
+    __shared__ uint32_t red[8];
+    block_stamp(h, stamp, red, stamp_ref, same);
+  }
 }
 
 // ============================================================================
@@ -1598,10 +1684,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     if (idx < n) {
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
       mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<BOX>(A, C, tx0, ty0);
-      if (p.hit_bits) {   // (probe, wave-uniform pointer test: see DrawParams)
+#if EGS_PROBE_HIT_BITS   // (measurement builds only: even this wave-uniform test cost the production kernel two spilled registers)
+      if (p.hit_bits) {
         const uint32_t gi = (uint32_t)(r0 + idx);
         if (!((p.hit_bits[gi >> 5] >> (gi & 31u)) & 1u)) mymask = 0;
       }
+#endif
       sA[lane] = A;
       sB[lane] = B;
       sC[lane] = C;
@@ -1894,7 +1982,7 @@ using namespace egs;
 static const uint32_t* g_probe_hit_bits = nullptr;
 extern "C" int egs_probe_set_hit_bits(const void* bits) {
   g_probe_hit_bits = (const uint32_t*)bits;
-  return 0;
+  return EGS_PROBE_HIT_BITS ? 0 : 1;   // 1: this build's k_draw_bwd ignores the bits (compile with -DEGS_PROBE_HIT_BITS=1)
 }
 
 extern "C" size_t egs_sort_pairs_ws_bytes(int64_t n) { return sort_ws_bytes(n); }
@@ -1967,7 +2055,10 @@ extern "C" int egs_splat_bin_mb(int n, int width, int height, const float* us, i
 extern "C" int egs_splat_bin_pack(int n, int width, int height, const float* us, const float* cinv2ds,
                                   const float* alphas, const float* colors, int32_t* areas, float* depths,
                                   const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
-                                  uint32_t* total_patches, uint32_t* host_totals, void* rec, void* stream) {
+                                  uint32_t* total_patches, uint32_t* host_totals, void* rec, uint32_t* stamp,
+                                  void* stream) {
+  // stamp (nullable, egs_pair_stamp_words(n) words): content stamps of us / cinv2ds / alphas for a later
+  // egs_pack_records_validate
   EGS_CHECK_ARG(n >= 0 && width > 0 && height > 0 && pol && total_patches);
   EGS_CHECK_ARG(width < 32768 && height < 32768);
   EGS_CHECK_ARG(pol->footprint == 0 && pol->alpha_skip > 0.f && n < (1 << EGS_GSID_BITS));
@@ -1987,7 +2078,7 @@ extern "C" int egs_splat_bin_pack(int n, int width, int height, const float* us,
   const BinParams p = make_bin_params(width, height, pol);
   EGS_LAUNCH("k_pack_bin", k_pack_bin, dim3(div_up(n, 256)), dim3(256), s, n, p, pol->alpha_skip, us, cinv2ds, alphas,
              colors, areas, depths, (float4*)rec, L.cr, L.br, L.dkeys, L.ids, L.maxkey, L.sort.sup,
-             (uint32_t)L.sort.sup_words);
+             (uint32_t)L.sort.sup_words, stamp);
   EGS_LAUNCH_OK();
   return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, host_totals);
 }
@@ -2150,7 +2241,8 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   const float4* rec = rec_in ? rec_in : D.rec;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
-               pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, D.rec);
+               pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, D.rec, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+               (uint8_t*)nullptr);
   EGS_LAUNCH_OK();
   int rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s, nullptr, patches_dev, nullptr, 0, nullptr, nullptr,
                       nullptr, nullptr, nullptr,   // (its last pass also writes the tile ranges)
@@ -2285,7 +2377,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   dp.hit_bits = g_probe_hit_bits;
   if (!rec_in)
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
-               pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws);
+               pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+               (uint8_t*)nullptr);
   static const int by_work = [] { const char* e = getenv("EGS_DRAWB_BY_WORK"); return e ? atoi(e) : 1; }();
   const bool same_mode = tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0;
   if (tile_order && keep_forward_order && same_mode) {
@@ -2367,7 +2460,38 @@ extern "C" int egs_pack_records(int n, int width, int height, const float* us, c
   EGS_CHECK_ARG(((uintptr_t)rec & 15) == 0);
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, pol->footprint,
-             pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)rec);
+             pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)rec, (uint32_t*)nullptr, (const uint32_t*)nullptr,
+             (uint8_t*)nullptr);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// words of a content-stamp array for n Gaussians: two per workgroup of 256, + ceil(workgroups / 4) for the byte table
+// egs_pack_records_validate keeps behind its own stamps
+extern "C" size_t egs_pair_stamp_words(int n) {
+  const size_t nwg = (size_t)div_up(n > 0 ? n : 1, 256);
+  return 2 * nwg + (nwg + 3) / 4 + 4;
+}
+
+// splatB's half of the content-validated pairing: pack the records from the tensors splatB was given, stamp
+// them (stamp_b), and make the kept list (the one the forward draw walked, with masks) agree with them: every entry
+// that is not the caller's own entry (plain) or whose Gaussian sits in a block of 256 whose stamps differ from the
+// forward pass's (stamp_a, egs_splat_bin_pack) is replaced by the caller's entry with all four blocks set.
+extern "C" int egs_pack_records_validate(int n, int width, int height, const float* us, const float* cinv2ds,
+                                         const float* alphas, const float* colors, const EgsPolicy* pol, void* rec,
+                                         const uint32_t* stamp_a, uint32_t* stamp_b, int64_t patches, void* kept,
+                                         const int32_t* plain, void* stream) {
+  EGS_CHECK_ARG(n > 0 && width > 0 && height > 0 && pol && pol->footprint == 0 && n < (1 << EGS_GSID_BITS));
+  EGS_CHECK_ARG(us && cinv2ds && alphas && colors && rec && stamp_a && stamp_b && patches >= 0);
+  EGS_CHECK_ARG(patches == 0 || (kept && plain && (((uintptr_t)kept | (uintptr_t)plain) & 15) == 0));
+  EGS_CHECK_ARG(((uintptr_t)rec & 15) == 0 && (((uintptr_t)stamp_a | (uintptr_t)stamp_b) & 7) == 0);
+  hipStream_t s = (hipStream_t)stream;
+  uint8_t* same = (uint8_t*)(stamp_b + 2 * (size_t)div_up(n, 256));     // one byte per block of 256 Gaussians
+  EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height, 0,
+             pol->alpha_skip, us, cinv2ds, alphas, colors, (const int32_t*)nullptr, (float4*)rec, stamp_b, stamp_a, same);
+  if (patches > 0)
+    EGS_LAUNCH("k_pair_fix", k_pair_fix, dim3(div_up(patches, 1024)), dim3(256), s, patches, (uint32_t*)kept, plain,
+               (const uint8_t*)same);
   EGS_LAUNCH_OK();
   return 0;
 }

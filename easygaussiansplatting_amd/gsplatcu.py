@@ -269,25 +269,26 @@ def _alphas(alphas, n):
     return _chk(alphas.reshape(n), "alphas", torch.float32, (n,))
 
 
-# ---- what `splat` can keep for the `splatB` that follows it ---------------------------------------------------
-# GSFunction.backward (gsmodel.py:67-69) calls splatB with the very tensors its forward gave to splat; the packed 48-B
-# records built from them, the draw's [dispatch order | measured work] buffer and an [N][12] gradient-record buffer
-# the forward draw kernel cleared on the side can be reused instead of rebuilt (~45 us per step at 1 M Gaussians).
-# Reusing records is only correct if the four input tensors still hold what was packed.  That is knowable for
-#   * a caller that OWNS the tensors between the two calls: ``splat_with_records`` returns a ``SplatRecords`` handle
-#     and ``splatB(..., records=handle)`` takes it back -- what this package's GSFunction (mode "ops") does with its
-#     own intermediates (us / cinv2ds / colors never leave the autograd node);
-#   * nobody else: a write through ``tensor.data``, ``torch.as_strided`` aliases or another library's kernel leaves
-#     ``tensor._version`` untouched.  The PUBLIC ``splat`` / ``splatB`` pair therefore keeps NOTHING by default and
-#     ``splatB`` packs its records from the tensors it is given (what the reference does, gausplat.cu:114-159).
-#     ``set_memo(True)`` opts a process in to the implicit per-(device, stream) memo for unmodified reference
-#     callers (reference gsmodel.GSFunction): validated by (data_ptr, _version, shape) of the four inputs, policy,
-#     image size and stream -- in-place ops, other tensors, another policy or stream all fall back to packing; raw
-#     writes are the caller's responsibility in that mode.
-# A handle / memo entry keeps STRONG references to the four tensors (their memory cannot be handed to another tensor
-# while it lives) and is stored only after the draw stage was enqueued (the order buffer then holds a permutation,
-# the gradient records are cleared).
-_memo_enabled = False
+# ---- what `splat` keeps for the `splatB` that follows it ------------------------------------------------------
+# GSFunction.backward (gsmodel.py:67-69) calls splatB with the very tensors its forward gave to splat: the list with
+# block masks the forward draw walked, the draw's [dispatch order | measured work] buffer and an [N][12] gradient-record
+# buffer the forward draw kernel cleared on the side can be reused instead of rebuilt.  Two forms:
+#
+#   * the PUBLIC pair (what an unmodified reference GSFunction calls), CONTENT-VALIDATED (round 4, second half):
+#     `splat` keeps, per (device, stream), the masked list, the order buffer, the cleared gradient records and a STAMP
+#     of the us / cinv2ds / alphas VALUES (two position-dependent 32-bit sums per 256 Gaussians, written by the kernel
+#     that packs them).  `splatB` always packs its records from the tensors it is given, stamps them too, and a kernel
+#     repairs the kept list on the device: an entry that is not the caller's own (gsid_per_patch[i] differs) or whose
+#     Gaussian lies in a block with a different stamp becomes the caller's entry with all four blocks set.  No pointer
+#     or version is compared: a write through ``tensor.data``, another library's kernel, other tensors with the same
+#     values -- all handled by what the VALUES are.  The order buffer (any permutation is correct) and the cleared
+#     gradient records (data-independent, handed out once) need no validation.  ``set_memo(False)`` switches the
+#     keeping off (~80 MB per (device, stream) at 1 M Gaussians until the next splat).
+#   * the explicit HANDLE for a caller that OWNS the tensors between the two calls: ``splat_with_records`` returns a
+#     ``SplatRecords`` and ``splatB(..., records=handle)`` takes it back -- this package's GSFunction (mode "ops") does
+#     that with its own intermediates (us / cinv2ds / colors never leave the autograd node) and skips both the re-pack
+#     and the validation (21 + 10 us); the handle is checked by (data_ptr, _version, shape), policy, size and stream.
+_memo_enabled = True
 _splat_memo = {}
 MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's list values (egs_splat_bin_pack)
 
@@ -295,7 +296,7 @@ MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's 
 class SplatRecords:
     """Opaque: what one ``splat`` call left for the ``splatB`` of the same tensors (see above)."""
     __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream",
-                 "lists", "pair", "pair_sig")
+                 "lists", "pair", "pair_sig", "stamp", "n")
 
     def matches(self, dev, st, tensors, width, height):
         if (self.dev_index != dev.index or self.stream != int(st.value or 0) or self.width != width
@@ -306,7 +307,7 @@ class SplatRecords:
 
 
 def set_memo(on: bool) -> None:
-    """Opt in (``True``) to / out of the implicit ``splat`` -> ``splatB`` memo of the public pair (default off)."""
+    """Switch the content-validated keeping of the public ``splat`` -> ``splatB`` pair on (default) or off."""
     global _memo_enabled
     _memo_enabled = bool(on)
     if not on:
@@ -314,9 +315,8 @@ def set_memo(on: bool) -> None:
 
 
 def clear_memo() -> None:
-    """Drop what ``splat`` keeps for the next ``splatB`` when ``set_memo(True)`` is in force (per device and stream:
-    the four input tensors it packed, the 48-B records built from them, the dispatch-order buffer and the cleared
-    gradient records -- ~130 MB at 1 M Gaussians until the next ``splat``)."""
+    """Drop what ``splat`` keeps for the next ``splatB`` (per device and stream: the list with masks, the dispatch-order
+    buffer, the cleared gradient records and the content stamps -- ~80 MB at 1 M Gaussians until the next ``splat``)."""
     _splat_memo.clear()
 
 
@@ -329,17 +329,18 @@ def _memo_sig(tensors):
         return None
 
 
-def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None, pair=None):
-    sig = _memo_sig(tensors)
+def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None, pair=None, stamp=None, n=0):
+    sig = _memo_sig(tensors) if tensors is not None else ()
     if sig is None:
         return None
     h = SplatRecords()
+    h.stamp, h.n = stamp, n
     h.tensors, h.sig, h.width, h.height, h.policy = tensors, sig, width, height, _policy_name
     h.rec, h.order, h.gpack, h.dev_index, h.stream = rec, order, gpack, dev.index, int(st.value or 0)
     # the list WITH block masks the forward draw walked, valid for the (gsid_per_patch, patch_range_per_tile) pair
     # this splat returned -- and only for it
     h.lists, h.pair, h.pair_sig = lists, pair, (_memo_sig(pair) if pair is not None else None)
-    if h.pair_sig is None:
+    if tensors is not None and h.pair_sig is None:   # (handle form: the masked list is tied to its returned pair)
         h.lists = None
     return h
 
@@ -365,7 +366,7 @@ def _take_records(h, dev, st, tensors, width, height):
 def splat_with_records(height, width, us, cinv2ds, alphas, depths, colors, areas):
     """``splat`` + a ``SplatRecords`` handle (or None) for ``splatB(..., records=handle)``.  For callers that own
     the four input tensors until that ``splatB`` (see the note above ``SplatRecords``)."""
-    return _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep=True)
+    return _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep="handle")
 
 
 def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
@@ -373,9 +374,13 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
            patch_range_per_tile[T,2] int32, gsid_per_patch[P] int32].
     ``depths`` and ``areas`` are updated IN PLACE for Gaussians whose tile rect is
     empty (kernel.cu:114-119).  Reference: ext.cpp:10-18, gausplat.cu:24-112."""
-    out, h = _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep=_memo_enabled)
-    if _memo_enabled and h is not None:
-        _splat_memo[(h.dev_index, h.stream)] = h
+    out, h = _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep="public" if _memo_enabled else False)
+    if _memo_enabled:
+        key = (us.device.index, int(_stream().value or 0))
+        if h is not None:
+            _splat_memo[key] = h
+        else:
+            _splat_memo.pop(key, None)      # (nothing kept this time: an older entry must not outlive its splat)
     return out
 
 
@@ -407,7 +412,8 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
     rec = torch.empty((max(n, 1), 12), dtype=torch.float32, device=dev)
     order = torch.empty(lib.egs_tile_order_len(width, height), dtype=torch.int32, device=dev)
     gpack = None
-    keep = bool(keep) and n > 0 and _pol().footprint != 1   # (pixel-box records also depend on `areas`, which this op mutates)
+    if not (n > 0 and _pol().footprint != 1):   # (pixel-box records also depend on `areas`, which this op mutates)
+        keep = False
     # Tile-footprint policies with a skip threshold: records and binning state in ONE pass (egs_splat_bin_pack); the
     # lists are the reference's (gsid_per_patch bit-exact), their values carry exact 8x8-block masks the draw kernels
     # take instead of testing a box per entry.  The masked list stays internal; the caller gets the stripped copy.
@@ -422,18 +428,22 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
             # VALU-bound, the memory system idles), good for ONE backward pass
             gpack = torch.empty((n, 12), dtype=torch.float32, device=dev)
     lists = [None]     # the list the draw kernels walked (with masks), kept for the backward draw
+    # content stamps of us / cinv2ds / alphas (public pair: splatB validates what it is given against them)
+    stamp = torch.empty(lib.egs_pair_stamp_words(n), dtype=torch.int32, device=dev) if (masks and keep == "public") else None
 
     def records(gsid):    # only once the draw stage is enqueued: the order buffer is written, the gradient records cleared
-        if not keep:
-            return None
-        return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
-                             lists[0], (gsid, ranges) if lists[0] is not None else None)
+        if keep == "handle":
+            return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
+                                 lists[0], (gsid, ranges) if lists[0] is not None else None)
+        if keep == "public" and lists[0] is not None:   # no tensor is referenced, no record kept: values are validated
+            return _make_records(dev, st, None, width, height, None, order, gpack, lists[0], None, stamp, n)
+        return None
 
     def enqueue_bin(hint, total, host_slot=None):
         if masks:
             _lib.check(lib.egs_splat_bin_pack(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
                                               _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
-                                              _ptr(total), host_slot, _ptr(rec), st))
+                                              _ptr(total), host_slot, _ptr(rec), _ptr(stamp), st))
         elif host_slot is not None:
             _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint,
                                             _ptr(ws_bin), ws_bin_bytes, _ptr(total), host_slot, st))
@@ -556,10 +566,23 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
     st = _stream()
     rec, order, gpack, walked = (None, None, None, None)
     if n > 0 and pol.footprint != 1:   # (the pixel-box policy's records also depend on `areas`, which splat mutates)
-        h = records if records is not None else (_splat_memo.get((dev.index, int(st.value or 0))) if _memo_enabled else None)
-        rec, order, gpack = _take_records(h, dev, st, (us, cinv2ds, alphas, colors), width, height)
-        if rec is not None:            # ... and the list with block masks, if gsid / ranges are that splat's own pair
-            walked = _walked_lists(h, gsid, ranges)
+        if records is not None:        # explicit handle: trusted if the signatures still match
+            rec, order, gpack = _take_records(records, dev, st, (us, cinv2ds, alphas, colors), width, height)
+            if rec is not None:        # ... and the list with block masks, if gsid / ranges are that splat's own pair
+                walked = _walked_lists(records, gsid, ranges)
+        elif _memo_enabled:            # public pair: what the last splat of this stream kept, validated by CONTENT
+            h = _splat_memo.get((dev.index, int(st.value or 0)))
+            npatch = gsid.shape[0]
+            if (h is not None and h.tensors is None and h.lists is not None and h.n == n and h.width == width
+                    and h.height == height and h.policy == _policy_name and h.lists.shape[0] >= npatch > 0
+                    and pol.alpha_skip > 0 and (gsid.data_ptr() & 15) == 0):
+                rec = torch.empty((n, 12), dtype=torch.float32, device=dev)
+                stamp_b = torch.empty(lib.egs_pair_stamp_words(n), dtype=torch.int32, device=dev)
+                _lib.check(lib.egs_pack_records_validate(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                                         _ptr(colors), C.byref(pol), _ptr(rec), _ptr(h.stamp),
+                                                         _ptr(stamp_b), npatch, _ptr(h.lists), _ptr(gsid), st))
+                walked, order = h.lists, h.order
+                gpack, h.gpack = h.gpack, None
     if rec is not None:     # the records (and the measured per-tile work) of the splat call these tensors came from
         _lib.check(lib.egs_splat_bwd_rec_lists(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
                                                _ptr(final_tau), _ptr(ranges), _ptr(gsid if walked is None else walked),

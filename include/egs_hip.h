@@ -166,7 +166,20 @@ int egs_pack_records(int n, int width, int height, const float* us, const float*
 int egs_splat_bin_pack(int n, int width, int height, const float* us, const float* cinv2ds, const float* alphas,
                        const float* colors, int32_t* areas, float* depths, const EgsPolicy* pol, int key_bits_hint,
                        void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* rec,
-                       void* stream);
+                       uint32_t* stamp /* nullable: egs_pair_stamp_words(n) words, content stamps */, void* stream);
+/* Content-validated pairing of the reference's two independent calls splat and splatB.  splat keeps the list with
+ * masks and a STAMP of the us / cinv2ds / alphas values it was built from (two position-dependent 32-bit sums per 256
+ * Gaussians, written by egs_splat_bin_pack).  splatB calls egs_pack_records_validate: it packs the records from the
+ * tensors splatB was given (always fresh), stamps them (stamp_b), and REPAIRS the kept list on the device: an entry
+ * that is not the caller's own (plain[i] differs) or whose Gaussian lies in a block of 256 with a different stamp
+ * becomes the caller's entry with all four blocks set (valid for any data).  egs_splat_bwd_rec_lists(.., kept, flags =
+ * EGS_DRAW_MASKED_LISTS) then walks a list that IS the caller's: no pointer or version comparison is involved, a write
+ * through tensor.data or another library's kernel between the two calls is seen. */
+size_t egs_pair_stamp_words(int n);
+int egs_pack_records_validate(int n, int width, int height, const float* us, const float* cinv2ds,
+                              const float* alphas, const float* colors, const EgsPolicy* pol, void* rec,
+                              const uint32_t* stamp_a, uint32_t* stamp_b, int64_t patches, void* kept,
+                              const int32_t* plain, void* stream);
 /* plain[i] = masked[i] & 0x0FFFFFFF for i < min(count, *count_dev) (count_dev nullable: a device-side patch count
  * the host has not read yet): gsid_per_patch as the reference returns it (gausplat.cu:108-111). */
 int egs_strip_list_masks(int64_t count, const uint32_t* count_dev, const void* masked, int32_t* plain, void* stream);
@@ -288,7 +301,9 @@ int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
 /* Measurement helper (tools/bwd_hit_stats.py): one bit per list entry of the NEXT backward draws of this process
  * (bit i = entry i of gsid_per_patch blended into some pixel of its tile; NULL switches the probe off).  Entries with
  * a 0 bit are dropped by k_draw_bwd before staging.  Prices a "the forward draw leaves a hit bit per entry" design
- * from the backward side alone; never set by the product path. */
+ * from the backward side alone; never set by the product path.  Returns 1 (and does nothing) unless the library was
+ * built with -DEGS_PROBE_HIT_BITS=1: the test inside k_draw_bwd, wave-uniform as it is, cost the production kernel two
+ * spilled registers. */
 int egs_probe_set_hit_bits(const void* bits);
 /* Mailbox for that read-back: `slots` page-locked landing zones, each with a HIP event.  egs_mailbox_post
  * enqueues the asynchronous 8-byte copy of total_patches[0..1] into a slot on `stream` and records the

@@ -4,9 +4,10 @@
 Ground truth of every case: ``splatB`` on CLONES of the (mutated) tensors -- fresh storage that no handle or memo entry
 can match, i.e. the pack-from-scratch path ``egs_splat_bwd`` (the reference's behaviour, gausplat.cu:114-159).
 
-* the PUBLIC pair keeps nothing by default: a write through ``.data`` (invisible to ``_version``), an in-place op,
-  a policy swap, another stream between the two calls -- gradients equal the ground truth;
-* ``set_memo(True)`` (opt-in implicit memo): in-place ops, other tensors, policy and stream changes are detected;
+* the PUBLIC pair keeps the forward draw's masked list, order buffer and cleared gradient records and validates them
+  by CONTENT on the device (stamps of the values, egs_pack_records_validate): a write through ``.data`` (invisible to
+  ``_version``), an in-place op, a policy swap, another stream, other tensors between the two calls -- gradients equal
+  the ground truth every time; with ``set_memo(False)`` nothing is kept at all;
 * the explicit handle (``splat_with_records`` / ``records=``, what GSFunction mode "ops" uses): reused when nothing
   changed, dropped when a tensor's version moved;
 * ``torch.inference_mode()``: ``splat`` works (inference tensors have no version counter; round 3 raised);
@@ -84,8 +85,6 @@ MUTATIONS = ["none", "data_write", "inplace", "policy", "stream", "other_tensor"
 @pytest.mark.parametrize("memo", [False, True])
 @pytest.mark.parametrize("what", MUTATIONS)
 def test_public_pair_never_differentiates_stale_records(gsc, what, memo):
-    if memo and what == "data_write":
-        pytest.skip("opt-in memo: raw writes are the caller's responsibility (documented); the default keeps nothing")
     gsc.set_memo(memo)
     d = _inputs(gsc)
     out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
@@ -120,14 +119,61 @@ def test_public_pair_never_differentiates_stale_records(gsc, what, memo):
 
 def test_policy_swap_between_the_calls(gsc):
     """Records packed under one policy are not used under another (forward_cpu needs areas=: checked separately)."""
-    gsc.set_memo(True)
     d = _inputs(gsc)
-    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
-    h = gsc._splat_memo[(0, int(torch.cuda.current_stream().cuda_stream or 0))]
+    out, h = gsc.splat_with_records(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
     gsc.set_policy("forward_cpu")
     assert not h.matches(d["us"].device, gsc._stream(), (d["us"], d["cinv"], d["alphas"], d["col"]), d["W"], d["H"])
     gsc.set_policy("gsplatcu")
     assert h.matches(d["us"].device, gsc._stream(), (d["us"], d["cinv"], d["alphas"], d["col"]), d["W"], d["H"])
+
+
+def test_public_pair_validates_by_content(gsc):
+    """What the content validation does to the kept list: untouched when splatB gets the values splat saw (the masks are
+    used: some are narrower than 0xF), untouched for OTHER tensors holding the same values, repaired entry by entry
+    where values changed -- a write through ``.data`` to the first 300 Gaussians turns exactly the entries of the stamp
+    blocks those rows live in (rows 0..511) into (caller's index | all four blocks)."""
+    gsc.set_memo(True)
+    d = _inputs(gsc, n=3000)
+    key = (0, int(torch.cuda.current_stream().cuda_stream or 0))
+    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    h = gsc._splat_memo[key]
+    assert h.tensors is None and h.rec is None and h.stamp is not None          # no tensor is referenced
+    P = out[4].shape[0]
+    kept0 = h.lists[:P].clone()
+    assert torch.equal(kept0 & 0x0FFFFFFF, out[4]) and int((((kept0 >> 28) & 0xF) != 0xF).sum()) > 0.2 * P
+    got = _splatB(gsc, d, out)
+    torch.cuda.synchronize()
+    assert torch.equal(h.lists[:P], kept0) and h.gpack is None                  # nothing repaired, records handed out
+    _same(got, _truth(gsc, d, out))
+    # other tensors, same values: still valid (nothing about identity is compared)
+    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    h = gsc._splat_memo[key]
+    c = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in d.items()}
+    got = gsc.splatB(c["H"], c["W"], c["us"], c["cinv"], c["alphas"], c["depths"], c["col"], out[1], out[2], out[3],
+                     out[4], c["dl"])
+    torch.cuda.synchronize()
+    assert torch.equal(h.lists[:P], kept0)
+    _same(got, _truth(gsc, d, out))
+    # a raw write to some rows: exactly the entries of their stamp blocks lose their masks
+    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    h = gsc._splat_memo[key]
+    d["us"].data[:300] += 0.37
+    got = _splatB(gsc, d, out)
+    torch.cuda.synchronize()
+    kept1 = h.lists[:P]
+    touched = (out[4] >> 8) < 2                                                  # Gaussians 0..511: stamp blocks 0 and 1
+    assert torch.equal(kept1 & 0x0FFFFFFF, out[4])
+    assert bool((((kept1[touched] >> 28) & 0xF) == 0xF).all()) and torch.equal(kept1[~touched], kept0[~touched])
+    _same(got, _truth(gsc, d, out))
+    # a foreign gsid_per_patch (another list of the same length): every entry is the caller's afterwards
+    out = gsc.splat(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], d["areas"])
+    h = gsc._splat_memo[key]
+    other = out[4].flip(0).contiguous()
+    out_f = list(out); out_f[4] = other
+    gsc.splatB(d["H"], d["W"], d["us"], d["cinv"], d["alphas"], d["depths"], d["col"], out[1], out[2], out[3], other,
+               d["dl"])
+    torch.cuda.synchronize()
+    assert torch.equal(h.lists[:P] & 0x0FFFFFFF, other)
 
 
 def test_explicit_handle_is_reused_and_dropped(gsc):
