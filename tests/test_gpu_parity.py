@@ -650,8 +650,9 @@ def big(gsc):
 
 def test_full_size_policy_g_sampled_tiles_and_invariants(gsc, big):
     """BASELINE configs[1]/[2] size: size-independent invariants of the tile lists
-    (coverage, sortedness, P = sum of counts) and 24 sampled tiles re-blended by the
-    oracle from the device's own lists (forward + backward)."""
+    (coverage, sortedness, P = sum of counts), 24 sampled tiles re-blended by the
+    oracle from the device's own lists, and the gradients of the ~3 400 Gaussians complete
+    inside three contiguous windows of tiles (relative rule, tests/gradcheck.py)."""
     sc = big
     cam = sc.cam
     g = gpu_stages(gsc, sc, False, "gsplatcu")

@@ -7,9 +7,12 @@ the image), patch count and list lengths.
 
 Per view:   * invariants of the tile lists (they tile the patch array, every list is sorted by (depth key, index),
               every Gaussian appears exactly rect-many times);
-            * the image on sampled tiles against ``O.draw`` fed with the ORACLE's own float64 2D Gaussians;
-            * the five parameter gradients (+ dL/du) of the Gaussians complete inside sampled tiles against
-              ``O.draw_backward`` + ``O.chain_rule``.
+            * the image on sampled tiles against ``O.draw`` fed with the ORACLE's own float64 2D Gaussians, and ALL
+              8160 tiles against the all-tile digest of the pinned oracle (fixture G11: mean RGB, mean tau, finished
+              pixels per tile; 64 full tiles for views 0 and 3);
+            * the five parameter gradients (+ dL/du) of the Gaussians complete inside three contiguous windows of
+              tiles (3 000+ per view) against ``O.draw_backward`` + ``O.chain_rule`` under the RELATIVE rule of
+              tests/gradcheck.py (threshold-flip Gaussians named by the oracle and counted).
 Then:       * gradients accumulated by autograd over the 8 views in one process == sum of the per-view gradients;
             * the 8 views dealt to three HIP streams (``ViewStreams``, deferred validation) give the same sum;
             * the same 8 views through the overlapped exchange path (``ChunkedExchange`` on a one-rank process group,
