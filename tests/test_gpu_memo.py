@@ -274,3 +274,22 @@ def test_masked_lists_of_the_seven_op_surface_change_no_output(gsc, mod, monkeyp
         assert gsc._walked_lists(h, out[4], out[3]) is not None
         assert gsc._walked_lists(h, out[4].clone(), out[3]) is None and gsc._walked_lists(h, out[4], out[3].clone()) is None
     _same(masked, _truth(gsc, q, out))
+
+
+def test_two_forwards_then_two_backwards_through_the_public_pair(gsc):
+    """A loss over two views: splat(A), splat(B), then splatB for A and for B.  What the stream keeps belongs to B; A's
+    backward must not be touched by it -- the validation turns every kept entry that is not A's own into A's entry with
+    a full mask (or, when B's list is shorter than A's, nothing kept is used at all).  Both orders, both gradients
+    against splatB on clones."""
+    gsc.set_memo(True)
+    A = _inputs(gsc, seed=7)
+    B = _inputs(gsc, seed=8, mod="giants")
+    args = lambda q: (q["H"], q["W"], q["us"], q["cinv"], q["alphas"], q["depths"], q["col"], q["areas"])
+    for first, second in ((A, B), (B, A)):
+        out1 = gsc.splat(*args(first))
+        out2 = gsc.splat(*args(second))
+        g1 = _splatB(gsc, first, out1)          # the kept state is out2's
+        g2 = _splatB(gsc, second, out2)         # ... which the call above may have repaired towards out1's list
+        torch.cuda.synchronize()
+        _same(g1, _truth(gsc, first, out1))
+        _same(g2, _truth(gsc, second, out2))
