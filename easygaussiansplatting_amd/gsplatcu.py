@@ -296,7 +296,7 @@ MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's 
 class SplatRecords:
     """Opaque: what one ``splat`` call left for the ``splatB`` of the same tensors (see above)."""
     __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream",
-                 "lists", "pair", "pair_sig", "stamp", "n")
+                 "lists", "pair", "pair_sig", "stamp", "n", "npatch")
 
     def matches(self, dev, st, tensors, width, height):
         if (self.dev_index != dev.index or self.stream != int(st.value or 0) or self.width != width
@@ -329,12 +329,13 @@ def _memo_sig(tensors):
         return None
 
 
-def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None, pair=None, stamp=None, n=0):
+def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None, pair=None, stamp=None, n=0,
+                  npatch=-1):
     sig = _memo_sig(tensors) if tensors is not None else ()
     if sig is None:
         return None
     h = SplatRecords()
-    h.stamp, h.n = stamp, n
+    h.stamp, h.n, h.npatch = stamp, n, npatch
     h.tensors, h.sig, h.width, h.height, h.policy = tensors, sig, width, height, _policy_name
     h.rec, h.order, h.gpack, h.dev_index, h.stream = rec, order, gpack, dev.index, int(st.value or 0)
     # the list WITH block masks the forward draw walked, valid for the (gsid_per_patch, patch_range_per_tile) pair
@@ -436,7 +437,8 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
             return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
                                  lists[0], (gsid, ranges) if lists[0] is not None else None)
         if keep == "public" and lists[0] is not None:   # no tensor is referenced, no record kept: values are validated
-            return _make_records(dev, st, None, width, height, None, order, gpack, lists[0], None, stamp, n)
+            return _make_records(dev, st, None, width, height, None, order, gpack, lists[0], None, stamp, n,
+                                 int(gsid.shape[0]))
         return None
 
     def enqueue_bin(hint, total, host_slot=None):
@@ -574,7 +576,8 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
             h = _splat_memo.get((dev.index, int(st.value or 0)))
             npatch = gsid.shape[0]
             if (h is not None and h.tensors is None and h.lists is not None and h.n == n and h.width == width
-                    and h.height == height and h.policy == _policy_name and h.lists.shape[0] >= npatch > 0
+                    and h.height == height and h.policy == _policy_name and h.npatch == npatch > 0   # (the kept
+                    # list is valid for exactly that many entries: a capacity-sized buffer holds garbage behind them)
                     and pol.alpha_skip > 0 and (gsid.data_ptr() & 15) == 0):
                 rec = torch.empty((n, 12), dtype=torch.float32, device=dev)
                 stamp_b = torch.empty(lib.egs_pair_stamp_words(n), dtype=torch.int32, device=dev)
