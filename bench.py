@@ -142,7 +142,9 @@ def relaunch_command(gpus, env, argv):
     --master-port P bench.py <same flags>`` to exec instead -- one rank per GPU over RCCL, the very command the
     driver's contract names -- so that either way of starting the multi-GPU bench yields the one JSON line.
     None when no relaunch is due (N == 1, or already running under a launcher)."""
-    if gpus <= 1 or "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+    if "WORLD_SIZE" in env or "RANK" in env or "LOCAL_RANK" in env:
+        return None
+    if gpus <= 1 and env.get("EGS_BENCH_FORCE_LAUNCHER") != "1":   # (the knob: exercise the re-exec path on a 1-GPU box)
         return None
     port = env.get("MASTER_PORT") or str(29500 + (os.getpid() % 2000))
     return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
