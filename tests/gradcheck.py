@@ -9,7 +9,8 @@ anything, all-zeros included.  The rule below cannot be dodged by the scale of `
   (2) over the entries with |ref| >= big * max|ref| (big = 1e-2; "the large entries"):
         median relative error    <= med_rel                                            (1e-4)
         relative error           <= max_rel   for all but ``outliers`` of them         (5e-3)
-      the entries beyond max_rel are COUNTED (returned and asserted <= outliers, default 0): they are where a
+      the entries beyond max_rel are COUNTED (returned and asserted <= outliers, default 0; a float < 1 = that
+      fraction of the large entries, for million-row tensors): they are where a
       pixel sits on the other side of an alpha' >= 0.002 / tau < 1e-4 threshold in fp32 (kernel.cu:246,256) --
       "threshold-flip Gaussians", reported separately as the image checks do with flipped pixels;
   (3) max|ref| > 0 (a comparison against an all-zero reference is vacuous and refused).
@@ -45,8 +46,12 @@ def report(got, ref, big=BIG, max_rel=MAX_REL):
 def grad_close(got, ref, tol_max=TOL_MAX, big=BIG, med_rel=MED_REL, max_rel=MAX_REL, outliers=0):
     """-> (ok, report dict)."""
     r = report(got, ref, big, max_rel)
+    # ``outliers``: an absolute count, or (a float below 1) a FRACTION of the large entries -- for million-row tensors,
+    # where a handful of entries in a million sit on an unflagged threshold; at least 2 are then allowed
+    allowed = max(2, int(outliers * r["n_big"])) if isinstance(outliers, float) and outliers < 1 else outliers
+    r["outliers_allowed"] = int(allowed)
     ok = (r["finite"] and r["ref_max"] > 0 and r["abs_over_max"] <= tol_max and r["med_rel"] <= med_rel
-          and r["n_out"] <= outliers)
+          and r["n_out"] <= allowed)
     return ok, r
 
 
