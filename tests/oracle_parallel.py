@@ -45,12 +45,15 @@ def draw_backward_tiles(width, height, ranges, gsid, us, cinv2ds, alphas, colors
     procs = max(1, min(procs or (os.cpu_count() or 1), 96, len(tiles)))
     nchunk = max(1, min(len(tiles), procs * chunks_per_proc))
     chunks = [tiles[i::nchunk] for i in range(nchunk)]                          # dealt round-robin: balanced
-    tmp = tempfile.mkdtemp(prefix="egs_oracle_", dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    arrays = dict(ranges=ranges, gsid=gsid, us=np.asarray(us, np.float64), cinv2ds=np.asarray(cinv2ds, np.float64),
+                  alphas=np.asarray(alphas, np.float64).reshape(-1), colors=np.asarray(colors, np.float64),
+                  contrib=np.asarray(contrib), final_tau=np.asarray(final_tau, np.float64),
+                  dl=np.asarray(dl, np.float64))
+    need = sum(v.nbytes for v in arrays.values())
+    # /dev/shm when it has room (a container's default is 64 MB), else the ordinary temporary directory
+    shm = "/dev/shm" if (os.path.isdir("/dev/shm") and shutil.disk_usage("/dev/shm").free > 2 * need + (64 << 20)) else None
+    tmp = tempfile.mkdtemp(prefix="egs_oracle_", dir=shm)
     try:
-        arrays = dict(ranges=ranges, gsid=gsid, us=np.asarray(us, np.float64), cinv2ds=np.asarray(cinv2ds, np.float64),
-                      alphas=np.asarray(alphas, np.float64).reshape(-1), colors=np.asarray(colors, np.float64),
-                      contrib=np.asarray(contrib), final_tau=np.asarray(final_tau, np.float64),
-                      dl=np.asarray(dl, np.float64))
         for k, v in arrays.items():
             np.save(os.path.join(tmp, k + ".npy"), v)
         jobs = [(tmp, width, height, c, near_margin, repo) for c in chunks]
