@@ -67,7 +67,10 @@ SIGNATURES = {
     "egs_splat_bwd_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P]),
     "egs_splat_bwd_rec_lists": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _i,
                                      _P]),
-    "egs_splat_bin_pack": (_i, [_i, _i, _i, _P, _P, _P, _P, _P, _P, _PP, _i, _P, _sz, _P, _P, _P, _P, _P]),
+    "egs_splat_bin_pack": (_i, [_i, _i, _i, _P, _P, _P, _P, _P, _P, _PP, _i, _P, _sz, _P, _P, _P, _P, _P, _P]),
+    "egs_splat_draw_rec_plain": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P, _i, _P]),
+    "egs_splat_draw_rec_dev_plain": (_i, [_i, _i64, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P, _i,
+                                          _P]),
     "egs_pair_stamp_words": (_sz, [_i]),
     "egs_pack_records_validate": (_i, [_i, _i, _i, _P, _P, _P, _P, _PP, _P, _P, _P, _i64, _P, _P, _P]),
     "egs_strip_list_masks": (_i, [_i64, _P, _P, _P, _P]),

@@ -599,7 +599,9 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
                                                   uint4* __restrict__ cr, BinRec* __restrict__ br,
                                                   uint32_t* __restrict__ dkeys, uint32_t* __restrict__ ids,
                                                   uint32_t* __restrict__ maxkey, uint32_t* __restrict__ sort_sup,
-                                                  uint32_t sort_sup_words, uint32_t* __restrict__ stamp) {
+                                                  uint32_t sort_sup_words, uint32_t* __restrict__ stamp,
+                                                  uint8_t* __restrict__ visible) {
+  // visible (nullable): depth > 0.2 AFTER the in-place cull below -- the mask GSFunction returns (gsmodel.py:50)
   const int i = blockIdx.x * 256 + threadIdx.x;
   for (uint32_t z = (uint32_t)i; z < sort_sup_words; z += gridDim.x * 256u) sort_sup[z] = 0u;   // for the depth sort
   uint32_t key = 0u, hst = 0u;
@@ -618,11 +620,13 @@ __global__ __launch_bounds__(256) void k_pack_bin(int n, BinParams p, float alph
     bool cull;
     const uint32_t cnt = bin_count_one(p, ux, uy, (float)areas[2 * (size_t)i], (float)areas[2 * (size_t)i + 1],
                                        depths[i], rect, key, cull);
+    const float depth_in = depths[i];
     if (cull) {  // the in-place contract of the reference (kernel.cu:114-119)
       depths[i] = EGS_BAD_MARKER;
       areas[2 * (size_t)i] = 0;
       areas[2 * (size_t)i + 1] = 0;
     }
+    if (visible) visible[i] = (cull ? EGS_BAD_MARKER : depth_in) > 0.2f;
     ids[i] = (uint32_t)i;
     uint4 c = make_uint4(0u, 0u, 0u, 0u);
     if (cnt) {
@@ -893,10 +897,23 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
 // getRanges (reference kernel.cu:125-150; its P==1 hole is closed here)
 __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* __restrict__ tkeys,
                                                      int32_t* __restrict__ ranges,
-                                                     const uint32_t* __restrict__ n_dev) {
+                                                     const uint32_t* __restrict__ n_dev,
+                                                     const uint32_t* __restrict__ masked, int32_t* __restrict__ plain) {
+  // masked / plain (nullable pair, seven-op surface): gsid_per_patch as the reference returns it -- the sorted list
+  // values without their block masks -- written on the way (this kernel is a chain of latencies: the 8 bytes per
+  // patch ride along; as a launch of its own, k_strip_masks, they cost 6-8 us)
   if (n_dev) P = min(P, (int64_t)*n_dev);
   const int64_t p0 = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;   // four keys per thread: one dwordx4
   if (p0 >= P) return;
+  if (plain) {
+    if (p0 + 4 <= P) {
+      uint4 v = *reinterpret_cast<const uint4*>(masked + p0);
+      v.x &= EGS_GSID_MASK; v.y &= EGS_GSID_MASK; v.z &= EGS_GSID_MASK; v.w &= EGS_GSID_MASK;
+      *reinterpret_cast<uint4*>(plain + p0) = v;
+    } else {
+      for (int64_t q = p0; q < P; ++q) plain[q] = (int32_t)(masked[q] & EGS_GSID_MASK);
+    }
+  }
   uint32_t k[5];
   k[0] = p0 > 0 ? tkeys[p0 - 1] : 0u;
   if (p0 + 4 <= P) {
@@ -2056,7 +2073,8 @@ extern "C" int egs_splat_bin_pack(int n, int width, int height, const float* us,
                                   const float* alphas, const float* colors, int32_t* areas, float* depths,
                                   const EgsPolicy* pol, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes,
                                   uint32_t* total_patches, uint32_t* host_totals, void* rec, uint32_t* stamp,
-                                  void* stream) {
+                                  uint8_t* visible, void* stream) {
+  // visible (nullable, n bytes): depth > 0.2 after this call's in-place cull (the mask of gsmodel.py:50)
   // stamp (nullable, egs_pair_stamp_words(n) words): content stamps of us / cinv2ds / alphas for a later
   // egs_pack_records_validate
   EGS_CHECK_ARG(n >= 0 && width > 0 && height > 0 && pol && total_patches);
@@ -2078,7 +2096,7 @@ extern "C" int egs_splat_bin_pack(int n, int width, int height, const float* us,
   const BinParams p = make_bin_params(width, height, pol);
   EGS_LAUNCH("k_pack_bin", k_pack_bin, dim3(div_up(n, 256)), dim3(256), s, n, p, pol->alpha_skip, us, cinv2ds, alphas,
              colors, areas, depths, (float4*)rec, L.cr, L.br, L.dkeys, L.ids, L.maxkey, L.sort.sup,
-             (uint32_t)L.sort.sup_words, stamp);
+             (uint32_t)L.sort.sup_words, stamp, visible);
   EGS_LAUNCH_OK();
   return splat_bin_after_count(n, key_bits_hint, ws_bin, ws_bin_bytes, total_patches, stream, host_totals);
 }
@@ -2179,7 +2197,8 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
                            void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
                            float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr,
-                           int order_ready = 0, int flags = 0) {
+                           int order_ready = 0, int flags = 0, int32_t* gsid_plain = nullptr) {
+  // gsid_plain (nullable, with EGS_DRAW_MASKED_LISTS): receives the list values without their masks
   // flags & EGS_DRAW_CULLED_LISTS: the binning stage counted the footprint-culled tiles (egs_fused_forward with
   // cull_lists): the lists are emitted with block masks in the high bits of their values and drawn from those
   // order_ready != 0: tile_order already holds a dispatch order (an earlier render through the SAME buffer left
@@ -2250,7 +2269,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   if (rc) return rc;
   if (!EGS_RANGES_FOLD)
     EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 1024)), dim3(256), s, patches, D.tkeys,
-               patch_range_per_tile, patches_dev);
+               patch_range_per_tile, patches_dev, (const uint32_t*)(gsid_plain ? gsid_per_patch : nullptr), gsid_plain);
   if (order_ready && tile_order && tile_order_mode(0) > 0 && dp.T <= TILE_ORDER_MAX_T) {
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(0) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
@@ -2346,6 +2365,35 @@ extern "C" int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint3
                          ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
                          patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records,
                          prev_tile_work, order_ready, flags);
+}
+
+// egs_splat_draw_rec / _dev with flags = EGS_DRAW_MASKED_LISTS for the seven-op surface: gsid_per_patch receives the
+// list the draw kernels walk (with masks), gsid_plain the list the CALLER of splat gets (gausplat.cu:108-111), written
+// by the range kernel on its way over the sorted keys (no egs_strip_list_masks launch)
+extern "C" int egs_splat_draw_rec_plain(int n, int64_t patches, int width, int height, const void* rec,
+                                        const EgsPolicy* pol, const void* ws_bin, void* ws_draw, size_t ws_draw_bytes,
+                                        float* image, int32_t* contrib, float* final_tau,
+                                        int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* gsid_plain,
+                                        int32_t* tile_order, float* grad_records, int flags, void* stream) {
+  EGS_CHECK_ARG(rec || n == 0);
+  EGS_CHECK_ARG(!gsid_plain || ((((uintptr_t)gsid_plain | (uintptr_t)gsid_per_patch) & 15) == 0));
+  return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
+                         ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
+                         patch_range_per_tile, gsid_per_patch, stream, nullptr, tile_order, grad_records,
+                         nullptr, 0, flags, gsid_plain);
+}
+extern "C" int egs_splat_draw_rec_dev_plain(int n, int64_t patch_capacity, const uint32_t* total_patches, int width,
+                                            int height, const void* rec, const EgsPolicy* pol, const void* ws_bin,
+                                            void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib,
+                                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
+                                            int32_t* gsid_plain, int32_t* tile_order, float* grad_records, int flags,
+                                            void* stream) {
+  EGS_CHECK_ARG((rec || n == 0) && total_patches && patch_capacity > 0);
+  EGS_CHECK_ARG(!gsid_plain || ((((uintptr_t)gsid_plain | (uintptr_t)gsid_per_patch) & 15) == 0));
+  return splat_draw_impl(n, patch_capacity, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin,
+                         ws_draw, ws_draw_bytes, (const float4*)rec, image, contrib, final_tau,
+                         patch_range_per_tile, gsid_per_patch, stream, total_patches, tile_order, grad_records,
+                         nullptr, 0, flags, gsid_plain);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]

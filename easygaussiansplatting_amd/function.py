@@ -76,7 +76,9 @@ class GSFunction(torch.autograd.Function):
         ctx.save_for_backward(us, cinv2ds, alphas, depths, colors, contrib, final_tau, patch_range_per_tile,
                               gsid_per_patch, dcinv2d_dcov2ds, dcov2d_dcov3ds, dcov3d_drots, dcov3d_dscales,
                               dcolor_dshs, du_dpcs, dcov2d_dpcs, dcolor_dpws)
-        mask = depths > 0.2  # read after the in-place culling of inverseCov2D / splat (gsmodel.py:50)
+        # depths > 0.2 after the in-place culling of inverseCov2D / splat (gsmodel.py:50): the packing kernel of splat
+        # left it in the handle; otherwise one compare kernel
+        mask = ctx.records.visible if (ctx.records is not None and ctx.records.visible is not None) else depths > 0.2
         ctx.mark_non_differentiable(mask)
         return image, mask
 

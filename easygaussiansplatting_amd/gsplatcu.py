@@ -296,7 +296,7 @@ MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's 
 class SplatRecords:
     """Opaque: what one ``splat`` call left for the ``splatB`` of the same tensors (see above)."""
     __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream",
-                 "lists", "pair", "pair_sig", "stamp", "n", "npatch")
+                 "lists", "pair", "pair_sig", "stamp", "n", "npatch", "visible")
 
     def matches(self, dev, st, tensors, width, height):
         if (self.dev_index != dev.index or self.stream != int(st.value or 0) or self.width != width
@@ -335,7 +335,7 @@ def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None
     if sig is None:
         return None
     h = SplatRecords()
-    h.stamp, h.n, h.npatch = stamp, n, npatch
+    h.stamp, h.n, h.npatch, h.visible = stamp, n, npatch, None
     h.tensors, h.sig, h.width, h.height, h.policy = tensors, sig, width, height, _policy_name
     h.rec, h.order, h.gpack, h.dev_index, h.stream = rec, order, gpack, dev.index, int(st.value or 0)
     # the list WITH block masks the forward draw walked, valid for the (gsid_per_patch, patch_range_per_tile) pair
@@ -431,11 +431,17 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
     lists = [None]     # the list the draw kernels walked (with masks), kept for the backward draw
     # content stamps of us / cinv2ds / alphas (public pair: splatB validates what it is given against them)
     stamp = torch.empty(lib.egs_pair_stamp_words(n), dtype=torch.int32, device=dev) if (masks and keep == "public") else None
+    # depths > 0.2 after this op's in-place cull (the mask of gsmodel.py:50), written by the packing kernel on the side
+    # for a caller that asked for the handle (this package's GSFunction): no separate compare kernel
+    visible = torch.empty(n, dtype=torch.bool, device=dev) if (masks and keep == "handle") else None
 
     def records(gsid):    # only once the draw stage is enqueued: the order buffer is written, the gradient records cleared
         if keep == "handle":
-            return _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
-                                 lists[0], (gsid, ranges) if lists[0] is not None else None)
+            h = _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
+                              lists[0], (gsid, ranges) if lists[0] is not None else None)
+            if h is not None:
+                h.visible = visible
+            return h
         if keep == "public" and lists[0] is not None:   # no tensor is referenced, no record kept: values are validated
             return _make_records(dev, st, None, width, height, None, order, gpack, lists[0], None, stamp, n,
                                  int(gsid.shape[0]))
@@ -445,7 +451,7 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         if masks:
             _lib.check(lib.egs_splat_bin_pack(n, width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas), _ptr(colors),
                                               _ptr(areas), _ptr(depths), pol, hint, _ptr(ws_bin), ws_bin_bytes,
-                                              _ptr(total), host_slot, _ptr(rec), _ptr(stamp), st))
+                                              _ptr(total), host_slot, _ptr(rec), _ptr(stamp), _ptr(visible), st))
         elif host_slot is not None:
             _lib.check(lib.egs_splat_bin_mb(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint,
                                             _ptr(ws_bin), ws_bin_bytes, _ptr(total), host_slot, st))
@@ -458,11 +464,12 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         walked = torch.empty(patches, dtype=torch.int32, device=dev) if masks else gsid
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw_rec(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
-                                          ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau), _ptr(ranges),
-                                          _ptr(walked), _ptr(order), _ptr(gpack), None, 0, flags, st))
+        # (with masks the range kernel also writes the plain list the caller gets: no strip launch)
+        _lib.check(lib.egs_splat_draw_rec_plain(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
+                                                ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau),
+                                                _ptr(ranges), _ptr(walked), _ptr(gsid) if masks else None, _ptr(order),
+                                                _ptr(gpack), flags, st))
         if masks:
-            _lib.check(lib.egs_strip_list_masks(patches, None, _ptr(walked), _ptr(gsid), st))
             lists[0] = walked
         return gsid
 
@@ -500,12 +507,11 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         walked_full = torch.empty(cap, dtype=torch.int32, device=dev) if masks else gsid_full
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, width, height, _ptr(rec), pol, _ptr(ws_bin),
-                                              _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
-                                              _ptr(final_tau), _ptr(ranges), _ptr(walked_full), _ptr(order),
-                                              _ptr(gpack), None, 0, flags, st))
-        if masks:
-            _lib.check(lib.egs_strip_list_masks(cap, _ptr(total), _ptr(walked_full), _ptr(gsid_full), st))
+        _lib.check(lib.egs_splat_draw_rec_dev_plain(n, cap, _ptr(total), width, height, _ptr(rec), pol, _ptr(ws_bin),
+                                                    _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
+                                                    _ptr(final_tau), _ptr(ranges), _ptr(walked_full),
+                                                    _ptr(gsid_full) if masks else None, _ptr(order), _ptr(gpack),
+                                                    flags, st))
     except BaseException:
         # Kernels enqueued before the failure (the arm, the binning chain) still store {P, max key} into the slot:
         # it may only go back on the free list once they have run, or a later render that picks it up could settle

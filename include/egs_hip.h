@@ -166,7 +166,23 @@ int egs_pack_records(int n, int width, int height, const float* us, const float*
 int egs_splat_bin_pack(int n, int width, int height, const float* us, const float* cinv2ds, const float* alphas,
                        const float* colors, int32_t* areas, float* depths, const EgsPolicy* pol, int key_bits_hint,
                        void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches, uint32_t* host_totals, void* rec,
-                       uint32_t* stamp /* nullable: egs_pair_stamp_words(n) words, content stamps */, void* stream);
+                       uint32_t* stamp /* nullable: egs_pair_stamp_words(n) words, content stamps */,
+                       uint8_t* visible /* nullable: n bytes, depths > 0.2 after the in-place cull (gsmodel.py:50) */,
+                       void* stream);
+/* egs_splat_draw_rec / egs_splat_draw_rec_dev for the seven-op surface (flags = EGS_DRAW_MASKED_LISTS): gsid_per_patch
+ * receives the list the draw kernels walk (with masks), gsid_plain (nullable) the list splat's caller gets
+ * (gausplat.cu:108-111), written by the range kernel on its way: no egs_strip_list_masks launch. */
+int egs_splat_draw_rec_plain(int n, int64_t patches, int width, int height, const void* rec, const EgsPolicy* pol,
+                             const void* ws_bin, void* ws_draw, size_t ws_draw_bytes, float* image, int32_t* contrib,
+                             float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
+                             int32_t* gsid_plain, int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/,
+                             int flags, void* stream);
+int egs_splat_draw_rec_dev_plain(int n, int64_t patch_capacity, const uint32_t* total_patches, int width, int height,
+                                 const void* rec, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                                 size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                                 int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* gsid_plain,
+                                 int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/, int flags,
+                                 void* stream);
 /* Content-validated pairing of the reference's two independent calls splat and splatB.  splat keeps the list with
  * masks and a STAMP of the us / cinv2ds / alphas values it was built from (two position-dependent 32-bit sums per 256
  * Gaussians, written by egs_splat_bin_pack).  splatB calls egs_pack_records_validate: it packs the records from the
