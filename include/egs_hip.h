@@ -361,7 +361,7 @@ size_t egs_fused_backward_ws_bytes(int n);
  * egs_splat_bin_pack prepares.  The draw kernels take the masks instead of testing the record's certain-miss box per
  * entry (1.95 instead of 2.35 block evaluations per entry, entries with an empty mask cost a list read); images and
  * gradients are unchanged (the pixels skipped are pixels the reference `continue`s on, kernel.cu:246).  The caller
- * hands gsid_per_patch back to ITS caller through egs_strip_list_masks. */
+ * hands gsid_per_patch back to ITS caller without the masks (egs_splat_draw_rec_plain, or egs_strip_list_masks). */
 #define EGS_DRAW_MASKED_LISTS 2
 /* phase 0: the whole backward pass.  phase 1: only splatB's draw pass (packed gradient records -> ws).
  * phase 2: only the per-Gaussian chain rule for rows [row_begin, row_begin + row_count), row_begin a multiple
