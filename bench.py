@@ -178,6 +178,11 @@ def main():
     ap.add_argument("--overlap-exchange", action="store_true",
                     help="several ranks, one view each: start the all-reduce of the gradient chunks inside the backward "
                          "pass (dist_views.ChunkedExchange) instead of one flat all-reduce after it")
+    ap.add_argument("--factored-sh", default="auto", choices=["auto", "on", "off"],
+                    help="keep the SH gradient of a step factored (dist_views.FactoredShGrad): a view leaves dL/dcolour "
+                         "[N,3], the ranks all-gather 12 B per Gaussian and view instead of all-reducing the 192-B rows, "
+                         "one kernel forms the rows per step.  auto: when it moves fewer bytes "
+                         "(dist_views.factored_exchange_pays)")
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
     ap.add_argument("--no-ring8", action="store_true", help="skip the extra eight-ring-views step (configs[3])")
@@ -272,35 +277,48 @@ def main():
     vs = DV.ViewStreams([params[k] for k in order], n_lanes) if n_lanes > 1 else None
     us_lane = [us0] + [torch.zeros((sc.n, 2), device=dev, requires_grad=True) for _ in range(n_lanes - 1)]
 
-    def render_views(cams_v, vs_v, us_v, dl_v):
+    # The SH gradient of a step kept factored (dist_views.FactoredShGrad): 48 of the 59 gradient floats per Gaussian are
+    # outer products dL/dcolour (x) basis -- a view leaves 3 floats, the exchange all-gathers them, one kernel forms
+    # the rows.  auto: whenever that moves fewer bytes (any world > 1 at V = 1; several views on one GPU)
+    want_fx = a.factored_sh == "on" or (a.factored_sh == "auto" and
+                                        DV.factored_exchange_pays(world if exchange else 1, V, a.sh_dim))
+    fx = DV.FactoredShGrad(V) if (want_fx and a.mode == "fused" and overlap is None) else None
+    rest = ("pws", "alphas", "scales", "rots")
+
+    def render_views(cams_v, vs_v, us_v, dl_v, fx_v=None):
         """forward + backward of the given views on the lanes of ``vs_v``; the parameters' .grad = sum over the views"""
         for p in params.values():
             p.grad = None
         for u in us_v:
             u.grad = None
         vs_v.begin()
-        with fused_path.accumulate_in_kernel():
+        with fused_path.accumulate_in_kernel(), (fx_v.attach() if fx_v is not None else contextlib.nullcontext()):
             for i, c in enumerate(cams_v):
                 with vs_v.lane(i) as lv:
                     image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_v[vs_v.lane_index(i)], c)
                     image.backward(dl_v)
         vs_v.finish()
+        if fx_v is not None and not exchange:       # (with an exchange: finished there, it is a collective)
+            fx_v.finish(params["pws"], params["shs"])
         return image
 
     def render_step():
         if vs is not None:
-            return render_views(my_cams, vs, us_lane, dl)
+            return render_views(my_cams, vs, us_lane, dl, fx)
         for p in params.values():
             p.grad = None
         for u in us_lane:
             u.grad = None
         # V views: forward + backward each; from the second view on the chain-rule kernel adds this view's gradients
         # to the leaves' .grad itself (fused.accumulate_in_kernel) instead of autograd accumulating fresh tensors
-        with (fused_path.accumulate_in_kernel() if (V > 1 and a.mode == "fused") else contextlib.nullcontext()):
+        with (fused_path.accumulate_in_kernel() if (V > 1 and a.mode == "fused") else contextlib.nullcontext()), \
+                (fx.attach() if fx is not None else contextlib.nullcontext()):
             for c in my_cams:
                 image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
                                                params["rots"], us0, c)
                 image.backward(dl)
+        if fx is not None and not exchange:
+            fx.finish(params["pws"], params["shs"])
         return image
 
     def step(timing=False):
@@ -322,7 +340,10 @@ def main():
             if overlap is not None and overlap.finish([params[k] for k in order]):
                 pass                  # issued chunk by chunk from inside backward; now complete
             else:
-                flat = fused_path.flat_grad_buffer([params[k] for k in order])
+                if fx is not None:        # all-gather of the views' dL/dcolour + one kernel: shs.grad = the mean rows
+                    fx.finish(params["pws"], params["shs"], average=True)
+                names = rest if fx is not None else order
+                flat = fused_path.flat_grad_buffer([params[k] for k in names])
                 if flat is not None:      # the fused backward hands out slices of one buffer: ONE all-reduce
                     if world > 1 and dist.get_backend() == "nccl":
                         # RCCL scales inside the collective (ncclAvg): no separate 472-MB div_ pass (80 us per step
@@ -334,7 +355,7 @@ def main():
                         if world > 1:
                             flat.div_(float(world))
                 else:
-                    grads = [params[k].grad for k in order]
+                    grads = [params[k].grad for k in names]
                     hs = [dist.all_reduce(g, op=dist.ReduceOp.SUM, async_op=True) for g in grads]
                     for h in hs:
                         h.wait()
@@ -420,13 +441,23 @@ def main():
         dist.all_gather(allr, mine)
         nbytes = DV.grad_exchange_bytes(sc.n)
         te_max = max(float(x[1]) for x in allr)
-        exch = {"bytes": nbytes, "t_render_ms": [round(float(x[0]), 4) for x in allr],
+        form = {"form": "flat all-reduce of 59 floats per Gaussian", "link_bytes_per_rank": 2 * (world - 1) / world * nbytes,
+                "direct_bytes_per_link": 2 * nbytes / world}
+        if fx is not None:
+            # all-gather: a rank receives (world - 1) * V rows of 12 N + 16 bytes; all-reduce of the other 11 floats
+            rest_b = 4 * 11 * sc.n
+            ag = (world - 1) * V * 4 * DV.FactoredShGrad.row_stride(sc.n)
+            form = {"form": "SH gradient factored: all-gather of dL/dcolour (12 B per Gaussian and view) + all-reduce of "
+                            "11 floats per Gaussian + one kernel forming the rows",
+                    "link_bytes_per_rank": ag + 2 * (world - 1) / world * rest_b,
+                    "direct_bytes_per_link": V * 4 * DV.FactoredShGrad.row_stride(sc.n) + 2 * rest_b / world}
+        exch = {"bytes": nbytes, **form, "t_render_ms": [round(float(x[0]), 4) for x in allr],
                 "t_exchange_ms": [round(float(x[1]), 4) for x in allr],
                 "overlapped_with_backward": bool(overlap is not None and overlap.used),
-                "bus_GBs": round(2 * (world - 1) / world * nbytes / (te_max * 1e-3) / 1e9, 1) if world > 1 else None,
+                "bus_GBs": round(form["link_bytes_per_rank"] / (te_max * 1e-3) / 1e9, 1) if world > 1 else None,
                 "xgmi_bound_ms": None if world == 1 else {
-                    "ring_one_link": round(2 * (world - 1) / world * nbytes / (XGMI_LINK_GBS * 1e9) * 1e3, 3),
-                    "direct_all_links": round(2 * nbytes / world / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}}
+                    "ring_one_link": round(form["link_bytes_per_rank"] / (XGMI_LINK_GBS * 1e9) * 1e3, 3),
+                    "direct_all_links": round(form["direct_bytes_per_link"] / (XGMI_LINK_GBS * 1e9) * 1e3, 3)}}
 
     # realised scene statistics (bytes depend on them)
     with torch.no_grad():
@@ -515,11 +546,13 @@ def main():
         us8 = [torch.zeros((sc.n, 2), device=dev, requires_grad=True) for _ in range(lanes8)]
         dl8 = dl / 8
 
+        fx8 = DV.FactoredShGrad(8) if a.factored_sh != "off" else None     # eight views, one GPU: it pays
+
         def step8():
             with fused_path.deferred() as d8:
-                render_views(cams8, vs8, us8, dl8)
+                render_views(cams8, vs8, us8, dl8, fx8)
                 if d8.commit():          # (a view outgrew the buffers learnt so far: exact redo)
-                    render_views(cams8, vs8, us8, dl8)
+                    render_views(cams8, vs8, us8, dl8, fx8)
         for _ in range(6):
             step8()
         torch.cuda.synchronize()
@@ -528,7 +561,7 @@ def main():
             step8()
         torch.cuda.synchronize()
         ms8 = (time.perf_counter() - t80) / 12 * 1e3
-        ring8 = {"views": 8, "view_streams": lanes8, "ms_per_step": round(ms8, 4),
+        ring8 = {"views": 8, "view_streams": lanes8, "factored_sh": fx8 is not None, "ms_per_step": round(ms8, 4),
                  "Mpix/s": round(8 * HW / (ms8 * 1e-3) / 1e6, 2),
                  "what": "forward + backward of the 8 ring cameras of BASELINE configs[3] as one step on this GPU "
                          "(12 steps after 6 untimed; host clock around a synchronize)"}

@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegs_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 
 class EgsPolicy(C.Structure):
@@ -85,6 +85,7 @@ SIGNATURES = {
                               + [_i, _i, _P, _sz, _P, _P, _P]),
     "egs_fused_backward_raw": (_i, [_i, _i, _i64, _i, _i] + [_P] * 9 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
                                + [_P] * 7 + [_P, _P, _P, _i, _i, _i, _P]),
+    "egs_sh_grad_views": (_i, [_i, _i, _i, _P, _P, _i64, _f, _P, _P, _i, _P]),
     "egs_tile_order_len": (_sz, [_i, _i]),
     "egs_splat_draw_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P]),
     "egs_splat_draw_rec_dev": (_i, [_i, _i64, _P, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P,

@@ -731,8 +731,13 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
     const float* __restrict__ tcw, const float* __restrict__ twc, const float* __restrict__ depths,
     const float4* __restrict__ gpack, float* __restrict__ dL_dpw, float* __restrict__ dL_dsh,
     float* __restrict__ dL_dsh_high, float* __restrict__ dL_dalpha, float* __restrict__ dL_dscale, float* __restrict__ dL_drot,
-    float* __restrict__ dL_du, const float* __restrict__ dcolor_dpws, int accum) {
+    float* __restrict__ dL_du, const float* __restrict__ dcolor_dpws, int mode) {
   // dcolor_dpws (nullable): [N][9] left by k_preprocess_fwd; with it this kernel never reads the SH coefficients
+  // mode bit 1 (EGS_BWD_FACTORED_SH): the SH gradient stays in its factored form -- eq (5) is an outer product
+  // dL/dcolour (x) basis, so dL_dsh receives the THREE floats dL/dcolour per Gaussian ([N][3], always written, never
+  // accumulated) and the rows are formed once per step, for all views, by k_sh_grad_views; dL_dsh_high is not touched
+  const int accum = mode & 1;
+  const bool factored = (mode & 2) != 0;
   // accum: the five (six) parameter-gradient outputs already hold the gradients of EARLIER views of the step and this
   // view's are ADDED to them (dL_du is per view and always written): a rank that renders V views per step then needs
   // no separate accumulation kernels (torch's `.grad += new`: 976 B per Gaussian and view against 488 here)
@@ -756,6 +761,7 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   }
 #pragma unroll
   for (int k = 0; k < K; ++k) gsh[k] = 0.f;
+  f3 gcol_out = {0.f, 0.f, 0.f};
   if (i < n) {
     // Every input of the row is requested here, before anything is used: with the parameter loads behind the depth
     // test, the Jacobian row at its use and the old gradients (accum) at theirs, a row went through four dependent
@@ -834,9 +840,12 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
                       gu0 * j02 + gu1 * j12 + g2[0] * Jp[2] + g2[1] * Jp[5] + g2[2] * Jp[8]};
       const ShDir<NC> d = sh_basis_f<NC>(pw, twc);
       // eq (5): dL/dsh[c, rgb] = dL/dcolor[rgb] * basis[c]
+      gcol_out = gcol;
+      if (!factored) {
 #pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
+        for (int c = 0; c < NC; ++c) {
+          gsh[3 * c] = gcol.x * d.B[c]; gsh[3 * c + 1] = gcol.y * d.B[c]; gsh[3 * c + 2] = gcol.z * d.B[c];
+        }
       }
       if constexpr (!JW) sh_jac_dpw<NC>(d, sh, W);
       float* opw = dL_dpw + 3 * (size_t)i;  // eq (7)
@@ -846,6 +855,59 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
         opw[k] = gpc.x * Rcw[k] + gpc.y * Rcw[3 + k] + gpc.z * Rcw[6 + k] + gcol.x * W[k] + gcol.y * W[3 + k] +
                  gcol.z * W[6 + k] + opw_old[k];
     }
+  }
+  if (factored) {   // (a kernel argument: the whole workgroup leaves here)
+    if (i < n) st3(dL_dsh + 3 * (size_t)i, gcol_out);
+    return;
+  }
+  if constexpr (RAW) {
+    if (i < n) {
+#pragma unroll
+      for (int k = 0; k < 3; ++k) dL_dsh[3 * (size_t)i + k] = gsh[k] + (accum ? dL_dsh[3 * (size_t)i + k] : 0.f);
+    }
+    if constexpr (KH > 0) {
+      if constexpr (KH % 2 == 1) stage_span_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage, accum != 0);
+      else stage_rows_out<KH>(gsh + 3, dL_dsh_high, n, blockIdx.x * 256, stage, accum != 0);
+    }
+  } else {
+    stage_rows_out<K>(gsh, dL_dsh, n, blockIdx.x * 256, stage, accum != 0);
+  }
+}
+
+// The SH gradient of a step from its FACTORED form (dist_views.FactoredShGrad).  For one view dL/dsh[c][rgb] is the
+// outer product dL/dcolour[rgb] * basis_c(pw - camera centre) -- eq (5), gsmodel.py:84-85 -- so the views of a step
+// (this rank's and, all-gathered, every other rank's) travel as 3 floats per Gaussian and view instead of 48 per
+// Gaussian and rank, and this kernel forms  scale * sum_v dcolour_v (x) basis(pw - twc_v)  once.
+// rows: [views][stride] floats, row v = {dL/dcolour [N][3], twc[3], padding}.  Outputs as k_preprocess_bwd's.
+template <int NC, bool RAW>
+__global__ __launch_bounds__(256) void k_sh_grad_views(int n, int views, const float* __restrict__ pws,
+                                                       const float* __restrict__ rows, int64_t stride, float scale,
+                                                       float* __restrict__ dL_dsh, float* __restrict__ dL_dsh_high,
+                                                       int accum) {
+  constexpr int K = 3 * NC;
+  constexpr int KH = K - 3;
+  constexpr int KS = RAW ? (KH > 0 ? KH : 1) : K;
+  __shared__ float stage[RowStage<KS>::LDS_FLOATS];
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  float gsh[K];
+#pragma unroll
+  for (int k = 0; k < K; ++k) gsh[k] = 0.f;
+  if (i < n) {
+    const f3 pw = ld3(pws + 3 * (size_t)i);
+    for (int v = 0; v < views; ++v) {
+      const float* row = rows + (size_t)v * stride;
+      const f3 g = ld3(row + 3 * (size_t)i);
+      if (g.x == 0.f && g.y == 0.f && g.z == 0.f) continue;   // not drawn in this view
+      const ShDir<NC> d = sh_basis_f<NC>(pw, row + 3 * (size_t)n);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        gsh[3 * c] = __builtin_fmaf(g.x, d.B[c], gsh[3 * c]);
+        gsh[3 * c + 1] = __builtin_fmaf(g.y, d.B[c], gsh[3 * c + 1]);
+        gsh[3 * c + 2] = __builtin_fmaf(g.z, d.B[c], gsh[3 * c + 2]);
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) gsh[k] *= scale;
   }
   if constexpr (RAW) {
     if (i < n) {
@@ -1114,8 +1176,10 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   EGS_CHECK_ARG(n >= 0 && pol && width > 0 && height > 0 && patches >= 0);
   const bool keep_order = (phase & EGS_BWD_KEEP_FORWARD_ORDER) != 0;
   const bool masked = (phase & EGS_BWD_CULLED_LISTS) != 0;
-  const int accum = (phase & EGS_BWD_ACCUMULATE) ? 1 : 0;
-  phase &= ~(EGS_BWD_KEEP_FORWARD_ORDER | EGS_BWD_CULLED_LISTS | EGS_BWD_ACCUMULATE);
+  // kernel `mode`: bit 0 accumulate, bit 1 factored SH gradient (dloss_dshs = dL/dcolour [N][3])
+  const int accum = ((phase & EGS_BWD_ACCUMULATE) ? 1 : 0) | ((phase & EGS_BWD_FACTORED_SH) ? 2 : 0);
+  const bool factored = (phase & EGS_BWD_FACTORED_SH) != 0;
+  phase &= ~(EGS_BWD_KEEP_FORWARD_ORDER | EGS_BWD_CULLED_LISTS | EGS_BWD_ACCUMULATE | EGS_BWD_FACTORED_SH);
   EGS_CHECK_ARG(phase >= 0 && phase <= 2);
   if (phase != 2) { row_begin = 0; row_count = n; }
   EGS_CHECK_ARG(row_begin >= 0 && row_count >= 0 && row_begin + (int64_t)row_count <= n && row_begin % 256 == 0);
@@ -1123,7 +1187,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   if (n == 0) return 0;
   EGS_CHECK_ARG(pws && rots && scales && shs && alphas && Rcw && tcw && twc && depths && ws && dloss_dpws &&
                 dloss_dshs && dloss_dalphas && dloss_dscales && dloss_drots && dloss_dus);
-  if (raw) EGS_CHECK_ARG(rec && (sh_dim == 3 || (shs_high && dloss_dshs_high)));
+  if (raw) EGS_CHECK_ARG(rec && (sh_dim == 3 || (shs_high && (dloss_dshs_high || factored))));
   if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
     set_error(EGS_ERR_WORKSPACE, "fused_backward workspace too small", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
@@ -1147,7 +1211,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
 #define EGS_PREB_ARGS(NC, RAW)                                                                                    \
   row_count, pp, pws + 3 * r0, rots + 4 * r0, scales + 3 * r0, shs + (RAW ? 3 : sh_dim) * r0,                      \
       (RAW && shs_high) ? shs_high + kh * r0 : shs_high, alphas + r0, Rcw, tcw, twc, depths + r0,                  \
-      (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0, dloss_dshs + (RAW ? 3 : sh_dim) * r0,                    \
+      (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0, dloss_dshs + (factored ? 3 : (RAW ? 3 : sh_dim)) * r0,   \
       (RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high, dloss_dalphas + r0,                  \
       dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0, dcolor_dpws ? dcolor_dpws + 9 * r0 : dcolor_dpws, \
       accum
@@ -1210,4 +1274,32 @@ extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int wi
                              dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
                              dloss_drots_raw, dloss_dus, tile_order, grad_records, dcolor_dpws, phase, row_begin,
                              row_count, stream);
+}
+
+extern "C" int egs_sh_grad_views(int n, int sh_dim, int views, const float* pws, const float* rows,
+                                 int64_t row_stride, float scale, float* dloss_dshs, float* dloss_dhigh_shs,
+                                 int accumulate, void* stream) {
+  EGS_CHECK_ARG(n >= 0 && views >= 0);
+  EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
+  if (n == 0) return 0;
+  EGS_CHECK_ARG(pws && dloss_dshs && (views == 0 || rows) && row_stride >= 3 * (int64_t)n + 3);
+  const bool raw = dloss_dhigh_shs != nullptr;
+  EGS_CHECK_ARG((((uintptr_t)dloss_dshs | (uintptr_t)dloss_dhigh_shs) & 15) == 0);
+  dim3 g(div_up(n, 256)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+#define EGS_SHV(NC, RAW)                                                                                     \
+  EGS_LAUNCH("k_sh_grad_views", (k_sh_grad_views<NC, RAW>), g, b, s, n, views, pws, rows, row_stride, scale, \
+             dloss_dshs, dloss_dhigh_shs, accumulate ? 1 : 0)
+  switch (sh_dim * 2 + (raw ? 1 : 0)) {
+    case 6: case 7: EGS_SHV(1, false); break;   // degree 0: the row IS the low part ([N][3] either way)
+    case 24: EGS_SHV(4, false); break;
+    case 25: EGS_SHV(4, true); break;
+    case 54: EGS_SHV(9, false); break;
+    case 55: EGS_SHV(9, true); break;
+    case 96: EGS_SHV(16, false); break;
+    default: EGS_SHV(16, true); break;
+  }
+#undef EGS_SHV
+  EGS_LAUNCH_OK();
+  return 0;
 }

@@ -226,6 +226,156 @@ def grad_exchange_bytes(n_gaussians: int) -> int:
     return 4 * n_gaussians * sum(GRAD_FLOATS_PER_GAUSSIAN.values())
 
 
+def factored_exchange_pays(world: int, views_per_rank: int, sh_dim: int = 48) -> bool:
+    """Does a step move fewer bytes per link with its SH gradient FACTORED (``FactoredShGrad``) than with the rows
+    all-reduced?  An all-gather of 3 floats per Gaussian and VIEW receives ``(world - 1) * views * 3`` floats per
+    Gaussian; a (ring or direct) all-reduce of the rows moves ``2 (world - 1) / world * sh_dim``.  One rank: the
+    factored form still saves HBM traffic once a rank renders several views (12 B instead of 2 x 192 B per Gaussian
+    and accumulated view), and costs one extra kernel with a single view."""
+    if world <= 1:
+        return views_per_rank > 1
+    return (world - 1) * views_per_rank * 3 < 2.0 * (world - 1) / world * sh_dim
+
+
+class FactoredShGrad:
+    """The SH-coefficient gradient of a step, kept in the form it is born in.
+
+    ``dL/dshs`` of ONE view is an outer product per Gaussian (backward.md eq (5), gsmodel.py:84-85):
+    ``dL/dcolour[rgb] * basis_c(pw - camera centre)`` -- 3 numbers and a direction every rank can recompute from the
+    replicated ``pws``.  48 of the 59 gradient floats per Gaussian of SURVEY 8e's exchange are these rows.  While
+    attached, every ``GSFunction`` / ``GSRawFunction`` backward (fused path) leaves its view's ``dL/dcolour [N,3]``
+    and camera centre in a row of this object instead of forming the 48-float rows (autograd gets ``None`` for the
+    SH tensors; the 11 other floats go on as before), and ``finish()``
+
+    * all-gathers the rows of every rank (one collective: ``views * (12 N + 16)`` bytes per rank -- against an
+      all-reduce of ``192 N`` bytes; RCCL over xGMI on GPUs, gloo in the CPU tests),
+    * forms ``scale * sum over all views of dL/dcolour (x) basis`` ONCE (``egs_sh_grad_views``) into the ``.grad`` of
+      the SH tensors (allocated, or added to when one exists).
+
+    The result equals the all-reduced rows up to the order of the float sums.  Whether it pays: see
+    ``factored_exchange_pays``.
+
+        fx = FactoredShGrad(views=len(my_cams))
+        with fx.attach():
+            for cam in my_cams: GSFunction.apply(pws, shs, ..., cam)[0].backward(dl)
+        fx.finish(pws, shs)                                        # shs.grad = mean over ranks of the sum over views
+        exchange_gradients(params, names=("pws", "alphas", "scales", "rots"))     # 44 of the 236 bytes per Gaussian
+
+    With ``ViewStreams``: attach around the lanes, call ``vs.finish()`` first (it orders every lane before the
+    caller's stream), then ``finish``.  Only ``.backward()`` passes that accumulate into the leaves use it
+    (``torch.autograd.grad`` gets its rows as always); not together with ``ChunkedExchange``."""
+
+    def __init__(self, views: int, group=None):
+        self.views = max(1, int(views))
+        self.group = group
+        self.rows = None          # [views, stride] float32: row v = {dL/dcolour [N,3], twc[3], padding}
+        self.n = 0
+        self.sh_dim = None
+        self._next = 0
+        import threading
+        self._lock = threading.Lock()     # backward runs on autograd's thread(s)
+
+    @staticmethod
+    def row_stride(n: int) -> int:
+        return (3 * n + 3 + 3) // 4 * 4   # floats; a multiple of four keeps every row 16-B aligned
+
+    def attach(self):
+        import contextlib
+        from . import fused
+
+        @contextlib.contextmanager
+        def cm():
+            prev, fused._sh_sink = fused._sh_sink, self
+            self._next = 0
+            try:
+                yield self
+            finally:
+                fused._sh_sink = prev
+        return cm()
+
+    def restart(self):
+        """Forget the rows of the step so far (the step is rendered again)."""
+        with self._lock:
+            self._next = 0
+
+    def slot(self, n: int, sh_dim: int, cam, raw: bool) -> torch.Tensor:
+        """Called by ``fused.backward``: the [N,3] tensor this view's dL/dcolour goes to (its camera centre is
+        stored behind it on the current stream)."""
+        with self._lock:
+            v = self._next
+            if v >= self.views:
+                raise RuntimeError("FactoredShGrad(views=%d): a backward pass of view %d -- every rank gathers "
+                                   "exactly `views` rows per step" % (self.views, v + 1))
+            self._next = v + 1
+            stride = self.row_stride(n)
+            dev = cam.twc.device
+            if self.rows is None or self.n != n or self.rows.device != dev:
+                # (not zero-filled: a fill enqueued on THIS lane's stream would race the rows other lanes write; every
+                # word a reader touches is written by the backward kernel, by the copy below or by gathered())
+                self.rows = torch.empty((self.views, stride), dtype=torch.float32, device=dev)
+                self.n = n
+            if v > 0 and self.sh_dim != sh_dim:
+                raise RuntimeError("FactoredShGrad: views of one step with different SH widths")
+            self.sh_dim = sh_dim
+        row = self.rows[v]
+        row[3 * n:3 * n + 3].copy_(cam.twc.reshape(3))
+        return row[:3 * n].view(n, 3)
+
+    def gathered(self):
+        """-> (rows of every rank [world * views, stride], world).  Rows no backward pass filled count as zeros."""
+        if self._next < self.views:
+            self.rows[self._next:].zero_()
+        world = _world(self.group)
+        if world == 1:
+            return self.rows, 1
+        out = torch.empty((world * self.views, self.rows.shape[1]), dtype=torch.float32, device=self.rows.device)
+        try:
+            dist.all_gather_into_tensor(out.view(-1), self.rows.view(-1), group=self.group)
+        except (RuntimeError, NotImplementedError):     # a backend without the flat form (gloo on device tensors)
+            dist.all_gather(list(out.view(world, -1).unbind(0)), self.rows.view(-1), group=self.group)
+        return out, world
+
+    def finish(self, pws: torch.Tensor, shs: torch.Tensor, high_shs: Optional[torch.Tensor] = None,
+               average: bool = True) -> None:
+        """``shs.grad`` (raw layout: ``shs`` = low_shs [N,3] and ``high_shs`` [N,K-3]) += scale * the step's SH gradient
+        over the views of ALL ranks; scale = 1 / ranks (``average``: what ``exchange_gradients`` does to the other
+        tensors) or 1 (``Trainer``, whose loss already carries 1 / views).  A collective: every rank calls it."""
+        from . import _lib
+        if self.rows is None or self._next == 0:
+            if _world(self.group) > 1:
+                raise RuntimeError("FactoredShGrad.finish without a backward pass on this rank (its peers would wait "
+                                   "in the all-gather)")
+            return
+        n = self.n
+        rows, world = self.gathered()
+        self._next = 0
+        raw = high_shs is not None
+        K = self.sh_dim
+        lib = _lib.load()
+        outs = [shs, high_shs] if (raw and K > 3) else [shs]
+        widths = [3, K - 3] if (raw and K > 3) else [K]
+        grads = [t.grad for t in outs]
+        usable = all(g is not None and g.dtype == torch.float32 and g.is_contiguous() and g.shape == (n, w)
+                     and not (g.data_ptr() & 15) for g, w in zip(grads, widths))
+        accumulate = usable
+        if not usable:
+            fresh = [torch.empty((n, w), dtype=torch.float32, device=rows.device) for w in widths]
+        tgt = grads if usable else fresh
+        st = torch.cuda.current_stream(rows.device).cuda_stream
+        _lib.check(lib.egs_sh_grad_views(
+            n, K, rows.shape[0], pws.data_ptr(), rows.data_ptr(), rows.shape[1],
+            (1.0 / world) if average else 1.0, tgt[0].data_ptr(), tgt[1].data_ptr() if len(tgt) > 1 else None,
+            1 if accumulate else 0, st))
+        if not usable:
+            for t, g, f in zip(outs, grads, fresh):
+                if g is None:
+                    t.grad = f
+                else:
+                    g.add_(f)
+
+
+
+
 class ViewStreams:
     """The views of ONE rank's share of a step, dealt round-robin to ``n_streams`` HIP streams.
 
@@ -334,9 +484,14 @@ class ViewStreams:
         for k, lane in enumerate(self.leaves[1:]):
             if all(q.grad is None for q in lane):
                 continue
-            fa, fb = flat_grad_buffer(self.params), flat_grad_buffer(lane)
+            # (tensors without a gradient in this lane -- the SH tensors under FactoredShGrad -- are left out: the
+            # others still tile one buffer)
+            pq = [(p, q) for p, q in zip(self.params, lane) if q.grad is not None]
+            have = all(p.grad is not None for p, _ in pq)
+            fa = flat_grad_buffer([p for p, _ in pq]) if have else None
+            fb = flat_grad_buffer([q for _, q in pq]) if have else None
             if fa is not None and fb is not None and fa.numel() == fb.numel() and \
-                    all(p.grad.storage_offset() == q.grad.storage_offset() for p, q in zip(self.params, lane)):
+                    all(p.grad.storage_offset() == q.grad.storage_offset() for p, q in pq):
                 if self.cuda:
                     fb.record_stream(self._main)
                 fa.add_(fb)                     # both came out of fused.backward: ONE add over 59 N floats

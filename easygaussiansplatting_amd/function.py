@@ -89,9 +89,14 @@ class GSFunction(torch.autograd.Function):
             return (None,) * 7
         if ctx.mode == "fused":
             pws, shs, alphas, scales, rots = ctx.saved_tensors
-            acc = _fused.accumulation_targets((pws, shs, alphas, scales, rots), ctx)
+            # a training step that keeps its SH gradient factored (dist_views.FactoredShGrad): this view leaves
+            # dL/dcolour [N,3] in the sink, autograd gets None for shs, the other four go on as usual
+            sink = _fused.sh_sink_for(ctx, 5, (shs,))
+            leaves = (pws, alphas, scales, rots) if sink is not None else (pws, shs, alphas, scales, rots)
+            acc = _fused.accumulation_targets(leaves, ctx, 5)
             dpws, dshs, dalphas, dscales, drots, dus = _fused.backward(
-                pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous(), accumulate=acc)
+                pws, shs, alphas, scales, rots, cam, ctx.state, dloss_dgammas.contiguous(), accumulate=acc,
+                sh_sink=sink)
             if acc is not None:      # added to the leaves' .grad inside the kernel: nothing for autograd to accumulate
                 return None, None, None, None, None, dus, None
             return dpws, dshs, dalphas, dscales, drots, dus, None
@@ -131,10 +136,13 @@ class GSRawFunction(torch.autograd.Function):
         if dloss_dgammas is None:
             return (None,) * 8
         pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw = ctx.saved_tensors
-        acc = _fused.accumulation_targets((pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw), ctx)
+        sink = _fused.sh_sink_for(ctx, 6, (low_shs, high_shs))       # see GSFunction.backward
+        leaves = (pws, alphas_raw, scales_raw, rots_raw) if sink is not None else \
+            (pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw)
+        acc = _fused.accumulation_targets(leaves, ctx, 6)
         dpws, dlow, dhigh, dalphas, dscales, drots, dus = _fused.backward(
             pws, low_shs, alphas_raw, scales_raw, rots_raw, ctx.cam, ctx.state, dloss_dgammas.contiguous(),
-            high_shs=high_shs, accumulate=acc)
+            high_shs=high_shs, accumulate=acc, sh_sink=sink)
         if acc is not None:
             return None, None, None, None, None, None, dus, None
         return dpws, dlow, dhigh, dalphas, dscales, drots, dus, None

@@ -38,6 +38,7 @@ SAVE_DCOLOR = os.environ.get("EGS_SAVE_DCOLOR", "1") != "0"          # A/B knob:
 CULL_LISTS = os.environ.get("EGS_CULL_LISTS", "1") != "0"            # A/B knob: footprint-culled tile lists
 CULLED_LISTS = 32         # include/egs_hip.h EGS_BWD_CULLED_LISTS
 ACCUMULATE = 64           # include/egs_hip.h EGS_BWD_ACCUMULATE
+FACTORED_SH = 128         # include/egs_hip.h EGS_BWD_FACTORED_SH
 GSID_MASK = 0x0FFFFFFF    # csrc/egs_common.h EGS_GSID_MASK
 MAILBOX_SLOTS = 64
 
@@ -96,6 +97,7 @@ class _DeviceCtx:
 _contexts = {}
 _tls = threading.local()
 _exchange_hook = None    # dist_views.ChunkedExchange while attached (process-wide: backward runs on autograd's thread)
+_sh_sink = None          # dist_views.FactoredShGrad while attached: the SH gradient of a view stays dL/dcolour [N,3]
 
 
 def _ctx(dev) -> _DeviceCtx:
@@ -474,14 +476,31 @@ def _engine_accumulates_into(node_ctx, count):
         return False
 
 
-def accumulation_targets(leaves, node_ctx=None):
+def sh_sink_for(node_ctx, count, sh_tensors):
+    """The attached ``dist_views.FactoredShGrad`` when the running backward pass may leave its SH gradient there: the
+    SH inputs are leaves (``finish`` writes their ``.grad``; behind a torch ``cat`` the rows are needed here) and the
+    engine accumulates into the node's ``count`` leaves (a ``.backward()`` of a training step -- never under
+    ``torch.autograd.grad``, whose caller expects the rows returned)."""
+    sink = _sh_sink
+    if sink is None or not all(t.is_leaf and t.requires_grad for t in sh_tensors) or \
+            not _engine_accumulates_into(node_ctx, count):
+        return None
+    if _exchange_hook is not None:
+        raise RuntimeError("FactoredShGrad and ChunkedExchange cannot be attached together (the overlapped exchange "
+                           "all-reduces the SH rows the factored form never writes)")
+    return sink
+
+
+def accumulation_targets(leaves, node_ctx=None, count=None):
     """The ``.grad`` tensors of ``leaves`` when the coming backward may add to them in place (see
     ``accumulate_in_kernel``), else None.  ``node_ctx``: the autograd node whose backward is running -- the in-kernel
     accumulation is only taken when the engine itself would accumulate into every leaf (never under
-    ``torch.autograd.grad``, whose callers expect returned tensors and an untouched ``.grad``)."""
+    ``torch.autograd.grad``, whose callers expect returned tensors and an untouched ``.grad``).  ``count``: how many
+    inputs of the node are differentiated leaves (default ``len(leaves)``; larger when ``leaves`` leaves the SH
+    tensors out because their gradient goes to a ``FactoredShGrad``)."""
     if not getattr(_acc_flag, "on", False) or _exchange_hook is not None:
         return None
-    if node_ctx is not None and not _engine_accumulates_into(node_ctx, len(leaves)):
+    if node_ctx is not None and not _engine_accumulates_into(node_ctx, len(leaves) if count is None else count):
         return None
     grads = []
     for t in leaves:
@@ -495,13 +514,17 @@ def accumulation_targets(leaves, node_ctx=None):
     return grads
 
 
-def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, high_shs=None, accumulate=None):
+def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, high_shs=None, accumulate=None,
+             sh_sink=None):
     """-> (dloss_dpws[N,3], dloss_dshs[N,K], dloss_dalphas[N,1], dloss_dscales[N,3],
            dloss_drots[N,4], dloss_dus[N,2])  -- the gradient tuple of gsmodel.py:87-93.
     With ``high_shs`` (raw tensors, see ``forward``): -> (dpws, dlow_shs[N,3], dhigh_shs[N,K-3],
     dalphas_raw[N,1], dscales_raw, drots_raw, dus).
     ``accumulate``: the five (raw: six) gradient tensors of earlier views, in the order of the return tuple; this
-    view's gradients are ADDED to them by the kernel and the same tensors are returned."""
+    view's gradients are ADDED to them by the kernel and the same tensors are returned.
+    ``sh_sink`` (``dist_views.FactoredShGrad``): the SH gradient of this view is left there as dL/dcolour [N,3]
+    (``EGS_BWD_FACTORED_SH``); the SH entries of the return tuple are None, ``accumulate`` holds the other four
+    tensors only, and the flat buffer is the 11 floats per Gaussian of pws, alphas, scales, rots."""
     raw = high_shs is not None
     pws = _chk(pws, "pws", torch.float32, (None, 3))
     n = pws.shape[0]
@@ -523,6 +546,8 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
     # ``flat_grad_buffer(params)`` instead of five or six latency-bound ones (autograd adopts the slices as
     # ``.grad`` without copying).
     widths = [3, 3, K - 3, 1, 3, 4] if raw else [3, K, 1, 3, 4]
+    if sh_sink is not None:
+        widths = [3, 1, 3, 4]
     if accumulate is not None:
         parts = [g.view(n, w) for g, w in zip(accumulate, widths)]
     else:
@@ -542,7 +567,10 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
                 idx = _pad_index[pk] = torch.tensor(pad, dtype=torch.int64, device=dev)
             flat.index_fill_(0, idx, 0.0)
         parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]
-    if raw:
+    if sh_sink is not None:
+        dpws, dalphas, dscales, drots = parts
+        dshs, dhigh = sh_sink.slot(n, K, cam, raw), None     # [N,3]: dL/dcolour of this view (written, never added to)
+    elif raw:
         dpws, dshs, dhigh, dalphas, dscales, drots = parts
     else:
         dpws, dshs, dalphas, dscales, drots = parts
@@ -572,7 +600,11 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
         keep |= CULLED_LISTS          # the list values carry block masks
     if accumulate is not None:
         keep |= ACCUMULATE            # the outputs hold earlier views' gradients: add to them
+    if sh_sink is not None:
+        keep |= FACTORED_SH
     hook = _exchange_hook
+    if hook is not None and sh_sink is not None:
+        raise RuntimeError("fused.backward: sh_sink and an attached ChunkedExchange exclude each other")
     chunks = hook.chunks if hook is not None else 1
     rows = -(-n // (256 * chunks)) * 256 if chunks > 1 else n     # rows per chunk: whole workgroups
     if hook is not None:
@@ -589,8 +621,10 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
         launch(1 | keep, 0, 0)
         for b in range(0, n, rows):
             c = min(rows, n - b)
-            launch(2 | (keep & ACCUMULATE), b, c)
+            launch(2 | (keep & (ACCUMULATE | FACTORED_SH)), b, c)
             hook.on_chunk([p[b:b + c] for p in parts])
+    if sh_sink is not None:
+        return (dpws, None, None, dalphas, dscales, drots, dus) if raw else (dpws, None, dalphas, dscales, drots, dus)
     if raw:
         return dpws, dshs, dhigh, dalphas, dscales, drots, dus
     return dpws, dshs, dalphas, dscales, drots, dus

@@ -76,12 +76,14 @@ def make_optimizer(p, fused=True):
 class Trainer:
     def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
                  scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0,
-                 fused_activations: bool = True, view_streams: int = 3):
+                 fused_activations: bool = True, view_streams: int = 3, factored_sh: bool = True):
         self.device = device
         # a rank's views of a step go round-robin to this many HIP streams (dist_views.ViewStreams); 1 = one after
         # the other on the caller's stream
         self.view_streams = max(1, int(view_streams))
         self._vs = None
+        self.factored_sh = bool(factored_sh)     # see step(): the SH gradient of a step kept as dL/dcolour per view
+        self._fx = None
         # True: GSRawFunction (activations inside the HIP kernels); False: torch activations + GSFunction,
         # the reference's structure (gsmodel.py:198-210)
         self.fused_activations = fused_activations
@@ -163,16 +165,32 @@ class Trainer:
         # kernels are still queued) tells whether some view outgrew the buffers sized from earlier renders;
         # that happens while the trainer still meets new views, and the step is then redone exactly.
         # (from the second local view on the chain-rule kernel adds to the leaves' .grad itself: accumulate_in_kernel)
-        with _fused.accumulate_in_kernel():
+        # The SH gradient of the step stays factored when that moves fewer bytes (dist_views.FactoredShGrad: a view
+        # leaves dL/dcolour [N,3]; 12 B per Gaussian and view are all-gathered instead of 192 B per Gaussian
+        # all-reduced, and on one rank V views write 12 V + 192 B instead of accumulating 192-B rows V times)
+        fx = None
+        vmax = -(-len(view_ids) // self.world)      # rows per rank: the same on every rank (one all-gather)
+        if self.factored_sh and self.fused_activations and \
+                DV.factored_exchange_pays(self.world, vmax, 3 + self.params["high_shs"].shape[1]):
+            if self._fx is None or self._fx.views != vmax:
+                self._fx = DV.FactoredShGrad(vmax)
+            fx = self._fx
+        with _fused.accumulate_in_kernel(), (fx.attach() if fx is not None else contextlib.nullcontext()):
             with _fused.deferred() as d:
                 loss_sum, gnorm, count = self._render_views(mine, len(view_ids))
                 incomplete = d.commit()
             if incomplete:
                 self.redone_steps += 1
                 self.opt.zero_grad(set_to_none=True)
+                if fx is not None:
+                    fx.restart()
                 loss_sum, gnorm, count = self._render_views(mine, len(view_ids))   # validated render by render
+        others = self.params
+        if fx is not None:   # (a collective when world > 1; the loss already carries 1 / views: a SUM over ranks)
+            fx.finish(self.params["pws"], self.params["low_shs"], self.params["high_shs"], average=False)
+            others = {k: v for k, v in self.params.items() if k not in ("low_shs", "high_shs")}
         if self.world > 1:   # sum over ranks of (sum over local views)/V == mean over all views
-            DV.allreduce_sum_(DV.coalesce_grads(list(self.params.values())) + [gnorm, count, loss_sum])
+            DV.allreduce_sum_(DV.coalesce_grads(list(others.values())) + [gnorm, count, loss_sum])
         self.grad_accum += gnorm
         self.vis_count += count
         self.opt.step()

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 5
+#define EGS_ABI_VERSION 6
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -355,6 +355,15 @@ size_t egs_fused_backward_ws_bytes(int n);
  * ADDED to them by the chain-rule kernel (dloss_dus is per view and always written).  Replaces autograd's separate
  * accumulation kernels for a rank that renders several views per step (bench.py --views-per-rank, Trainer.step). */
 #define EGS_BWD_ACCUMULATE 64
+/* OR-ed into `phase` of egs_fused_backward(_raw): the SH gradient of this view stays in its FACTORED form.  Eq (5)
+ * (gsmodel.py:84-85: dL/dshs = dL/dcolors @ dcolor/dshs) is an outer product per Gaussian -- dL/dcolour[rgb] times the
+ * SH basis of the direction from the camera centre -- so `dloss_dshs` (raw: `dloss_dlow_shs`) receives the THREE
+ * floats dL/dcolour per Gaussian ([N][3]; always written, never accumulated; zero for a Gaussian this view did not
+ * draw) and `dloss_dhigh_shs` is not touched (may be NULL).  The rows are formed once per step, for all views, by
+ * egs_sh_grad_views.  A host that renders V views per step writes 12 instead of 4 sh_dim bytes per Gaussian and view;
+ * a data-parallel host all-gathers 12 bytes per Gaussian and VIEW instead of all-reducing 4 sh_dim per Gaussian
+ * (192 of the 236 bytes of SURVEY 8e's exchange at degree 3). */
+#define EGS_BWD_FACTORED_SH 128
 #define EGS_DRAW_CULLED_LISTS 1
 /* flags of egs_splat_draw_rec* / egs_splat_bwd_rec_lists: the lists are the REFERENCE's complete lists (every tile of
  * every rect, kernel.cu:46-80) whose values carry the same 4-bit block masks above the Gaussian index -- what
@@ -406,6 +415,17 @@ int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int he
                            const int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/,
                            const float* dcolor_dpws /*nullable*/, int phase, int row_begin, int row_count,
                            void* stream);
+/* The SH-coefficient gradient of a step from the factored form EGS_BWD_FACTORED_SH leaves:
+ *     dloss_dshs[i][c][rgb] (+)= scale * sum_v  rows[v][3 i + rgb] * basis_c(pws[i] - twc_v)
+ * rows: `views` rows of `row_stride` floats, row v = { dL/dcolour of view v [N][3], twc_v[3], padding } -- this rank's
+ * views or the all-gathered rows of every rank (then scale = 1 / ranks for the mean the exchange of SURVEY 8e forms).
+ * dloss_dhigh_shs == NULL: dloss_dshs is [N][sh_dim]; else the raw layout (dloss_dshs = low [N][3], high
+ * [N][sh_dim - 3]).  accumulate != 0: added to what the outputs hold.  (Replaces, per step instead of per view, the
+ * dL/dshs rows of gsmodel.py:84-85.) */
+int egs_sh_grad_views(int n, int sh_dim, int views, const float* pws, const float* rows, int64_t row_stride,
+                      float scale, float* dloss_dshs, float* dloss_dhigh_shs /*nullable*/, int accumulate,
+                      void* stream);
+
 
 /* ---- fused training loss -----------------------------------------
  * gau_loss = (1 - lambda) * mean|image - gt| + lambda * (1 - SSIM(image, gt)), SSIM with the

@@ -34,6 +34,7 @@ def view_grads(sc, cam, seed):
              du_dpcs=du, dcov2d_dpcs=dpc, dcolor_dpws=dpw)
     g = O.chain_rule(dus, dcinv, dal, dcol, cam.Rcw, J)
     grads = dict(pws=g["dpws"], shs=g["dshs"], alphas=g["dalphas"][:, None], scales=g["dscales"], rots=g["drots"])
+    grads["_dcolor"] = dcol        # (not a parameter gradient: the factor FactoredShGrad exchanges)
     return grads, dus, depths > 0.2
 
 
@@ -152,3 +153,63 @@ def test_two_rank_exchange_of_a_flat_gradient_buffer_is_one_collective():
         for k, a, w in zip(DV.PARAM_ORDER, starts, widths):
             want = np.arange(n * w, dtype=np.float32).reshape(n, w) * 1.5 + a      # mean of x1 and x2
             np.testing.assert_allclose(grads[k], want, rtol=1e-6)
+
+
+def _worker_factored(rank, world, port, q):
+    """The SH gradient exchanged in its factored form: every rank puts dL/dcolour [N,3] and the camera centre of ITS
+    view into a ``FactoredShGrad`` row; ``gathered()`` is the collective of ``finish()`` (the kernel that forms the rows
+    from it is HIP: tests/test_gpu_factored_sh.py, tests/test_gpu_dist_views.py)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sc, cams = _scene()
+        grads, _, _ = view_grads(sc, cams[rank], seed=100)
+        n = sc.pws.shape[0]
+        fx = DV.FactoredShGrad(views=2)                 # two rows per rank, this rank fills one: the other counts as 0
+
+        class Cam:
+            twc = torch.from_numpy(np.asarray(cams[rank].twc, np.float32).reshape(3))
+        slot = fx.slot(n, sc.shs.shape[1], Cam, False)
+        assert slot.shape == (n, 3) and fx.rows.shape == (2, DV.FactoredShGrad.row_stride(n))
+        slot.copy_(torch.from_numpy(grads["_dcolor"].astype(np.float32)))
+        rows, w = fx.gathered()
+        q.put((rank, rows.numpy().copy(), w))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_factored_sh_exchange_carries_the_rows():
+    """eq (5) of backward.md (gsmodel.py:84-85) is an outer product: from the all-gathered (dL/dcolour, camera centre)
+    of both views every rank can form the mean of the two views' dL/dshs rows -- 12 B per Gaussian and view on the wire
+    instead of 4 sh_dim per Gaussian."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_factored, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=300) for _ in range(world)], key=lambda r: r[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    sc, cams = _scene()
+    n, K = sc.shs.shape
+    per_view = [view_grads(sc, c, seed=100)[0] for c in cams]
+    want = (per_view[0]["shs"] + per_view[1]["shs"]) / 2
+    assert np.abs(want).max() > 0
+    for rank, rows, w in res:
+        assert w == 2 and rows.shape == (4, DV.FactoredShGrad.row_stride(n))
+        np.testing.assert_array_equal(rows, res[0][1])                  # every rank holds the same rows
+        assert not rows[1, :3 * n].any() and not rows[3, :3 * n].any()  # the rows nobody filled
+        got = np.zeros((n, K))
+        for v in range(rows.shape[0]):
+            g = rows[v, :3 * n].reshape(n, 3).astype(np.float64)
+            d = sc.pws - rows[v, 3 * n:3 * n + 3].astype(np.float64)
+            B = O.sh_basis(d / np.sqrt((d * d).sum(1))[:, None], K // 3)[:, :K // 3]
+            got += (B[:, :, None] * g[:, None, :]).reshape(n, K)        # sh[i, 3 c + rgb]
+        np.testing.assert_allclose(got / w, want, rtol=0, atol=2e-6 * np.abs(want).max())   # (fp32 on the wire)
+    assert DV.factored_exchange_pays(8, 1) and DV.factored_exchange_pays(2, 1) and not DV.factored_exchange_pays(8, 4)
+    assert DV.factored_exchange_pays(1, 8) and not DV.factored_exchange_pays(1, 1)
+    assert DV.factored_exchange_pays(4, 1, 12) and not DV.factored_exchange_pays(8, 1, 3)

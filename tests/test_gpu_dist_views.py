@@ -1,7 +1,8 @@
 """Two ranks, HIP path: every rank renders ITS camera view with ``GSFunction`` (fused kernels) on the GPU and
 the ranks exchange the parameter gradients -- once as the single flat all-reduce, once chunk by chunk from
-inside the backward pass (``dist_views.ChunkedExchange``).  The property pinned is the one the 8-GPU run of
-BASELINE configs[3] relies on (SURVEY 8a': the counterpart of the reference's one-view-per-step loop,
+inside the backward pass (``dist_views.ChunkedExchange``), once with the SH gradient factored (``FactoredShGrad``: an
+all-gather of 3 floats per Gaussian and view instead of the all-reduce of the 48-float rows).  The property pinned is
+the one the 8-GPU run of BASELINE configs[3] relies on (SURVEY 8a': the counterpart of the reference's one-view-per-step loop,
 train.py:48-57): the all-reduced mean of one view per rank == the two-view gradient accumulation of ONE process.
 
 Both ranks share ``cuda:0`` (the box has one GPU), so the collectives go through gloo (host staging); RCCL
@@ -59,7 +60,17 @@ def _worker(rank, world, port, q, chunked):
         for rep in range(2):               # the second pass runs the enqueue-ahead forward
             for p in P.values():
                 p.grad = None
-            if chunked:
+            if chunked < 0:
+                # the SH gradient factored: all-gather of dL/dcolour [N,3] per view + one kernel forming the rows; the
+                # other 11 floats per Gaussian as ONE all-reduce (they still tile a buffer of their own)
+                fx = DV.FactoredShGrad(views=1)
+                with fx.attach():
+                    _render(P, cams[rank], dl)
+                assert P["shs"].grad is None
+                fx.finish(P["pws"], P["shs"], average=True)
+                DV.exchange_gradients(P, names=("pws", "alphas", "scales", "rots"))
+                assert fused.flat_grad_buffer([P[k] for k in ("pws", "alphas", "scales", "rots")]) is not None
+            elif chunked:
                 ex = DV.ChunkedExchange(world, chunks=chunked)          # the chunk count is a knob: 2, 4, 8
                 with ex.attach():
                     _render(P, cams[rank], dl)
@@ -98,8 +109,9 @@ def _spawn(target, args):
     return sorted(res, key=lambda r: r[0])
 
 
-@pytest.mark.parametrize("chunked", [0, 2, 4, 8])
+@pytest.mark.parametrize("chunked", [0, 2, 4, 8, -1])
 def test_two_rank_hip_gradients_equal_one_process_two_view_accumulation(chunked):
+    """chunked: 0 = one flat all-reduce, 2 / 4 / 8 = ``ChunkedExchange``, -1 = ``FactoredShGrad``."""
     res = _spawn(_worker, (chunked,))
     sc, cams, dl = _setup()
     P = _params(sc)
