@@ -18,6 +18,7 @@ Then:       * gradients accumulated by autograd over the 8 views in one process 
             * the same 8 views through the overlapped exchange path (``ChunkedExchange`` on a one-rank process group,
               what ``EGS_FORCE_EXCHANGE=1 python bench.py --overlap-exchange`` runs; chunk counts 2, 4, 8 in turn) give the same mean.
 """
+import contextlib
 import os
 import socket
 
@@ -176,20 +177,26 @@ def test_eight_ring_views_full_size():
     vleaves = [P[k].detach().requires_grad_(True) for k in NAMES]
     vs = DV.ViewStreams(vleaves, 3)
     uss = [torch.zeros((sc.n, 2), device="cuda", requires_grad=True) for _ in range(3)]
-    for rep in range(2):                       # (the second step starts from empty accumulators, capacities learnt)
+    # third step: the SH gradient kept factored (``FactoredShGrad``: every view leaves dL/dcolour [N,3], one kernel forms
+    # the step's rows -- what the ``ring_views_8`` leg and ``--views-per-rank 8`` run by default)
+    fx = DV.FactoredShGrad(N_VIEWS)
+    for rep in range(3):                       # (the second step starts from empty accumulators, capacities learnt)
         for t in vleaves:
             t.grad = None
         with fused.deferred() as d:
             vs.begin()
-            with fused.accumulate_in_kernel():
+            with fused.accumulate_in_kernel(), (fx.attach() if rep == 2 else contextlib.nullcontext()):
                 for v in range(N_VIEWS):
                     with vs.lane(v) as lv:
                         image, _ = GSFunction.apply(*lv, uss[vs.lane_index(v)], cams[v])
                         image.backward(dls[v])
             vs.finish()
+            if rep == 2:
+                assert vleaves[1].grad is None
+                fx.finish(vleaves[0], vleaves[1])
             assert not d.commit()
         torch.cuda.synchronize()
-        assert fused.flat_grad_buffer(vleaves) is not None
+        assert fused.flat_grad_buffer(vleaves if rep < 2 else vleaves[:1] + vleaves[2:]) is not None
         for k, t in zip(NAMES, vleaves):
             ref = leaves[k].grad
             assert float((t.grad - ref).abs().max()) <= 2e-5 * float(ref.abs().max()), (rep, k)
