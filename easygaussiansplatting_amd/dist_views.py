@@ -326,7 +326,10 @@ class FactoredShGrad:
         if self._next < self.views:
             self.rows[self._next:].zero_()
         world = _world(self.group)
-        if world == 1:
+        initialised = dist.is_available() and dist.is_initialized()
+        # (EGS_FORCE_EXCHANGE=1: a one-rank process group still runs its collective -- bench.py's way of exercising
+        # the exchange code on a single GPU)
+        if world == 1 and not (initialised and os.environ.get("EGS_FORCE_EXCHANGE", "0") == "1"):
             return self.rows, 1
         out = torch.empty((world * self.views, self.rows.shape[1]), dtype=torch.float32, device=self.rows.device)
         try:
