@@ -171,7 +171,7 @@ def main():
                     help="camera views every rank renders per step (forward + backward each, gradients accumulated; "
                          "ONE gradient exchange per step): 8 on one GPU = BASELINE configs[3]'s eight ring views; on N "
                          "GPUs it amortises the 236-MB all-reduce over V renders")
-    ap.add_argument("--view-streams", type=int, default=3,
+    ap.add_argument("--view-streams", type=int, default=4,
                     help="with --views-per-rank > 1: HIP streams the views of a rank are dealt to (1 = one after the "
                          "other on the caller's stream); every stream accumulates its own gradient buffer, added at the "
                          "end of the step")

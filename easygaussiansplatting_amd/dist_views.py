@@ -407,7 +407,7 @@ class ViewStreams:
     the same code.
     """
 
-    def __init__(self, params: Sequence[torch.Tensor], n_streams: int = 3):
+    def __init__(self, params: Sequence[torch.Tensor], n_streams: int = 4):
         self.params = list(params)
         if not self.params:
             raise ValueError("ViewStreams needs at least one parameter tensor")

@@ -76,7 +76,7 @@ def make_optimizer(p, fused=True):
 class Trainer:
     def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
                  scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0,
-                 fused_activations: bool = True, view_streams: int = 3, factored_sh: bool = True):
+                 fused_activations: bool = True, view_streams: int = 4, factored_sh: bool = True):
         self.device = device
         # a rank's views of a step go round-robin to this many HIP streams (dist_views.ViewStreams); 1 = one after
         # the other on the caller's stream
