@@ -213,6 +213,12 @@ def main():
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with `python -m torch.distributed.run "
                          "--nproc-per-node %d bench.py --gpus %d ...` (or plain `python bench.py --gpus %d`, which "
                          "re-executes itself that way)" % (a.gpus, world, a.gpus, a.gpus, a.gpus))
+    # EGS_BENCH_REHEARSAL=1: every rank on cuda:0, collectives over gloo (RCCL refuses two ranks on one device) -- the
+    # N > 1 code path end to end on a one-GPU box.  The numbers mean nothing (the ranks share the GPU, the exchange is
+    # staged through the host) and the line says so ("rehearsal": true); what it checks is that the path runs.
+    rehearsal = os.environ.get("EGS_BENCH_REHEARSAL") == "1"
+    if rehearsal:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     # EGS_FORCE_EXCHANGE=1 runs the RCCL gradient exchange even with one rank (a 1-GPU box can then
@@ -223,7 +229,10 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
+        if rehearsal:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)  # "nccl" is RCCL on ROCm
 
     lib = _lib.load()
     gsc.set_policy("gsplatcu")
@@ -699,13 +708,18 @@ def main():
             "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
+            **({"rehearsal": "EGS_BENCH_REHEARSAL=1: all ranks on ONE GPU, collectives over gloo -- the numbers of this "
+                             "line are not measurements of the multi-GPU path"} if rehearsal else {}),
             "config": {"workload": "%s: %d synthetic Gaussians, %dx%d, SH degree %d, "
                                    "forward+backward (GSFunction, mode=%s)%s"
                                    % ("1 MI355X per view" if V == 1 else
                                       "%d ring views per MI355X and step (BASELINE configs[3]'s views, gradients "
                                       "accumulated)" % V,
                                       sc.n, a.width, a.height, {3: 0, 12: 1, 27: 2, 48: 3}[a.sh_dim], a.mode,
-                                      ", RCCL all-reduce of 59 fp32 grads/Gaussian" if world > 1 else ""),
+                                      "" if world == 1 else
+                                      (", RCCL all-gather of dL/dcolour (3 fp32 per Gaussian and view) + all-reduce of "
+                                       "11 fp32 grads/Gaussian, SH rows formed per step" if fx is not None else
+                                       ", RCCL all-reduce of 59 fp32 grads/Gaussian")),
                        "gaussians": sc.n, "width": a.width, "height": a.height, "sh_dim": a.sh_dim,
                        "views_per_step": world * V, "views_per_rank": V, "view_streams": n_lanes, "policy": "gsplatcu", "mode": a.mode,
                        "validation": "deferred (commit per step)" if deferred else "immediate",

@@ -10,11 +10,16 @@ python $R/bench.py > $O/bench.json 2> $O/bench.err
 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/bench_20_5.json 2>> $O/bench.err
 python $R/bench.py --views-per-rank 8 --steps 10 --warmup 3 --ramp-steps 20 --cpu-sample 0 --no-ops > $O/bench_v8.json 2>> $O/bench.err
 python $R/bench.py --views-per-rank 8 --view-streams 1 --steps 10 --warmup 3 --ramp-steps 20 --cpu-sample 0 --no-ops > $O/bench_v8_one_stream.json 2>> $O/bench.err
+python $R/bench.py --views-per-rank 8 --factored-sh off --steps 10 --warmup 3 --ramp-steps 20 --cpu-sample 0 --no-ops > $O/bench_v8_rows_per_view.json 2>> $O/bench.err
 EGS_FORCE_EXCHANGE=1 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-ops --no-ring8 > $O/bench_forced_exchange.json 2>> $O/bench.err
+EGS_FORCE_EXCHANGE=1 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-ops --no-ring8 --factored-sh on > $O/bench_forced_exchange_factored.json 2>> $O/bench.err
 EGS_FORCE_EXCHANGE=1 python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 --no-ops --no-ring8 --overlap-exchange > $O/bench_forced_exchange_overlap.json 2>> $O/bench.err
 # the same command under rocprofv3 kernel trace + stats
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ks -- python $R/bench.py --cpu-sample 0 --no-ops --no-ring8 > $O/bench_under_rocprof.json 2>/tmp/ks.err
 find /tmp/ks -name "*kernel_stats.csv" -exec cp {} $O/kernel_stats.csv \;
+# eight views per step on this GPU (configs[3]'s workload; SH gradient factored, four streams): kernel stats
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/k8 -- python $R/bench.py --views-per-rank 8 --steps 10 --warmup 3 --ramp-steps 20 --cpu-sample 0 --no-ops --no-prof > $O/bench_v8_under_rocprof.json 2>/tmp/k8.err
+find /tmp/k8 -name "*kernel_stats.csv" -exec cp {} $O/v8_kernel_stats.csv \;
 # the seven-op surface: kernel stats of 40 steps of GSFunction(mode="ops")
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/ko -- python $R/tools/profile_step.py --mode ops --steps 40 > /tmp/ko.log 2>&1
 find /tmp/ko -name "*kernel_stats.csv" -exec cp {} $O/ops_kernel_stats.csv \;
