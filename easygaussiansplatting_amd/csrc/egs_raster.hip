@@ -1537,7 +1537,13 @@ __device__ __forceinline__ void swap16(float& a, float& b) {  // odd rows of a <
 // v_permlane32_swap / v_permlane16_swap, then 9 -> 5 -> 3 -> 2 -> 1 inside the rows with DPP mirrors).
 // 54 + 27 instructions instead of 36 x 6 DPP adds, and the nine totals of an entry land in nine
 // different lanes of its row -- exactly where the one-instruction atomic wants them.
+#ifndef EGS_PROBE_REDUCE   // timing probes, WRONG results (profiles/r4_draw_bwd_reduction_probes.txt): 1 = the cross-row stage as plain adds, 2 = the in-row stage too
+#define EGS_PROBE_REDUCE 0
+#endif
 __device__ __forceinline__ float rows_of4(float e0, float e1, float e2, float e3) {
+#if EGS_PROBE_REDUCE
+  return (e0 + e1) + (e2 + e3);
+#endif
   swap32(e0, e1);
   const float s01 = e0 + e1;  // lanes 0-31: e0 halves, lanes 32-63: e1 halves
   swap32(e2, e3);
@@ -1587,6 +1593,9 @@ __device__ __forceinline__ float rows_to_lanes9(const float (&q)[9], int c16) {
   } while (0)
 // same result layout as rows_to_lanes9: totals in lanes {0, 8, 4, 12, 2, 10, 6, 14, odd} of every row
 __device__ __forceinline__ float rows_to_lanes9_bank(const float (&q)[9], int c16) {
+#if EGS_PROBE_REDUCE >= 2
+  return ((q[0] + q[1]) + (q[2] + q[3])) + ((q[4] + q[5]) + (q[6] + q[7])) + q[8];
+#endif
   const bool h2 = (c16 & 2) != 0, h1 = (c16 & 1) != 0;
   constexpr int M8 = 0x140, M4 = 0x141, M2 = 0x4E, M1 = 0xB1;
   float p01, p23, p45, p67, a, b;
