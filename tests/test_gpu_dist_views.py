@@ -148,6 +148,9 @@ def _trainer_worker(rank, world, port, q):
         start.shs[:, :3] += 0.4
         tr = Trainer(start, cams, gts, max_steps=50, scene_size=4.0)
         losses = [tr.step([0, 1]) for _ in range(3)]
+        # three views on two ranks: rank 0 renders two, rank 1 one -- the factored SH exchange gathers two rows per
+        # rank, the row rank 1 never fills counts as zeros
+        losses.append(tr.step([0, 1, 1]))
         with pytest.raises(ValueError):
             tr.step([0]) if world > 1 else (_ for _ in ()).throw(ValueError())   # fewer views than ranks
         q.put((rank, (losses, {k: v.detach().cpu().numpy() for k, v in tr.params.items()})))
