@@ -658,9 +658,24 @@ def main():
                     img, _ = GSFunction.apply(*activate(raw), us, cam)
                 gau_loss(img, gt).backward()
                 opt.step()
+            fxt = DV.FactoredShGrad(1)
+
+            def train_step_factored(opt):
+                """the SH gradient never leaves its factored form: the chain-rule kernel writes dL/dcolour [N,3], the
+                optimizer forms every Gaussian's row in LDS (egs_adam_sh_factored) -- what Trainer.step does"""
+                opt.zero_grad(set_to_none=True)
+                us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+                with fxt.attach():
+                    img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                                 raw["scales_raw"], raw["rots_raw"], us, cam)
+                    gau_loss(img, gt).backward()
+                rows, _w = fxt.take()
+                opt.step(factored_sh=(rows, 1.0, raw["pws"], raw["low_shs"], raw["high_shs"]))
             train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
             train_extra["train_step_ms_fused_activations_fused_adam"] = round(
                 timed(lambda: train_step(opts["fused"], True), nf), 4)
+            train_extra["train_step_ms_fused_activations_fused_adam_factored_sh"] = round(
+                timed(lambda: train_step_factored(opts["fused"]), nf), 4)
             for name, opt in opts.items():
                 train_extra["train_step_ms_torch_activations_%s_adam" % name] = round(
                     timed(lambda: train_step(opt), nf), 4)

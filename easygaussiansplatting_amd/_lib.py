@@ -109,6 +109,8 @@ SIGNATURES = {
                                C.c_uint64, _P]),
     "egs_reset_alpha": (_i, [_i, _f, _P, _P, _P, _P]),
     "egs_adam_step": (_i, [_i, C.POINTER(EgsAdamGroup), C.c_double, C.c_double, C.c_double, _P]),
+    "egs_adam_sh_factored": (_i, [_i, _i, _i, _P, _P, _i64, _f, C.POINTER(EgsAdamGroup), C.POINTER(EgsAdamGroup),
+                                  C.c_double, C.c_double, C.c_double, _P]),
     "egs_nn_sqdist_ws_bytes": (_sz, [_i]),
     "egs_nn_sqdist": (_i, [_i, _P, _P, _sz, _P, _P]),
     "egs_viewer_prep": (_i, [_i, _i, _P, C.POINTER(C.c_float), C.POINTER(C.c_float), _f, _f, _P, _P, _P]),

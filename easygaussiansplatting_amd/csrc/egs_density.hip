@@ -16,6 +16,7 @@
 // replica computes bit-identical new Gaussians without communicating (the reference draws from the
 // device RNG stream, gsmodel.py:274).
 #include "egs_common.h"
+#include "egs_gaussian_math.h"
 
 namespace egs {
 
@@ -255,6 +256,9 @@ struct AdamArgs {
 
 __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, const AdamArgs& A, float step_size,
                                       float sqrt_bc2) {
+  // (no contraction: torch's kernels round every product, and k_adam / k_adam_sh_factored must agree to the bit
+  // wherever the compiler inlines this)
+#pragma clang fp contract(off)
   m = m + (g - m) * A.omb1;                       // exp_avg.lerp_(grad, 1 - beta1)
   v = v * A.beta2 + g * g * A.omb2;               // exp_avg_sq.mul_(b2).addcmul_(g, g, 1 - b2)
   const float denom = sqrtf(v) / sqrt_bc2 + A.eps;   // (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps)
@@ -284,6 +288,84 @@ __global__ __launch_bounds__(256) void k_adam(AdamArgs A) {
       G.p[e] = p; G.m[e] = m; G.v[e] = v;
     }
   }
+}
+
+// ---- Adam on the SH coefficients straight from the factored gradient -------------------------------------------
+// A step that kept its SH gradient factored (EGS_BWD_FACTORED_SH: dL/dcolour [N][3] per view, egs_hip.h) never needs
+// the 4 sh_dim-byte rows in HBM: one wave of the workgroup forms the rows of 64 Gaussians in LDS -- the arithmetic of
+// k_sh_grad_views, scale * sum_v dL/dcolour_v (x) basis(pw - twc_v) -- and all four waves run torch's Adam update over
+// the 64 x K contiguous elements of param / exp_avg / exp_avg_sq (7 x 4 B per element instead of 8 plus the rows'
+// write: 1344 + 12 V bytes per Gaussian at degree 3 where k_sh_grad_views + k_adam move 1728 + 12 V).
+constexpr int ASH_ROWS = 64;
+struct AdamShTensor {
+  float *p, *m, *v;                               // [N][width]
+  float step_size, sqrt_bc2;
+  int width;                                      // floats per Gaussian; 0: tensor absent
+  int col0;                                       // first column of the K-wide row it holds (0: low / whole, 3: high)
+};
+template <int NC>
+__global__ __launch_bounds__(256) void k_adam_sh_factored(int n, int views, const float* __restrict__ pws,
+                                                          const float* __restrict__ rows, int64_t stride, float scale,
+                                                          AdamShTensor T0, AdamShTensor T1, AdamArgs A) {
+  constexpr int K = 3 * NC;
+  __shared__ float g[ASH_ROWS * K];
+  const int base = blockIdx.x * ASH_ROWS;
+  const int here = min(ASH_ROWS, n - base);
+  if (threadIdx.x < ASH_ROWS) {
+    float gsh[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) gsh[k] = 0.f;
+    const int i = base + threadIdx.x;
+    if (i < n) {
+      const f3 pw = ld3(pws + 3 * (size_t)i);
+      for (int v = 0; v < views; ++v) {
+        const float* row = rows + (size_t)v * stride;
+        const f3 gc = ld3(row + 3 * (size_t)i);
+        if (gc.x == 0.f && gc.y == 0.f && gc.z == 0.f) continue;
+        const ShDir<NC> d = sh_basis_f<NC>(pw, row + 3 * (size_t)n);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          gsh[3 * c] = __builtin_fmaf(gc.x, d.B[c], gsh[3 * c]);
+          gsh[3 * c + 1] = __builtin_fmaf(gc.y, d.B[c], gsh[3 * c + 1]);
+          gsh[3 * c + 2] = __builtin_fmaf(gc.z, d.B[c], gsh[3 * c + 2]);
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < K; ++k) gsh[k] *= scale;
+    }
+#pragma unroll
+    for (int k = 0; k < K; ++k) g[threadIdx.x * K + k] = gsh[k];
+  }
+  __syncthreads();
+  auto update = [&](const AdamShTensor& T) {
+    if (T.width == 0) return;
+    const int cnt = here * T.width;                         // this workgroup's contiguous elements of the tensor
+    const size_t off = (size_t)base * T.width;              // (64 rows: every offset is a multiple of 16 bytes)
+    for (int e0 = threadIdx.x * 4; e0 < cnt; e0 += 1024) {
+      float gg[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int e = min(e0 + q, cnt - 1);
+        gg[q] = g[(e / T.width) * K + T.col0 + e % T.width];
+      }
+      if (e0 + 4 <= cnt) {
+        float4 p = *(float4*)(T.p + off + e0), m = *(float4*)(T.m + off + e0), v = *(float4*)(T.v + off + e0);
+        adam1(p.x, gg[0], m.x, v.x, A, T.step_size, T.sqrt_bc2);
+        adam1(p.y, gg[1], m.y, v.y, A, T.step_size, T.sqrt_bc2);
+        adam1(p.z, gg[2], m.z, v.z, A, T.step_size, T.sqrt_bc2);
+        adam1(p.w, gg[3], m.w, v.w, A, T.step_size, T.sqrt_bc2);
+        *(float4*)(T.p + off + e0) = p; *(float4*)(T.m + off + e0) = m; *(float4*)(T.v + off + e0) = v;
+      } else {
+        for (int q = 0; e0 + q < cnt; ++q) {
+          float p = T.p[off + e0 + q], m = T.m[off + e0 + q], v = T.v[off + e0 + q];
+          adam1(p, gg[q], m, v, A, T.step_size, T.sqrt_bc2);
+          T.p[off + e0 + q] = p; T.m[off + e0 + q] = m; T.v[off + e0 + q] = v;
+        }
+      }
+    }
+  };
+  update(T0);
+  update(T1);
 }
 
 static ParamSet to_set(const EgsGaussianParams* p) {
@@ -410,6 +492,46 @@ extern "C" int egs_adam_step(int n_groups, const EgsAdamGroup* groups, double be
   EGS_CHECK_ARG(blocks < (int64_t)1 << 31);
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_adam", k_adam, dim3((unsigned)blocks), dim3(256), s, A);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+extern "C" int egs_adam_sh_factored(int n, int sh_dim, int views, const float* pws, const float* rows,
+                                    int64_t row_stride, float scale, const EgsAdamGroup* low,
+                                    const EgsAdamGroup* high, double beta1, double beta2, double eps, void* stream) {
+  EGS_CHECK_ARG(n >= 0 && views >= 0 && low);
+  EGS_CHECK_ARG(sh_dim == 3 || sh_dim == 12 || sh_dim == 27 || sh_dim == 48);
+  if (n == 0) return 0;
+  EGS_CHECK_ARG(pws && (views == 0 || rows) && row_stride >= 3 * (int64_t)n + 3);
+  const bool raw = high != nullptr && sh_dim > 3;
+  AdamArgs A;
+  A.n_groups = 0; A.beta1 = (float)beta1; A.beta2 = (float)beta2; A.eps = (float)eps;
+  A.omb1 = (float)(1.0 - beta1); A.omb2 = (float)(1.0 - beta2);
+  auto tensor = [&](const EgsAdamGroup* g, int width, int col0, AdamShTensor* t) -> bool {
+    t->width = 0; t->col0 = col0; t->p = t->m = t->v = nullptr; t->step_size = 0.f; t->sqrt_bc2 = 1.f;
+    if (!g) return true;
+    if (!(g->param && g->exp_avg && g->exp_avg_sq && g->step >= 1 && g->count == (int64_t)n * width)) return false;
+    if ((((uintptr_t)g->param | (uintptr_t)g->exp_avg | (uintptr_t)g->exp_avg_sq) & 15) != 0) return false;
+    t->p = g->param; t->m = g->exp_avg; t->v = g->exp_avg_sq; t->width = width;
+    const double bc1 = 1.0 - pow(beta1, (double)g->step), bc2 = 1.0 - pow(beta2, (double)g->step);
+    t->step_size = (float)((double)g->lr / bc1);
+    t->sqrt_bc2 = (float)sqrt(bc2);
+    return true;
+  };
+  AdamShTensor T0, T1;
+  EGS_CHECK_ARG(tensor(low, raw ? 3 : sh_dim, 0, &T0));
+  EGS_CHECK_ARG(tensor(raw ? high : nullptr, sh_dim - 3, 3, &T1));
+  dim3 g(div_up(n, ASH_ROWS)), b(256);
+  hipStream_t s = (hipStream_t)stream;
+#define EGS_ASH(NC) \
+  EGS_LAUNCH("k_adam_sh_factored", (k_adam_sh_factored<NC>), g, b, s, n, views, pws, rows, row_stride, scale, T0, T1, A)
+  switch (sh_dim) {
+    case 3: EGS_ASH(1); break;
+    case 12: EGS_ASH(4); break;
+    case 27: EGS_ASH(9); break;
+    default: EGS_ASH(16); break;
+  }
+#undef EGS_ASH
   EGS_LAUNCH_OK();
   return 0;
 }

@@ -338,20 +338,30 @@ class FactoredShGrad:
             dist.all_gather(list(out.view(world, -1).unbind(0)), self.rows.view(-1), group=self.group)
         return out, world
 
+    def take(self):
+        """The collective half of ``finish``: -> (rows of every rank, world) and the object is ready for the next step;
+        None when this rank rendered nothing (one rank only: its peers would wait in the all-gather).  For a consumer
+        that never needs the rows in memory (``FusedAdam.step(factored_sh=...)``: ``egs_adam_sh_factored``)."""
+        if self.rows is None or self._next == 0:
+            if _world(self.group) > 1:
+                raise RuntimeError("FactoredShGrad: no backward pass on this rank in this step (its peers would wait "
+                                   "in the all-gather)")
+            return None
+        rows, world = self.gathered()
+        self._next = 0
+        return rows, world
+
     def finish(self, pws: torch.Tensor, shs: torch.Tensor, high_shs: Optional[torch.Tensor] = None,
                average: bool = True) -> None:
         """``shs.grad`` (raw layout: ``shs`` = low_shs [N,3] and ``high_shs`` [N,K-3]) += scale * the step's SH gradient
         over the views of ALL ranks; scale = 1 / ranks (``average``: what ``exchange_gradients`` does to the other
         tensors) or 1 (``Trainer``, whose loss already carries 1 / views).  A collective: every rank calls it."""
         from . import _lib
-        if self.rows is None or self._next == 0:
-            if _world(self.group) > 1:
-                raise RuntimeError("FactoredShGrad.finish without a backward pass on this rank (its peers would wait "
-                                   "in the all-gather)")
+        taken = self.take()
+        if taken is None:
             return
+        rows, world = taken
         n = self.n
-        rows, world = self.gathered()
-        self._next = 0
         raw = high_shs is not None
         K = self.sh_dim
         lib = _lib.load()

@@ -48,7 +48,11 @@ class FusedAdam:
                     p.grad.zero_()
 
     @torch.no_grad()
-    def step(self):
+    def step(self, factored_sh=None):
+        """``factored_sh`` = ``(rows, scale, pws, low_shs, high_shs | None)``: the step's SH gradient in its factored
+        form (``dist_views.FactoredShGrad.take()``: dL/dcolour [N,3] and camera centre per view; ``scale`` = 1 / ranks
+        for a mean over ranks, 1 for a sum) -- the SH tensors (``.grad`` None) are then updated by
+        ``egs_adam_sh_factored``, which forms each Gaussian's gradient row in LDS instead of reading it from memory."""
         lib = _lib.load()
         recs = []
         keep = []          # keeps contiguous gradient copies alive until the launch is enqueued
@@ -67,6 +71,26 @@ class FusedAdam:
                 recs.append(_lib.EgsAdamGroup(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
                                               st["exp_avg_sq"].data_ptr(), p.numel(), float(g["lr"]), st["step"]))
         stream = torch.cuda.current_stream().cuda_stream
+        if factored_sh is not None:
+            rows, scale, pws, low, high = factored_sh
+            n = pws.shape[0]
+            groups = []
+            for t in ((low, high) if (high is not None and high.shape[1] > 0) else (low,)):
+                if t.grad is not None:
+                    raise ValueError("FusedAdam.step(factored_sh=...): an SH tensor already holds a .grad")
+                if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+                    raise ValueError("FusedAdam needs contiguous float32 device parameters")
+                lr = next(float(g["lr"]) for g in self.param_groups if any(q is t for q in g["params"]))
+                st = self.state.get(t)
+                if st is None:
+                    st = self.state[t] = {"step": 0, "exp_avg": torch.zeros_like(t), "exp_avg_sq": torch.zeros_like(t)}
+                st["step"] = int(st["step"]) + 1
+                groups.append(_lib.EgsAdamGroup(t.data_ptr(), None, st["exp_avg"].data_ptr(),
+                                                st["exp_avg_sq"].data_ptr(), t.numel(), lr, st["step"]))
+            K = low.shape[1] + (high.shape[1] if high is not None else 0)
+            _lib.check(lib.egs_adam_sh_factored(
+                n, K, rows.shape[0], pws.data_ptr(), rows.data_ptr(), rows.shape[1], float(scale), groups[0],
+                groups[1] if len(groups) > 1 else None, self.betas[0], self.betas[1], self.eps, stream))
         for i in range(0, len(recs), 8):
             chunk = recs[i:i + 8]
             arr = (_lib.EgsAdamGroup * len(chunk))(*chunk)

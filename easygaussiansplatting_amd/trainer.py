@@ -170,8 +170,11 @@ class Trainer:
         # all-reduced, and on one rank V views write 12 V + 192 B instead of accumulating 192-B rows V times)
         fx = None
         vmax = -(-len(view_ids) // self.world)      # rows per rank: the same on every rank (one all-gather)
+        # (on one rank it pays from the second view on -- or from the first when the optimizer consumes the factored
+        # form directly, FusedAdam: the 192-B rows are then never written at all)
         if self.factored_sh and self.fused_activations and \
-                DV.factored_exchange_pays(self.world, vmax, 3 + self.params["high_shs"].shape[1]):
+                (DV.factored_exchange_pays(self.world, vmax, 3 + self.params["high_shs"].shape[1]) or
+                 (self.world == 1 and isinstance(self.opt, FusedAdam))):
             if self._fx is None or self._fx.views != vmax:
                 self._fx = DV.FactoredShGrad(vmax)
             fx = self._fx
@@ -186,14 +189,25 @@ class Trainer:
                     fx.restart()
                 loss_sum, gnorm, count = self._render_views(mine, len(view_ids))   # validated render by render
         others = self.params
+        sh_rows = None
         if fx is not None:   # (a collective when world > 1; the loss already carries 1 / views: a SUM over ranks)
-            fx.finish(self.params["pws"], self.params["low_shs"], self.params["high_shs"], average=False)
+            if isinstance(self.opt, FusedAdam):
+                # the optimizer forms each Gaussian's SH gradient row in LDS (egs_adam_sh_factored): the 4 sh_dim-byte
+                # rows are never written or read
+                taken = fx.take()
+                sh_rows = None if taken is None else (taken[0], 1.0, self.params["pws"], self.params["low_shs"],
+                                                      self.params["high_shs"])
+            else:
+                fx.finish(self.params["pws"], self.params["low_shs"], self.params["high_shs"], average=False)
             others = {k: v for k, v in self.params.items() if k not in ("low_shs", "high_shs")}
         if self.world > 1:   # sum over ranks of (sum over local views)/V == mean over all views
             DV.allreduce_sum_(DV.coalesce_grads(list(others.values())) + [gnorm, count, loss_sum])
         self.grad_accum += gnorm
         self.vis_count += count
-        self.opt.step()
+        if sh_rows is not None:
+            self.opt.step(factored_sh=sh_rows)
+        else:
+            self.opt.step()
         self.density.update_pws_lr(self.opt)                                     # gsmodel.py:180-183, 332-338
         self.iteration += 1
         mean = loss_sum / len(view_ids)

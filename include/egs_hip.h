@@ -497,6 +497,14 @@ typedef struct EgsAdamGroup {
   int32_t step;
 } EgsAdamGroup;
 int egs_adam_step(int n_groups, const EgsAdamGroup* groups, double beta1, double beta2, double eps, void* stream);
+/* The same update for the SH coefficients of a step whose SH gradient stayed factored (EGS_BWD_FACTORED_SH): equal to
+ * egs_sh_grad_views(n, sh_dim, views, pws, rows, row_stride, scale, grad..) followed by egs_adam_step on that gradient,
+ * without the gradient rows ever reaching HBM.  low: the [n][3] tensor of the raw layout (gsmodel.py:117: low_shs) --
+ * or, with high == NULL, the whole [n][sh_dim] tensor; high: the [n][sh_dim - 3] tensor (high_shs).  `grad` of the
+ * groups is ignored, `count` must be n times the width. */
+int egs_adam_sh_factored(int n, int sh_dim, int views, const float* pws, const float* rows, int64_t row_stride,
+                         float scale, const EgsAdamGroup* low, const EgsAdamGroup* high /*nullable*/, double beta1,
+                         double beta2, double eps, void* stream);
 
 /* ---- initial scales from a point cloud -----------------------------
  * out_sqdist[i] = min_{j != i} |points[i] - points[j]|^2 (FLT_MAX when n == 1): the exact squared

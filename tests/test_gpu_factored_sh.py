@@ -186,3 +186,51 @@ def test_sh_grad_views_c_abi_against_the_oracle_basis():
     out = torch.full((n, 48), 7.0, device="cuda")
     _lib.check(lib.egs_sh_grad_views(n, 48, 0, d_pws.data_ptr(), None, stride, 1.0, out.data_ptr(), None, 0, st))
     assert not out.any()
+
+
+@pytest.mark.parametrize("K", [48, 12, 3])
+@pytest.mark.parametrize("raw", [False, True])
+def test_fused_adam_from_factored_rows_equals_rows_then_adam(raw, K):
+    """``FusedAdam.step(factored_sh=...)`` (``egs_adam_sh_factored``: every Gaussian's SH gradient row formed in LDS
+    and consumed there) == ``egs_sh_grad_views`` into ``.grad`` followed by the ordinary step, on the same rows:
+    parameters and both moments, three steps, two views, a row count that is not a multiple of 64."""
+    from easygaussiansplatting_amd import _lib, dist_views as DV
+    from easygaussiansplatting_amd.optim import FusedAdam
+    lib = _lib.load()
+    torch.manual_seed(3)
+    n, V = 4037, 2
+    stride = DV.FactoredShGrad.row_stride(n)
+    pws = (torch.randn(n, 3, device="cuda") * 3).contiguous()
+
+    def tensors():
+        g = torch.Generator(device="cuda").manual_seed(11)
+        if raw and K > 3:
+            return [torch.randn(n, 3, device="cuda", generator=g).requires_grad_(True),
+                    torch.randn(n, K - 3, device="cuda", generator=g).requires_grad_(True)]
+        return [torch.randn(n, K, device="cuda", generator=g).requires_grad_(True)]
+
+    def groups(ts):
+        return [{"params": [t], "lr": lr, "name": nm} for t, lr, nm in zip(ts, (1e-3, 5e-5), ("low_shs", "high_shs"))]
+    A, B = tensors(), tensors()
+    oa, ob = FusedAdam(groups(A), eps=1e-15), FusedAdam(groups(B), eps=1e-15)
+    st = torch.cuda.current_stream().cuda_stream
+    for step in range(3):
+        rows = torch.randn(V, stride, device="cuda") * 1e-3
+        rows[1, 0:3 * n:7] = 0.0
+        rows[:, 3 * n:3 * n + 3] = torch.randn(V, 3, device="cuda") * 6
+        grads = [torch.empty_like(t) for t in A]
+        _lib.check(lib.egs_sh_grad_views(n, K, V, pws.data_ptr(), rows.data_ptr(), stride, 0.5, grads[0].data_ptr(),
+                                         grads[1].data_ptr() if len(grads) > 1 else None, 0, st))
+        for t, g in zip(A, grads):
+            t.grad = g
+        oa.step()
+        for t in B:
+            t.grad = None
+        ob.step(factored_sh=(rows, 0.5, pws, B[0], B[1] if len(B) > 1 else None))
+        torch.cuda.synchronize()
+        for a, b in zip(A, B):
+            assert torch.equal(a.detach(), b.detach()), (step, float((a - b).abs().max()))
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert torch.equal(oa.state[a][key], ob.state[b][key]), (step, key)
+            assert oa.state[a]["step"] == ob.state[b]["step"] == step + 1
+    assert float((A[0].detach() - tensors()[0].detach()).abs().max()) > 1e-4      # the parameters did move
