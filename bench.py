@@ -660,21 +660,28 @@ def main():
                 opt.step()
             fxt = DV.FactoredShGrad(1)
 
+            from easygaussiansplatting_amd.loss import gau_loss_with_grad
+            us_keep = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+
             def train_step_factored(opt):
-                """the SH gradient never leaves its factored form: the chain-rule kernel writes dL/dcolour [N,3], the
-                optimizer forms every Gaussian's row in LDS (egs_adam_sh_factored) -- what Trainer.step does"""
+                """What Trainer.step does for one view: the render validated at commit() (no host wait inside the
+                step), the loss kernels hand dL/dimage straight to backward, a persistent `us` leaf, and the SH
+                gradient never leaves its factored form -- the chain-rule kernel writes dL/dcolour [N,3], the
+                optimizer forms every Gaussian's row in LDS (egs_adam_sh_factored)"""
                 opt.zero_grad(set_to_none=True)
-                us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-                with fxt.attach():
+                us_keep.grad = None
+                with fused_path.deferred() as d, fxt.attach():
                     img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
-                                                 raw["scales_raw"], raw["rots_raw"], us, cam)
-                    gau_loss(img, gt).backward()
+                                                 raw["scales_raw"], raw["rots_raw"], us_keep, cam)
+                    _stats, dimg = gau_loss_with_grad(img.detach(), gt)
+                    img.backward(dimg)
+                    d.commit()
                 rows, _w = fxt.take()
                 opt.step(factored_sh=(rows, 1.0, raw["pws"], raw["low_shs"], raw["high_shs"]))
             train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
             train_extra["train_step_ms_fused_activations_fused_adam"] = round(
                 timed(lambda: train_step(opts["fused"], True), nf), 4)
-            train_extra["train_step_ms_fused_activations_fused_adam_factored_sh"] = round(
+            train_extra["train_step_ms_as_trainer_factored_sh"] = round(
                 timed(lambda: train_step_factored(opts["fused"]), nf), 4)
             for name, opt in opts.items():
                 train_extra["train_step_ms_torch_activations_%s_adam" % name] = round(

@@ -164,9 +164,8 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int gx, int gy, 
 }
 
 // loss_out = {loss, l1, ssim}; fixed summation order -> bit-reproducible
-__global__ __launch_bounds__(256) void k_loss_finalize(int nparts, const float* __restrict__ partials, float lambda,
-                                                       float inv_count, float* __restrict__ loss_out) {
-  __shared__ double red[2][4];
+__device__ __forceinline__ void loss_finalize(int nparts, const float* __restrict__ partials, float lambda,
+                                              float inv_count, float* __restrict__ loss_out, double (*red)[4]) {
   double a = 0.0, b = 0.0;
   for (int i = threadIdx.x; i < nparts; i += 256) { a += partials[2 * (size_t)i]; b += partials[2 * (size_t)i + 1]; }
 #pragma unroll
@@ -181,14 +180,24 @@ __global__ __launch_bounds__(256) void k_loss_finalize(int nparts, const float* 
     loss_out[2] = (float)ss;
   }
 }
+__global__ __launch_bounds__(256) void k_loss_finalize(int nparts, const float* __restrict__ partials, float lambda,
+                                                       float inv_count, float* __restrict__ loss_out) {
+  __shared__ double red[2][4];
+  loss_finalize(nparts, partials, lambda, inv_count, loss_out, red);
+}
 
 __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int gx, int gy, LossWin win,
                                                   const float* __restrict__ img, const float* __restrict__ gt,
                                                   const float* __restrict__ Pm, const float* __restrict__ P11,
                                                   const float* __restrict__ P12, float c_l1, float c_ssim,
-                                                  float* __restrict__ dimg) {
+                                                  float* __restrict__ dimg, int nparts,
+                                                  const float* __restrict__ partials, float lambda, float inv_count,
+                                                  float* __restrict__ loss_out) {
+  // loss_out != NULL: workgroup 0 also reduces the forward kernel's per-tile partials to {loss, l1, ssim} (what
+  // k_loss_finalize does as a launch of its own: 8 us of a training step for a few thousand additions)
   __shared__ float s[3][IH][IW + 1];
   __shared__ float h[3][IH][TW + 1];
+  __shared__ double fred[2][4];
   const int tid = threadIdx.x;
   const int ntiles = gx * gy * 3;
   float fa[NLOAD], fb[NLOAD], fd[NLOAD];  // halo tile of the three derivative maps in flight (see k_ssim_fwd)
@@ -206,6 +215,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int gx, int gy, 
   };
   int t = blockIdx.x;
   if (t < ntiles) fetch(t);
+  if (loss_out && blockIdx.x == 0) loss_finalize(nparts, partials, lambda, inv_count, loss_out, fred);
   for (; t < ntiles; t += gridDim.x) {
   const TileAt T = tile_at(t, gx, gy, H, W);
   const int x0 = T.x0, y0 = T.y0;
@@ -334,13 +344,14 @@ extern "C" int egs_gau_loss(int height, int width, const float* image, const flo
   EGS_LAUNCH("k_ssim_fwd", k_ssim_fwd, grid, dim3(256), s, height, width, gx, gy, win, image, gt_image, Pm, P11, P12,
              partials);
   const float inv_count = (float)(1.0 / (double)npix);
-  EGS_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), s, nb, partials, loss_lambda, inv_count,
-             loss_out);
-  if (dloss_dimage) {
+  if (dloss_dimage) {   // (the gradient kernel's first workgroup reduces the partials on its way)
     const float c_l1 = grad_scale * (1.f - loss_lambda) * inv_count;
     const float c_ssim = -grad_scale * loss_lambda * inv_count;
     EGS_LAUNCH("k_ssim_bwd", k_ssim_bwd, grid, dim3(256), s, height, width, gx, gy, win, image, gt_image, Pm, P11, P12,
-               c_l1, c_ssim, dloss_dimage);
+               c_l1, c_ssim, dloss_dimage, nb, partials, loss_lambda, inv_count, loss_out);
+  } else {
+    EGS_LAUNCH("k_loss_finalize", k_loss_finalize, dim3(1), dim3(256), s, nb, partials, loss_lambda, inv_count,
+               loss_out);
   }
   EGS_LAUNCH_OK();
   return 0;

@@ -858,6 +858,8 @@ __global__ __launch_bounds__(256) void k_preprocess_bwd(
   }
   if (factored) {   // (a kernel argument: the whole workgroup leaves here)
     if (i < n) st3(dL_dsh + 3 * (size_t)i, gcol_out);
+    // the view's camera centre behind the [N][3] block: the row format of egs_sh_grad_views (dL_dsh_high = its address)
+    if (dL_dsh_high && blockIdx.x == 0 && threadIdx.x < 3) dL_dsh_high[threadIdx.x] = twc[threadIdx.x];
     return;
   }
   if constexpr (RAW) {
@@ -1212,7 +1214,8 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   row_count, pp, pws + 3 * r0, rots + 4 * r0, scales + 3 * r0, shs + (RAW ? 3 : sh_dim) * r0,                      \
       (RAW && shs_high) ? shs_high + kh * r0 : shs_high, alphas + r0, Rcw, tcw, twc, depths + r0,                  \
       (const float4*)gpack + 3 * r0, dloss_dpws + 3 * r0, dloss_dshs + (factored ? 3 : (RAW ? 3 : sh_dim)) * r0,   \
-      (RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high, dloss_dalphas + r0,                  \
+      factored ? (row_begin == 0 ? dloss_dshs + 3 * (size_t)n : nullptr)                                           \
+               : ((RAW && dloss_dshs_high) ? dloss_dshs_high + kh * r0 : dloss_dshs_high), dloss_dalphas + r0,       \
       dloss_dscales + 3 * r0, dloss_drots + 4 * r0, dloss_dus + 2 * r0, dcolor_dpws ? dcolor_dpws + 9 * r0 : dcolor_dpws, \
       accum
 #define EGS_PREB(NC, RAW)                                                                                         \

@@ -299,8 +299,8 @@ class FactoredShGrad:
             self._next = 0
 
     def slot(self, n: int, sh_dim: int, cam, raw: bool) -> torch.Tensor:
-        """Called by ``fused.backward``: the [N,3] tensor this view's dL/dcolour goes to (its camera centre is
-        stored behind it on the current stream)."""
+        """Called by ``fused.backward``: the [N,3] tensor this view's dL/dcolour goes to (the first 3 n floats of a
+        row; the kernel writes the camera centre into the three floats behind them)."""
         with self._lock:
             v = self._next
             if v >= self.views:
@@ -317,9 +317,8 @@ class FactoredShGrad:
             if v > 0 and self.sh_dim != sh_dim:
                 raise RuntimeError("FactoredShGrad: views of one step with different SH widths")
             self.sh_dim = sh_dim
-        row = self.rows[v]
-        row[3 * n:3 * n + 3].copy_(cam.twc.reshape(3))
-        return row[:3 * n].view(n, 3)
+        # (the backward kernel stores the view's camera centre behind the 3 n floats itself: EGS_BWD_FACTORED_SH)
+        return self.rows[v][:3 * n].view(n, 3)
 
     def gathered(self):
         """-> (rows of every rank [world * views, stride], world).  Rows no backward pass filled count as zeros."""

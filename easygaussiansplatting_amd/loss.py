@@ -20,8 +20,10 @@ from . import _lib
 from .gsplatcu import _chk, _lib_on, _ptr, _stream
 
 
-def gau_loss_with_grad(image, gt_image, loss_lambda=0.2, need_grad=True):
-    """-> (stats[3] = {loss, l1, ssim} device tensor, dloss_dimage [3,H,W] or None)."""
+def gau_loss_with_grad(image, gt_image, loss_lambda=0.2, need_grad=True, grad_scale=1.0):
+    """-> (stats[3] = {loss, l1, ssim} device tensor, grad_scale * dloss_dimage [3,H,W] or None).
+    A training loop that knows the factor in front of the loss (1 / views) passes it here and calls
+    ``image.backward(grad)``: no autograd node for the loss, no ones-fill, no scaling pass over the image."""
     image = _chk(image, "image", torch.float32, (3, None, None))
     H, W = int(image.shape[1]), int(image.shape[2])
     gt_image = _chk(gt_image, "gt_image", torch.float32, (3, H, W))
@@ -31,8 +33,8 @@ def gau_loss_with_grad(image, gt_image, loss_lambda=0.2, need_grad=True):
     grad = torch.empty_like(image) if need_grad else None
     ws_bytes = lib.egs_gau_loss_ws_bytes(H, W)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    _lib.check(lib.egs_gau_loss(H, W, _ptr(image), _ptr(gt_image), float(loss_lambda), 1.0, _ptr(ws), ws_bytes,
-                                _ptr(stats), _ptr(grad), _stream()))
+    _lib.check(lib.egs_gau_loss(H, W, _ptr(image), _ptr(gt_image), float(loss_lambda), float(grad_scale), _ptr(ws),
+                                ws_bytes, _ptr(stats), _ptr(grad), _stream()))
     return stats, grad
 
 

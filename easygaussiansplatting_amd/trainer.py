@@ -34,7 +34,7 @@ from . import dist_views as DV
 from . import fused as _fused
 from .density import DensityControl, expon_lr
 from .function import Camera, GSFunction, GSRawFunction
-from .loss import gau_loss
+from .loss import gau_loss, gau_loss_with_grad
 from .optim import FusedAdam, adam_groups
 from .scene import gsdata_type
 
@@ -84,6 +84,7 @@ class Trainer:
         self._vs = None
         self.factored_sh = bool(factored_sh)     # see step(): the SH gradient of a step kept as dL/dcolour per view
         self._fx = None
+        self._us = {}
         # True: GSRawFunction (activations inside the HIP kernels); False: torch activations + GSFunction,
         # the reference's structure (gsmodel.py:198-210)
         self.fused_activations = fused_activations
@@ -103,6 +104,15 @@ class Trainer:
         self.redone_steps = 0        # steps rendered twice because a view outgrew the enqueue-ahead buffers
 
     _KEYS = ("pws", "low_shs", "high_shs", "alphas_raw", "scales_raw", "rots_raw")
+
+    def _us_leaf(self, lane, n):
+        """The zero ``us`` leaf of gsmodel.py:198-199, one per lane, kept across steps (only its ``.grad`` matters:
+        dL/du of the view just rendered); a fresh ``torch.zeros`` per view is a fill kernel per view."""
+        u = self._us.get(lane)
+        if u is None or u.shape[0] != n:
+            u = self._us[lane] = torch.zeros((n, 2), device=self.device, requires_grad=True)
+        u.grad = None
+        return u
 
     def _render_views(self, mine, n_views):
         """forward + loss + backward of this rank's views; leaves accumulate the mean over ALL views of the step.
@@ -127,15 +137,17 @@ class Trainer:
             k = i % lanes
             with (vs.lane(i) if vs is not None else contextlib.nullcontext(None)) as lv:
                 p = dict(zip(self._KEYS, lv)) if lv is not None else self.params
-                us = torch.zeros((n, 2), device=self.device, requires_grad=True)     # gsmodel.py:198-199
+                us = self._us_leaf(k, n)                                             # gsmodel.py:198-199
                 if self.fused_activations:
                     image, mask = GSRawFunction.apply(p["pws"], p["low_shs"], p["high_shs"], p["alphas_raw"],
                                                       p["scales_raw"], p["rots_raw"], us, self.cams[v])
                 else:
                     image, mask = GSFunction.apply(*activate(p), us, self.cams[v])
-                loss = gau_loss(image, self.gts[v])
-                (loss / n_views).backward()
-                loss_sum[k] += loss.detach()
+                # loss / n_views (train.py:52-57 with the mean over the step's views): the loss kernels produce the
+                # scaled dL/dimage themselves, backward starts at the image
+                stats, dimage = gau_loss_with_grad(image.detach(), self.gts[v], grad_scale=1.0 / n_views)
+                image.backward(dimage)
+                loss_sum[k] += stats[0]
                 with torch.no_grad():                       # per-view ||dL/du|| (undo the 1/len scaling)
                     g = torch.norm(us.grad * n_views, dim=-1)
                     gnorm[k] += torch.where(mask, g, torch.zeros_like(g))

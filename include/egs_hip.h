@@ -359,7 +359,8 @@ size_t egs_fused_backward_ws_bytes(int n);
  * (gsmodel.py:84-85: dL/dshs = dL/dcolors @ dcolor/dshs) is an outer product per Gaussian -- dL/dcolour[rgb] times the
  * SH basis of the direction from the camera centre -- so `dloss_dshs` (raw: `dloss_dlow_shs`) receives the THREE
  * floats dL/dcolour per Gaussian ([N][3]; always written, never accumulated; zero for a Gaussian this view did not
- * draw) and `dloss_dhigh_shs` is not touched (may be NULL).  The rows are formed once per step, for all views, by
+ * draw) FOLLOWED by the view's camera centre twc[3] -- 3 n + 3 floats, one row of egs_sh_grad_views' input -- and
+ * `dloss_dhigh_shs` is not touched (may be NULL).  The rows are formed once per step, for all views, by
  * egs_sh_grad_views.  A host that renders V views per step writes 12 instead of 4 sh_dim bytes per Gaussian and view;
  * a data-parallel host all-gathers 12 bytes per Gaussian and VIEW instead of all-reducing 4 sh_dim per Gaussian
  * (192 of the 236 bytes of SURVEY 8e's exchange at degree 3). */

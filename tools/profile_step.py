@@ -18,6 +18,7 @@ ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--mode", default="fused", choices=["fused", "ops"], help="GSFunction evaluation (ops = the seven-op surface)")
 ap.add_argument("--train", action="store_true", help="whole optimizer step: GSRawFunction + HIP loss + FusedAdam")
+ap.add_argument("--factored", action="store_true", help="--train: SH gradient factored, consumed by FusedAdam")
 a = ap.parse_args()
 
 import torch
@@ -44,12 +45,34 @@ if a.train:
     gt = torch.rand((3, a.height, a.width), device=dev)
 for _ in range(a.steps):
     if a.train:
+        # what Trainer.step does for one view: deferred validation, the SH gradient factored and consumed by FusedAdam
+        from easygaussiansplatting_amd import dist_views as DV, fused
+        if a.factored and "fx" not in globals():
+            fx = DV.FactoredShGrad(1)
+        import contextlib
         opt.zero_grad(set_to_none=True)
-        us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-        img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
-                                     raw["scales_raw"], raw["rots_raw"], us, cam)
-        gau_loss(img, gt).backward()
-        opt.step()
+        if a.factored:      # (Trainer._render_views: a persistent `us` leaf, the loss kernels hand over dL/dimage)
+            from easygaussiansplatting_amd.loss import gau_loss_with_grad
+            if "us_keep" not in globals():
+                us_keep = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+            us = us_keep
+            us.grad = None
+        else:
+            us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+        with fused.deferred() as d, (fx.attach() if a.factored else contextlib.nullcontext()):
+            img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                         raw["scales_raw"], raw["rots_raw"], us, cam)
+            if a.factored:
+                stats, dimg = gau_loss_with_grad(img.detach(), gt, grad_scale=1.0)
+                img.backward(dimg)
+            else:
+                gau_loss(img, gt).backward()
+            assert not d.commit()
+        if a.factored:
+            rows, _w = fx.take()
+            opt.step(factored_sh=(rows, 1.0, raw["pws"], raw["low_shs"], raw["high_shs"]))
+        else:
+            opt.step()
     elif a.fwd_only:
         with torch.no_grad():
             render(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], cam)
