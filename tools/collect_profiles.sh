@@ -28,6 +28,12 @@ rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $R/tools/profi
 python $R/tools/trace_timeline.py /tmp/tr > $O/step_timeline.txt
 rocprofv3 --kernel-trace --output-format csv -d /tmp/tro -- python $R/tools/profile_step.py --mode ops --steps 60 > /tmp/tro.log 2>&1
 python $R/tools/trace_timeline.py /tmp/tro > $O/ops_step_timeline.txt 2>&1
+# one optimizer step (GSRawFunction + HIP loss + FusedAdam) as a timeline: as Trainer.step runs it (SH gradient factored and
+# consumed by the optimizer, loss kernels hand over dL/dimage) and with the rows + the loss as an autograd node
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tt -- python $R/tools/profile_step.py --train --factored --steps 120 > /tmp/tt.log 2>&1
+python $R/tools/trace_timeline.py /tmp/tt > $O/train_step_timeline.txt 2>&1
+rocprofv3 --kernel-trace --output-format csv -d /tmp/tu -- python $R/tools/profile_step.py --train --steps 120 > /tmp/tu.log 2>&1
+python $R/tools/trace_timeline.py /tmp/tu > $O/train_step_timeline_rows.txt 2>&1
 # HBM traffic counters (separate passes, no tracing besides kernel-trace), fused step and seven-op step
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p1 -- python $R/tools/profile_step.py --steps 3 > /tmp/p1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p2 -- python $R/tools/profile_step.py --steps 3 > /tmp/p2.log 2>&1
