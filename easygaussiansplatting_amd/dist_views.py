@@ -21,6 +21,7 @@ from __future__ import annotations
 from typing import Dict, Iterable, List, Optional, Sequence
 
 import os
+import threading
 
 import torch
 import torch.distributed as dist
@@ -272,7 +273,6 @@ class FactoredShGrad:
         self.n = 0
         self.sh_dim = None
         self._next = 0
-        import threading
         self._lock = threading.Lock()     # backward runs on autograd's thread(s)
 
     @staticmethod
@@ -298,7 +298,7 @@ class FactoredShGrad:
         with self._lock:
             self._next = 0
 
-    def slot(self, n: int, sh_dim: int, cam, raw: bool) -> torch.Tensor:
+    def slot(self, n: int, sh_dim: int, cam) -> torch.Tensor:
         """Called by ``fused.backward``: the [N,3] tensor this view's dL/dcolour goes to (the first 3 n floats of a
         row; the kernel writes the camera centre into the three floats behind them)."""
         with self._lock:

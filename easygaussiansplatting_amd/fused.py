@@ -569,7 +569,7 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
         parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]
     if sh_sink is not None:
         dpws, dalphas, dscales, drots = parts
-        dshs, dhigh = sh_sink.slot(n, K, cam, raw), None     # [N,3]: dL/dcolour of this view (written, never added to)
+        dshs, dhigh = sh_sink.slot(n, K, cam), None     # [N,3]: dL/dcolour of this view (written, never added to)
     elif raw:
         dpws, dshs, dhigh, dalphas, dscales, drots = parts
     else:

@@ -170,7 +170,7 @@ def _worker_factored(rank, world, port, q):
 
         class Cam:
             twc = torch.from_numpy(np.asarray(cams[rank].twc, np.float32).reshape(3))
-        slot = fx.slot(n, sc.shs.shape[1], Cam, False)
+        slot = fx.slot(n, sc.shs.shape[1], Cam)
         assert slot.shape == (n, 3) and fx.rows.shape == (2, DV.FactoredShGrad.row_stride(n))
         slot.copy_(torch.from_numpy(grads["_dcolor"].astype(np.float32)))
         fx.rows[0, 3 * n:3 * n + 3] = Cam.twc          # (on the GPU the backward kernel stores it: EGS_BWD_FACTORED_SH)
