@@ -307,8 +307,8 @@ def main():
                     image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_v[vs_v.lane_index(i)], c)
                     image.backward(dl_v)
         vs_v.finish()
-        if fx_v is not None and not exchange:       # (with an exchange: finished there, it is a collective)
-            fx_v.finish(params["pws"], params["shs"])
+        if fx_v is not None and not (exchange and fx_v is fx):   # (the step's own sink under an exchange: finished
+            fx_v.finish(params["pws"], params["shs"])            # there, it is a collective)
         return image
 
     def render_step():
