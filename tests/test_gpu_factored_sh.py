@@ -234,3 +234,35 @@ def test_fused_adam_from_factored_rows_equals_rows_then_adam(raw, K):
                 assert torch.equal(oa.state[a][key], ob.state[b][key]), (step, key)
             assert oa.state[a]["step"] == ob.state[b]["step"] == step + 1
     assert float((A[0].detach() - tensors()[0].detach()).abs().max()) > 1e-4      # the parameters did move
+
+
+@pytest.mark.parametrize("views", [[0], [0, 1, 2]])
+def test_trainer_steps_agree_across_the_sh_gradient_forms(views):
+    """``Trainer.step`` three ways -- the SH rows written per view (``factored_sh=False``), the factored form expanded
+    into ``.grad`` for ``torch.optim.Adam`` (``FactoredShGrad.finish``), the factored form consumed by ``FusedAdam``
+    (``egs_adam_sh_factored``) -- takes the same three optimizer steps: losses, parameters and the densification
+    statistics agree to the order of the float sums."""
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer
+    sc = S.small_scene(12000, 192, 128, 48, seed=8)
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 3, radius=5.0)]
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, np.float32)).cuda()
+    with torch.no_grad():
+        gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+    outs = []
+    for fused_adam, factored in ((True, False), (False, True), (True, True)):
+        start = S.small_scene(12000, 192, 128, 48, seed=8)
+        start.shs[:, :3] += 0.4
+        tr = Trainer(start, cams, gts, max_steps=100, scene_size=4.0, fused_adam=fused_adam, factored_sh=factored)
+        losses = [tr.step(views) for _ in range(3)]
+        outs.append((losses, {k: v.detach().cpu().numpy() for k, v in tr.params.items()},
+                     tr.grad_accum.cpu().numpy(), tr.vis_count.cpu().numpy()))
+    for o in outs[1:]:
+        np.testing.assert_allclose(o[0], outs[0][0], rtol=2e-5)
+        assert (o[3] == outs[0][3]).all()
+        np.testing.assert_allclose(o[2], outs[0][2], rtol=2e-4, atol=1e-9)
+        for k in o[1]:
+            a, b = outs[0][1][k], o[1][k]
+            # three Adam steps of size lr (the update is normalised: a strict check of the gradient's direction)
+            assert np.abs(a - b).max() < 2e-4 * max(1e-3, np.abs(a).max()), k
