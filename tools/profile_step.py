@@ -19,6 +19,8 @@ ap.add_argument("--fwd-only", action="store_true")
 ap.add_argument("--mode", default="fused", choices=["fused", "ops"], help="GSFunction evaluation (ops = the seven-op surface)")
 ap.add_argument("--train", action="store_true", help="whole optimizer step: GSRawFunction + HIP loss + FusedAdam")
 ap.add_argument("--factored", action="store_true", help="--train: SH gradient factored, consumed by FusedAdam")
+ap.add_argument("--public-pair", action="store_true",
+                help="--mode ops: the plain splat / splatB pair an unmodified reference GSFunction calls (no records handle)")
 a = ap.parse_args()
 
 import torch
@@ -27,6 +29,8 @@ from easygaussiansplatting_amd.function import Camera, GSFunction, render
 
 dev = torch.device("cuda", 0)
 GSFunction.mode = a.mode
+if a.public_pair:
+    GSFunction.ops_use_records = False
 sc = S.big_scene(a.gaussians, a.width, a.height, 48)
 cam = Camera.from_scene(sc.cam, dev)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
