@@ -36,13 +36,32 @@ __device__ __forceinline__ bool tile_src(int i, int x0, int y0, int H, int W, in
   return yy >= 0 && yy < H && xx >= 0 && xx < W;
 }
 
-// Persistent workgroups: workgroup b takes tiles b, b + gridDim.x, ...; the halo tile of the NEXT tile is
+// Persistent workgroups: a workgroup takes every step-th tile of its share (tile_walk); the halo tile of the NEXT tile is
 // fetched into registers while the two window passes of the current one run, so the HBM latency is paid
 // once per workgroup instead of once per tile (3 workgroups per CU fit: 49 KB of LDS each).
 struct TileAt { int x0, y0; size_t plane; };
 __device__ __forceinline__ TileAt tile_at(int t, int gx, int gy, int H, int W) {
   const int bx = t % gx, by = (t / gx) % gy, ch = t / (gx * gy);
   return {bx * TW, by * TH, (size_t)ch * H * W};
+}
+
+// Which tiles a persistent workgroup takes.  Workgroup b runs on XCD b % 8 (observed dispatch order; speed only), and
+// every XCD has its own 4-MB L2: with tiles b, b + grid, ... the two tiles that share a halo column sit on different
+// XCDs and the ones that share halo rows too (30 tiles per row, 30 % 8 != 0), so every halo came from HBM -- FETCH_SIZE
+// read 155 MB for the forward kernel's 50 MB of pixels and 281 MB for the gradient kernel's 125 (rocprofv3 --pmc).
+// Here every XCD walks a contiguous eighth of the tile list (row-major over channel, tile row, tile column), its
+// resident workgroups side by side: the ~96 tiles in flight on an XCD span three tile rows (1.5 MB of halo tiles).
+#ifndef EGS_LOSS_XCD_BANDS
+#define EGS_LOSS_XCD_BANDS 1
+#endif
+struct TileWalk { int t, end, step; };
+__device__ __forceinline__ TileWalk tile_walk(int ntiles) {
+  const int b = blockIdx.x, G = gridDim.x;
+  if (!EGS_LOSS_XCD_BANDS || G < 16) return {b, ntiles, G};
+  const int xcd = b & 7, slot = b >> 3;
+  const int per = (G - xcd + 7) >> 3;                       // workgroups that run on this XCD
+  const int lo = (int)((long long)ntiles * xcd / 8), hi = (int)((long long)ntiles * (xcd + 1) / 8);
+  return {lo + slot, hi, per};
 }
 
 __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int gx, int gy, LossWin win,
@@ -66,9 +85,10 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int gx, int gy, 
       if (i < IH * IW && tile_src(i, T.x0, T.y0, H, W, r, c, off)) { fa[j] = img[T.plane + off]; fb[j] = gt[T.plane + off]; }
     }
   };
-  int t = blockIdx.x;
-  if (t < ntiles) fetch(t);
-  for (; t < ntiles; t += gridDim.x) {
+  const TileWalk tw = tile_walk(ntiles);
+  int t = tw.t;
+  if (t < tw.end) fetch(t);
+  for (; t < tw.end; t += tw.step) {
   const TileAt T = tile_at(t, gx, gy, H, W);
   const int x0 = T.x0, y0 = T.y0;
   const size_t plane = T.plane;
@@ -78,7 +98,7 @@ __global__ __launch_bounds__(256) void k_ssim_fwd(int H, int W, int gx, int gy, 
     if (i < IH * IW) { const int r = i / IW, c = i - r * IW; sx[r][c] = fa[j]; sy[r][c] = fb[j]; }
   }
   __syncthreads();
-  if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+  if (t + tw.step < tw.end) fetch(t + tw.step);
   if (tid < IH * HSEG) {  // horizontal 11-tap pass: HRUN outputs of row r from HRUN + 10 inputs
     const int r = tid % IH, c0 = (tid / IH) * HRUN;  // lanes of a wave walk down the rows: odd row stride, few bank conflicts
     float u[HRUN + LW - 1], v[HRUN + LW - 1];
@@ -213,10 +233,11 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int gx, int gy, 
       }
     }
   };
-  int t = blockIdx.x;
-  if (t < ntiles) fetch(t);
+  const TileWalk tw = tile_walk(ntiles);
+  int t = tw.t;
+  if (t < tw.end) fetch(t);
   if (loss_out && blockIdx.x == 0) loss_finalize(nparts, partials, lambda, inv_count, loss_out, fred);
-  for (; t < ntiles; t += gridDim.x) {
+  for (; t < tw.end; t += tw.step) {
   const TileAt T = tile_at(t, gx, gy, H, W);
   const int x0 = T.x0, y0 = T.y0;
   const size_t plane = T.plane;
@@ -235,7 +256,7 @@ __global__ __launch_bounds__(256) void k_ssim_bwd(int H, int W, int gx, int gy, 
     if (i < IH * IW) { const int r = i / IW, c = i - r * IW; s[0][r][c] = fa[j]; s[1][r][c] = fb[j]; s[2][r][c] = fd[j]; }
   }
   __syncthreads();
-  if (t + (int)gridDim.x < ntiles) fetch(t + gridDim.x);
+  if (t + tw.step < tw.end) fetch(t + tw.step);
   if (tid < IH * HSEG) {  // horizontal pass, HRUN outputs per thread (see k_ssim_fwd)
     const int r = tid % IH, c0 = (tid / IH) * HRUN;
     float acc[3][HRUN];

@@ -43,6 +43,10 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/q1 -- pyth
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/q2 -- python $R/tools/profile_step.py --mode ops --steps 3 > /tmp/q2.log 2>&1
 python $R/tools/pmc_summary.py $(dirname $(find /tmp/q1 -name "*counter_collection.csv" | head -1)) $(dirname $(find /tmp/q2 -name "*counter_collection.csv" | head -1)) --all > $O/ops_pmc_fetch_write.txt
 cp /tmp/pmc_summary.json $O/ops_pmc_fetch_write.json
+# ... and of one optimizer step as Trainer.step runs it (factored SH gradient consumed by FusedAdam)
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/r1 -- python $R/tools/profile_step.py --train --factored --steps 3 > /tmp/r1.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/r2 -- python $R/tools/profile_step.py --train --factored --steps 3 > /tmp/r2.log 2>&1
+python $R/tools/pmc_summary.py $(dirname $(find /tmp/r1 -name "*counter_collection.csv" | head -1)) $(dirname $(find /tmp/r2 -name "*counter_collection.csv" | head -1)) --all > $O/train_pmc_fetch_write.txt
 # SQ counters of the step
 C1="SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_INSTS_SALU GRBM_GUI_ACTIVE"
 C2="SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_INSTS_BRANCH SQ_WAVES SQ_INSTS_VALU_TRANS_F32 SQ_THREAD_CYCLES_VALU SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE"
