@@ -80,7 +80,10 @@ class FusedAdam:
                     raise ValueError("FusedAdam.step(factored_sh=...): an SH tensor already holds a .grad")
                 if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
                     raise ValueError("FusedAdam needs contiguous float32 device parameters")
-                lr = next(float(g["lr"]) for g in self.param_groups if any(q is t for q in g["params"]))
+                lrs = [float(g["lr"]) for g in self.param_groups if any(q is t for q in g["params"])]
+                if len(lrs) != 1:
+                    raise ValueError("FusedAdam.step(factored_sh=...): an SH tensor that is not in exactly one group")
+                lr = lrs[0]
                 st = self.state.get(t)
                 if st is None:
                     st = self.state[t] = {"step": 0, "exp_avg": torch.zeros_like(t), "exp_avg_sq": torch.zeros_like(t)}
