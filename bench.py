@@ -63,9 +63,10 @@ def kernel_source_hash():
     return h.hexdigest()[:16]
 
 
-def algorithmic_bytes(kernel, N, P, T, HW, K):
+def algorithmic_bytes(kernel, N, P, T, HW, K, factored_views=0):
     """Algorithmic HBM bytes of ONE launch of `kernel` (each input read once, each output written once;
-    atomics as read-modify-write)."""
+    atomics as read-modify-write).  ``factored_views`` > 0: the step keeps its SH
+    gradient factored over that many views (the chain-rule kernel writes dL/dcolour + twc instead of the SH rows)."""
     nc = K // 3
     table = {
         # per-Gaussian stages with Jacobians: inputs + outputs + Jacobians
@@ -97,7 +98,11 @@ def algorithmic_bytes(kernel, N, P, T, HW, K):
         # the forward kernel left dcolor/dpw); 59 gradient floats + du out        (= 372 N at K = 48)
         "k_preprocess_bwd": N * (40 + 4 + 48 + 36 + 4 * (3 + K + 1 + 3 + 4 + 2)),
         "k_unpack_grads": N * (48 + 36),
+        # the SH rows of a step from its factored form: pw 12 + 12 per view in, 4K out
+        "k_sh_grad_views": N * (12 + 12 * max(factored_views, 1) + 4 * K),
     }
+    if factored_views > 0:   # 12 B of dL/dcolour instead of the 4K-byte row
+        table["k_preprocess_bwd"] = N * (40 + 4 + 48 + 36 + 4 * (3 + 3 + 1 + 3 + 4 + 2))
     return table.get(kernel)
 
 
@@ -493,7 +498,7 @@ def main():
         fwd_ms = (time.perf_counter() - tf0) / nf * 1e3
     # per-kernel algorithmic rate of the headline step (each input read once, each output written once)
     for k, row in kernels.items():
-        ab = algorithmic_bytes(k, sc.n, P, T, HW, a.sh_dim)
+        ab = algorithmic_bytes(k, sc.n, P, T, HW, a.sh_dim, (world * V) if fx is not None else 0)
         if ab and row.get("avg_us"):
             row["algorithmic_GBs"] = round(ab / (row["avg_us"] * 1e-6) / 1e9, 1)
             row["frac_of_hbm_peak"] = round(ab / (row["avg_us"] * 1e-6) / 1e9 / HBM_PEAK_GBS, 3)
