@@ -156,6 +156,79 @@ def relaunch_command(gpus, env, argv):
             "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + list(argv)
 
 
+def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
+    """One extra leg of the default run, outside the timed region: the headline step (GSFunction fused, forward +
+    backward, deferred validation) on ANOTHER scene -- list statistics, ms per step, the per-kernel table of the two
+    draw kernels, and their time against the iid scene's scaled by the pixel-Gaussian pairs (every number
+    of four rounds came from one iid distribution with lists <= 830).  ``iid_ref``: {"pairs", "k_draw_us",
+    "k_draw_bwd_us"} of the headline scene."""
+    import ctypes
+    import torch
+    from easygaussiansplatting_amd import fused as fused_path, scene as S
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    cam = Camera.from_scene(sc.cam, dev)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    P = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1).clone(), scales=t(sc.scales),
+             rots=t(sc.rots))
+    for p in P.values():
+        p.requires_grad_(True)
+    us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+    W, H = sc.cam.width, sc.cam.height
+    dl = torch.from_numpy(S.normal(1, 77, (3, H, W)).astype(np.float32)).to(dev) / (3 * H * W)
+
+    def once():
+        for p in P.values():
+            p.grad = None
+        us0.grad = None
+        img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+        img.backward(dl)
+
+    def step():
+        with fused_path.deferred() as d:
+            once()
+            if d.commit():
+                once()
+    for _ in range(6):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    lib.egs_prof_set_filter(None); lib.egs_prof_reset(); lib.egs_prof_enable(1)
+    for _ in range(3):
+        step()
+    torch.cuda.synchronize()
+    lib.egs_prof_enable(0)
+    need = lib.egs_prof_report(None, 0)
+    buf = ctypes.create_string_buffer(need + 16)
+    lib.egs_prof_report(buf, need + 16)
+    rep = parse_report(buf.value.decode())
+    lib.egs_prof_reset()
+    kern = {k: round(tot / c * 1e3, 2) for k, (c, tot) in sorted(rep.items(), key=lambda kv: -kv[1][1])}
+    with torch.no_grad():
+        d = {k: v.detach() for k, v in P.items()}
+        _, _, st = fused_path.forward(d["pws"], d["shs"], d["alphas"], d["scales"], d["rots"], cam)
+        lens = (st.ranges[:, 1] - st.ranges[:, 0]).to(torch.int64)
+        walked = st.contrib.to(torch.int64)
+        out = {"scene": name, "gaussians": sc.n, "patches_drawn": int(st.patch_count()),
+               "max_list_len": int(lens.max().item()), "median_list_len": int(lens.median().item()),
+               "pixel_gaussian_pairs": int(lens.sum().item()) * 256,
+               # what the blend loops really walk: per pixel the index of its last contributor (early termination)
+               "walked_pairs": int(walked.sum().item()), "max_walked": int(walked.max().item()),
+               "ms_per_step": round(ms, 4), "Mpix/s": round(W * H / (ms * 1e-3) / 1e6, 2), "kernels_avg_us": kern}
+    if iid_ref:
+        r = out["pixel_gaussian_pairs"] / iid_ref["pairs"]
+        out["pairs_ratio_to_iid"] = round(r, 3)
+        for k in ("k_draw", "k_draw_bwd"):
+            if k in kern and iid_ref.get(k + "_us"):
+                out[k + "_over_pairs_scaled_iid"] = round(kern[k] / (r * iid_ref[k + "_us"]), 3)
+    del P, us0, dl
+    torch.cuda.empty_cache()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -191,6 +264,11 @@ def main():
     ap.add_argument("--no-prof", action="store_true", help="do not bracket kernels with HIP events")
     ap.add_argument("--no-ops", action="store_true", help="skip the extra seven-op (--mode ops) timing")
     ap.add_argument("--no-ring8", action="store_true", help="skip the extra eight-ring-views step (configs[3])")
+    ap.add_argument("--scene", default="iid", choices=["iid", "skewed", "skewed_reset"],
+                    help="the synthetic scene of the timed region: iid = BASELINE's (scene.big_scene, the headline); skewed = "
+                         "scene.skewed_scene (1.5 M heavy-tailed Gaussians, lists up to ~24 k); skewed_reset = the same "
+                         "right after reset_alpha (every opacity <= 0.01: nothing saturates)")
+    ap.add_argument("--no-skewed", action="store_true", help="skip the extra legs on the two skewed scenes")
     ap.add_argument("--extras", action="store_true",
                     help="also time render+loss+backward and the whole optimizer step (other dL/dimage, so their "
                          "kernel launches would blur a rocprofv3 summary of the headline step)")
@@ -253,7 +331,10 @@ def main():
                 return img, st.ranges, st.gsid
             out = render(d["pws"], d["shs"], d["alphas"], d["scales"], d["rots"], cam)
             return out[0], out[3], out[4]
-    sc = S.big_scene(a.gaussians, a.width, a.height, a.sh_dim)
+    if a.scene == "iid":
+        sc = S.big_scene(a.gaussians, a.width, a.height, a.sh_dim)
+    else:
+        sc = S.skewed_scene(width=a.width, height=a.height, sh_dim=a.sh_dim, reset_alpha=(a.scene == "skewed_reset"))
     V = max(1, a.views_per_rank)
     cams = S.ring_cameras(sc.cam, max(8, world * V))
     # rank r renders views r*V .. r*V+V-1 of the ring; view 0 = the BASELINE camera (one view per GPU at V = 1)
@@ -584,6 +665,18 @@ def main():
             p.grad = None
         torch.cuda.empty_cache()
 
+    # the same step on the heavy-tailed scenes (an extra, outside the timed region)
+    skewed = None
+    if (a.mode == "fused" and a.scene == "iid" and not a.no_skewed and rank == 0 and world == 1 and V == 1
+            and not a.immediate and prof):
+        ref = {"pairs": pairs, "k_draw_us": kernels.get("k_draw", {}).get("avg_us"),
+               "k_draw_bwd_us": kernels.get("k_draw_bwd", {}).get("avg_us")}
+        for p in params.values():
+            p.grad = None
+        torch.cuda.empty_cache()
+        skewed = [scene_leg(nm, S.skewed_scene(width=a.width, height=a.height, sh_dim=a.sh_dim, reset_alpha=rs), dev, lib,
+                            12, ref) for nm, rs in (("skewed", False), ("skewed_reset", True))]
+
     # achievable HBM bandwidth on THIS box: a device-to-device float4 copy ("confirm on the box
     # with a device-to-device copy kernel and report both")
     peak_measured = None
@@ -731,7 +824,8 @@ def main():
     if rank == 0:
         value = world * V * HW / (ms * 1e-3) / 1e6       # every rank renders V full frames per step
         line = {
-            "metric": "rendered Mpix/s fwd+bwd at 1920x1080, 1M Gaussians", "value": round(value, 2),
+            "metric": "rendered Mpix/s fwd+bwd at 1920x1080, 1M Gaussians" if a.scene == "iid" else
+                      "rendered Mpix/s fwd+bwd at %dx%d, scene.skewed_scene (%s)" % (a.width, a.height, a.scene), "value": round(value, 2),
             "unit": "Mpix/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
@@ -766,7 +860,7 @@ def main():
             "ops_ms_per_step": None if ops_ms is None else round(ops_ms, 4),
             "ops_public_pair_ms_per_step": None if ops_public_ms is None else round(ops_public_ms, 4),
             "ops_kernels": ops_kernels,
-            "ring_views_8": ring8,
+            "ring_views_8": ring8, "skewed_scenes": skewed,
             "fwd_loss_bwd": None if loss_step_ms is None else {
                 "ms": round(loss_step_ms, 4), "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
             "train_step": train_extra, "exchange": exch,

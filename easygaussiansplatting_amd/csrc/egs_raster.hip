@@ -795,7 +795,7 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
     uint32_t r = s0 - s_off[lo];
     const uint4 cc = s_cr[lo];
     const int x0 = (int)(cc.x & 0xFFFFu), y0 = (int)(cc.x >> 16);
-    const int w = (int)(cc.y & 0xFFFFu), h = (int)((cc.y & EGS_CR_WH_MASK) >> 16);
+    const int w = (int)(cc.y & 0xFFFFu);
     uint32_t tile = 0u, mask = 0xFu;
     if (cc.y & EGS_CR_TILEMAP) {                    // <= 8 x 8 tiles: the r-th set bit of the tile bitmap
       const unsigned long long tb = ((unsigned long long)cc.w << 32) | cc.z;
@@ -870,27 +870,59 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
         const int tx = x0 + (int)rx;
         if (tx >= tlo && tx <= thi) mask = foot_mask(sa, sb, tx);
       }
-    } else {                                        // big cullable rect: walk its rows
-      const BinRec b = br[s_g[lo]];
-      const Foot f = foot_setup(b);
-      mask = 0u;
-      for (int ry = 0; ry < h; ++ry) {
-        SlabPx sa, sb;
-        int tlo, thi;
-        foot_row(f, y0 + ry, sa, sb, tlo, thi);
-        const uint32_t wd = thi >= tlo ? (uint32_t)(thi - tlo + 1) : 0u;
-        if (r < wd) {
-          const int tx = tlo + (int)r;
-          tile = (uint32_t)(y0 + ry) * (uint32_t)gx + (uint32_t)tx;
-          mask = foot_mask(sa, sb, tx);
-          break;
-        }
-        r -= wd;
-      }
+    } else {                                        // big cullable rect: emitted row by row by its wave, below
+      continue;
     }
     if (first + s0 >= cap) break;   // (only when the buffers were sized from an earlier call: see egs_splat_draw_rec_dev)
     tkeys[first + s0] = tile;
     gsid[first + s0] = with_masks ? (s_g[lo] | (mask << EGS_GSID_BITS)) : s_g[lo];
+  }
+  // Big cullable rects (more than 8 x 8 tiles, footprint-culled): the tiles of a row are the interval foot_row names,
+  // so a slot can only find its tile by summing the row widths in front of it.  Done per SLOT (the first version: every
+  // slot walked the rows from the top) a screen-filling Gaussian costs rows x tiles footprint evaluations -- 68 x 7820
+  // at 1080p: k_bin_emit 17 -> 515 us on a scene with 160 of them (profiles/r5_skewed_baseline.json).  Now the WAVE
+  // that holds such a Gaussian emits it: lane r evaluates row r once (the two slabs, the interval), a wave scan
+  // gives the rows' offsets inside the run, and the rows are then written one after the other by all 64 lanes --
+  // rows + tiles / 64 steps, consecutive lanes on consecutive addresses.
+  {
+    const int lane = tid & 63, wbase = tid & ~63;
+    unsigned long long bigs = __ballot(j < n && (c.y & EGS_CR_BIG) && c.w == 1u && c.z != 0u);
+    while (bigs != 0ull) {
+      const int t = wbase + (int)__builtin_ctzll(bigs);
+      bigs &= bigs - 1ull;
+      const uint4 cc = s_cr[t];
+      const uint32_t gg = s_g[t];
+      const uint32_t obase = first + s_off[t];
+      const int y0 = (int)(cc.x >> 16), h = (int)((cc.y & EGS_CR_WH_MASK) >> 16);
+      const BinRec b = br[gg];
+      const Foot f = foot_setup(b);
+      uint32_t run = 0u;                           // tiles of the rows above
+      for (int rb = 0; rb < h; rb += 64) {
+        SlabPx sa, sb;
+        sa.pl = sb.pl = 0x7fffffff; sa.pr = sb.pr = (int)0x80000000;
+        int tlo = 1, thi = 0;
+        if (rb + lane < h) foot_row(f, y0 + rb + lane, sa, sb, tlo, thi);
+        const uint32_t wd = thi >= tlo ? (uint32_t)(thi - tlo + 1) : 0u;
+        const uint32_t inc = wave_inclusive_scan(wd);
+        const uint32_t ex = run + inc - wd;
+        const int rows = min(64, h - rb);
+        for (int q = 0; q < rows; ++q) {
+          const int qlo = __shfl(tlo, q, 64), qhi = __shfl(thi, q, 64);
+          const uint32_t qoff = (uint32_t)__shfl((int)ex, q, 64);
+          SlabPx qa, qb;
+          qa.pl = __shfl(sa.pl, q, 64); qa.pr = __shfl(sa.pr, q, 64);
+          qb.pl = __shfl(sb.pl, q, 64); qb.pr = __shfl(sb.pr, q, 64);
+          for (int tx = qlo + lane; tx <= qhi; tx += 64) {
+            const uint32_t o = obase + qoff + (uint32_t)(tx - qlo);
+            if (o < cap) {
+              tkeys[o] = (uint32_t)(y0 + rb + q) * (uint32_t)gx + (uint32_t)tx;
+              gsid[o] = with_masks ? (gg | (foot_mask(qa, qb, tx) << EGS_GSID_BITS)) : gg;
+            }
+          }
+        }
+        run += (uint32_t)__shfl((int)inc, 63, 64);
+      }
+    }
   }
 }
 

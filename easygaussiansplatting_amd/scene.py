@@ -119,6 +119,59 @@ def big_scene(n: int = 1_000_000, width: int = 1920, height: int = 1080, sh_dim:
     return _make(seed, n, sh_dim, [(-4, 4), (-2.25, 2.25), (-2, 2)], 0.003, 0.03, 0.05, 0.99, 0.3, cam)
 
 
+def skewed_scene(n: int = 1_500_000, width: int = 1920, height: int = 1080, sh_dim: int = 48, seed: int = 7,
+                 reset_alpha: bool = False, fillers: int = 160) -> Scene:
+    """A heavy-tailed scene of the shape a trained model has (BASELINE configs[4] is real data, absent here): what
+    ``big_scene`` -- iid positions, every Gaussian <= ~4x4 tiles, lists 114..830 -- does not exercise.
+
+    * positions: 62 % of the Gaussians in eight depth-clustered blobs (sigma 0.12 .. 1.2 world units, depths 4.3 .. 8:
+      the densest puts > 10 k entries on its centre tiles and thousands of equal mm depth keys), the rest iid in
+      ``big_scene``'s box;
+    * scales: log-normal about 0.008 (sigma 0.85) with per-axis anisotropy 1/3 .. 3, clipped to [0.0015, 0.6]; on top,
+      ``fillers`` Gaussians with scales 0.35 .. 1.6 -- 3-sigma rects of 30 x 30 tiles up to the whole screen (the
+      row-walk paths of the binning, thousands of tiles per Gaussian);
+    * opacity bimodal: half U(0.55, 0.99), half U(0.004, 0.12) (some below alpha_skip = 0.002 / 0.99 never blend);
+      ``reset_alpha``: every opacity min(alpha, 0.01), the state right after the reference's ``reset_alpha``
+      (gsmodel.py:320-324, train.py:77): nothing saturates, every tile walks its whole list.
+    Same camera as ``big_scene``; every Gaussian in front of it (depth > 3.4)."""
+    cam = Camera(width, height, 1200.0, 1200.0, width / 2.0, height / 2.0,
+                 np.eye(3), np.array([0.0, 0.0, 6.0]))
+    u = uniform01(seed, 1, (n, 3))
+    box = np.array([[-4, 4], [-2.25, 2.25], [-2, 2]], np.float64)
+    pws = box[:, 0] + u * (box[:, 1] - box[:, 0])
+    # blobs: centre (x, y, z), sigma (x == y, z), share of the Gaussians
+    blobs = [((-2.6, -1.2, -1.6), 0.12, 0.05, 0.07), ((1.9, 0.9, -1.0), 0.16, 0.08, 0.09),
+             ((0.2, -0.3, 0.0), 0.30, 0.10, 0.10), ((-1.2, 1.3, 0.8), 0.22, 0.05, 0.07),
+             ((2.9, -1.4, 1.4), 0.45, 0.20, 0.08), ((-3.0, 0.6, 1.9), 0.60, 0.15, 0.07),
+             ((0.9, 1.5, -1.7), 0.15, 0.04, 0.06), ((0.0, 0.0, 1.0), 1.20, 0.30, 0.08)]
+    pick = uniform01(seed, 6, (n,))
+    g3 = normal(seed, 7, (n, 3))
+    lo = 0.0
+    for (cx_, cy_, cz_), sxy, sz, share in blobs:
+        m = (pick >= lo) & (pick < lo + share)
+        pws[m] = np.array([cx_, cy_, cz_]) + g3[m] * np.array([sxy, sxy, sz])
+        lo += share
+    pws[:, 2] = np.maximum(pws[:, 2], -2.6)            # depth = z + 6 > 3.4
+    q = normal(seed, 2, (n, 4))
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    base = np.exp(np.log(0.008) + 0.85 * normal(seed, 8, (n, 1)))
+    aniso = np.exp((uniform01(seed, 3, (n, 3)) * 2.0 - 1.0) * np.log(3.0))
+    s = np.clip(base * aniso, 0.0015, 0.6)
+    if fillers > 0:                                    # every (n // fillers)-th Gaussian fills (a part of) the screen
+        idx = (np.arange(fillers) * (n // fillers) + n // (2 * fillers)) % n
+        fs = np.exp(np.log(0.35) + uniform01(seed, 9, (fillers, 1)) * (np.log(1.6) - np.log(0.35)))
+        s[idx] = fs * aniso[idx] ** 0.5
+        pws[idx, 2] = 0.5 + 1.5 * uniform01(seed, 10, (fillers,))
+    ua = uniform01(seed, 4, (n,))
+    strong = uniform01(seed, 11, (n,)) < 0.5
+    a = np.where(strong, 0.55 + ua * 0.44, 0.004 + ua * 0.116)
+    if reset_alpha:
+        a = np.minimum(a, 0.01)
+    sh = 0.3 * normal(seed, 5, (n, sh_dim))
+    f = np.float32
+    return Scene(pws.astype(f), q.astype(f), s.astype(f), a.astype(f), sh.astype(f), cam)
+
+
 def small_scene(n: int = 10_000, width: int = 256, height: int = 256, sh_dim: int = 3,
                 seed: int = 0) -> Scene:
     """BASELINE configs[0]: 10 k Gaussians, 256x256, SH degree 0."""
