@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegs_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 
 class EgsPolicy(C.Structure):
@@ -84,7 +84,13 @@ SIGNATURES = {
     "egs_fused_forward_raw": (_i, [_i, _i] + [_P] * 9 + [_f] * 4 + [_i, _i, _PP] + [_P] * 8
                               + [_i, _i, _P, _sz, _P, _P, _P]),
     "egs_fused_backward_raw": (_i, [_i, _i, _i64, _i, _i] + [_P] * 9 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
-                               + [_P] * 7 + [_P, _P, _P, _i, _i, _i, _P]),
+                               + [_P] * 7 + [_P, _P, _P, _i, _i, _i, _P, _sz, _P]),
+    "egs_seg_ws_bytes": (_sz, [_i64, _i, _i]),
+    "egs_seg_config": (_i, [_i, _i, C.POINTER(C.c_int)]),
+    "egs_splat_draw_rec_seg": (_i, [_i, _i64, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P,
+                                    _i, _i, _P, _sz, _P, _P]),
+    "egs_mailbox_peek": (_i, [_P, _i, C.POINTER(C.c_uint32)]),
+    "egs_mailbox_clear": (_i, [_P, _i]),
     "egs_sh_grad_views": (_i, [_i, _i, _i, _P, _P, _i64, _f, _P, _P, _i, _P]),
     "egs_tile_order_len": (_sz, [_i, _i]),
     "egs_splat_draw_rec": (_i, [_i, _i64, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P, _i, _i, _P]),
@@ -99,7 +105,7 @@ SIGNATURES = {
     "egs_mailbox_fetch": (_i, [_P, _i, _i, C.POINTER(C.c_uint32)]),
     "egs_fused_backward_ws_bytes": (_sz, [_i]),
     "egs_fused_backward": (_i, [_i, _i, _i64, _i, _i] + [_P] * 8 + [_f] * 4 + [_PP] + [_P] * 11 + [_P, _sz]
-                           + [_P] * 6 + [_P, _P, _P, _i, _i, _i, _P]),
+                           + [_P] * 6 + [_P, _P, _P, _i, _i, _i, _P, _sz, _P]),
     "egs_gau_loss_ws_bytes": (_sz, [_i, _i]),
     "egs_gau_loss": (_i, [_i, _i, _P, _P, _f, _f, _P, _sz, _P, _P, _P]),
     "egs_density_accumulate": (_i, [_i, _P, _P, _i, _P, _P, _P]),

@@ -262,6 +262,23 @@ extern "C" int egs_mailbox_fetch(void* mb, int slot, int blocking, uint32_t* out
   return 1;
 }
 
+extern "C" int egs_mailbox_peek(void* mb, int slot, uint32_t* out4) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots && out4);
+  const volatile uint32_t* h = m->host + 4 * (size_t)slot;
+  for (int i = 0; i < 4; ++i) out4[i] = h[i];
+  return 0;
+}
+
+extern "C" int egs_mailbox_clear(void* mb, int slot) {
+  egs::Mailbox* m = (egs::Mailbox*)mb;
+  EGS_CHECK_ARG(m && slot >= 0 && slot < m->slots);
+  volatile uint32_t* h = m->host + 4 * (size_t)slot;
+  for (int i = 0; i < 4; ++i) h[i] = egs::MAILBOX_EMPTY;
+  __sync_synchronize();
+  return 0;
+}
+
 extern "C" const char* egs_last_error_string(void) { return egs::g_err; }
 extern "C" int egs_abi_version(void) { return EGS_ABI_VERSION; }
 

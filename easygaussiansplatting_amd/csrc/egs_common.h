@@ -151,7 +151,9 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* tile_order /* dispatch order left by the forward pass, or NULL */,
                      float* grad_records /* [N][12] records ALREADY ZEROED (by the forward draw kernel), or NULL */,
                      bool keep_forward_order = false /* dispatch the tiles exactly as tile_order says */,
-                     bool masked_lists = false /* gsid_per_patch carries block masks (culled lists, fused path) */);
+                     bool masked_lists = false /* gsid_per_patch carries block masks (culled lists, fused path) */,
+                     void* seg_ws = nullptr /* the segment workspace the forward draw filled (egs_splat_draw_rec_seg) */,
+                     size_t seg_ws_bytes = 0);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

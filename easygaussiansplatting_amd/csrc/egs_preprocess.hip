@@ -1171,7 +1171,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
                                float* dloss_dshs, float* dloss_dshs_high, float* dloss_dalphas, float* dloss_dscales,
                                float* dloss_drots, float* dloss_dus, const int32_t* tile_order,
                                float* grad_records, const float* dcolor_dpws, int phase, int row_begin, int row_count,
-                               void* stream) {
+                               void* seg_ws, size_t seg_ws_bytes, void* stream) {
   // phase 0: everything; 1: only the draw pass (-> packed gradient records in ws); 2: only the per-Gaussian
   // chain rule, for rows [row_begin, row_begin + row_count) -- a data-parallel caller launches the rows in a
   // few chunks and starts exchanging a chunk's gradients while the next one is computed (dist_views)
@@ -1199,7 +1199,7 @@ static int fused_backward_impl(bool raw, int n, int sh_dim, int64_t patches, int
   if (phase != 2) {
     int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, areas, pol, contrib, final_tau,
                               patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec,
-                              tile_order, grad_records, keep_order, masked);
+                              tile_order, grad_records, keep_order, masked, seg_ws, seg_ws_bytes);
     if (rc) return rc;
     if (phase == 1) return 0;
   }
@@ -1250,12 +1250,12 @@ extern "C" int egs_fused_backward(int n, int sh_dim, int64_t patches, int width,
                                   float* dloss_dshs, float* dloss_dalphas, float* dloss_dscales,
                                   float* dloss_drots, float* dloss_dus, const int32_t* tile_order,
                                   float* grad_records, const float* dcolor_dpws, int phase, int row_begin,
-                                  int row_count, void* stream) {
+                                  int row_count, void* seg_ws, size_t seg_ws_bytes, void* stream) {
   return fused_backward_impl(false, n, sh_dim, patches, width, height, pws, rots, scales, shs, nullptr, alphas, Rcw,
                              tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths, contrib,
                              final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, dloss_dpws,
                              dloss_dshs, nullptr, dloss_dalphas, dloss_dscales, dloss_drots, dloss_dus, tile_order,
-                             grad_records, dcolor_dpws, phase, row_begin, row_count, stream);
+                             grad_records, dcolor_dpws, phase, row_begin, row_count, seg_ws, seg_ws_bytes, stream);
 }
 
 extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int height, const float* pws,
@@ -1270,13 +1270,14 @@ extern "C" int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int wi
                                       float* dloss_dlow_shs, float* dloss_dhigh_shs, float* dloss_dalphas_raw,
                                       float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
                                       const int32_t* tile_order, float* grad_records, const float* dcolor_dpws,
-                                      int phase, int row_begin, int row_count, void* stream) {
+                                      int phase, int row_begin, int row_count, void* seg_ws, size_t seg_ws_bytes,
+                                      void* stream) {
   return fused_backward_impl(true, n, sh_dim, patches, width, height, pws, rots_raw, scales_raw, low_shs, high_shs,
                              alphas_raw, Rcw, tcw, twc, fx, fy, cx, cy, pol, us, cinv2ds, colors, areas, rec, depths,
                              contrib, final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes,
                              dloss_dpws, dloss_dlow_shs, dloss_dhigh_shs, dloss_dalphas_raw, dloss_dscales_raw,
                              dloss_drots_raw, dloss_dus, tile_order, grad_records, dcolor_dpws, phase, row_begin,
-                             row_count, stream);
+                             row_count, seg_ws, seg_ws_bytes, stream);
 }
 
 extern "C" int egs_sh_grad_views(int n, int sh_dim, int views, const float* pws, const float* rows,

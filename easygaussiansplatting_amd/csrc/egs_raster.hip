@@ -23,6 +23,8 @@
 
 #include <stdlib.h>
 
+#include <algorithm>
+
 // default dispatch order of the tiles for the forward / backward draw kernel (k_tile_order modes)
 #ifndef EGS_TILE_ORDER_F_DEFAULT
 #define EGS_TILE_ORDER_F_DEFAULT 1
@@ -1549,6 +1551,623 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
 }
 
 // ============================================================================
+// long lists: a tile's list split over several waves                 
+// ============================================================================
+// k_draw / k_draw_bwd spend ONE wave64 on a tile, and a lone wave walks about five entries per microsecond forward, 2.5
+// backward: both kernels end when the longest walk ends.  On the iid scene (lists <= 830) that is the throughput time;
+// on a heavy-tailed scene right after reset_alpha (every opacity 0.01: nothing saturates, scene.skewed_scene) one tile
+// walks 8 325 entries and the two kernels take 1.6 + 3.4 ms for 0.25 + 0.65 ms of work (profiles/r5_skewed_baseline.json).
+// The reference spends 256 threads on a tile (kernel.cu:152-271, launched (16, 16) at gausplat.cu:94) -- one pixel per
+// thread, every thread walks the whole list: that splits the PIXELS, which buys at most 2.5x here (the block masks
+// already skip the blocks an entry cannot reach).  This splits the LIST, in segments of L entries (L a multiple of the
+// 64-entry chunk), which scales with the list:
+//
+//   front-to-back blending is associative on (colour, tau) pairs:  (C1, t1) o (C2, t2) = (C1 + t1 C2, t1 t2),
+//
+// so a segment can be blended from tau = 1 ("local frame") by its own wave and composed afterwards.  What is NOT
+// associative is the early stop (a pixel is finished once tau < tau_stop, kernel.cu:256-260): it depends on the
+// transmittance in front of the segment.  A segment wave therefore stops a pixel only when its LOCAL tau falls below
+// tau_stop (the true tau is smaller still: conservative), and the composing wave -- which knows the true transmittance
+// T in front of every segment -- re-walks a segment for exactly the pixels that finish inside it (T tau_local <
+// tau_stop), with the per-pixel threshold tau_stop / T in the local frame.  Every pixel finishes once, so this costs at
+// most one extra segment walk per segment that holds a finishing pixel, restricted to the 8x8 blocks of those pixels.
+//
+// Work items (one wave64 each; k_seg_plan writes them longest first):
+//   DIRECT(tile)          a tile of at most `split_min` entries: exactly k_draw
+//   SPEC(tile, s)         segment s of a split tile, blended from tau = 1 into the tile's state slot s
+//   COMPOSE(tile, nspec)  composes the tile's first nspec segments (re-walking where a pixel finishes), CONTINUES
+//                         sequentially from there while a pixel is still alive -- segment by segment in the local
+//                         frame, each leaving its state -- and writes the tile's pixels; then turns the slots into what
+//                         the BACKWARD pass needs at the end of each segment: the transmittance there and the colour
+//                         of everything behind it, G_s = C_(s+1) + tau_(s+1) G_(s+1) (no cancellation, no division).
+// With those, the backward pass has no sequential dependence left at all: k_draw_bwd<SEG> walks segment s of a tile
+// from (T_s, dL/dgamma . G_s) exactly as the unsplit kernel walks a tile from (final_tau, 0), one wave per segment.
+// SPEC items need a prediction of how far the tile will be walked -- the walk length this camera's previous render
+// measured (a trainer meets every view again; without one the COMPOSE item does the whole tile, exactly, and only the
+// backward pass is split).  Nothing depends on the prediction but the balance.
+constexpr int SEG_HDR = 16;          // header words: see SegLayout
+constexpr int SEG_SLOT_FLOATS = 256 * 6;
+constexpr uint32_t SEG_TILE_MASK = 0x7FFFFu, SEG_SEG_MASK = 0x7FFu;   // item = tile | seg << 19 | kind << 30
+constexpr int SEG_SPEC = 1, SEG_COMPOSE = 2;   // (0: a DIRECT item, the bare tile index)
+enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_ITEMSB = 5, SH_L = 6, SH_MIN = 7 };
+struct SegArgs {
+  int32_t* hdr;        // SEG_HDR words
+  int32_t* seg_base;   // [T] first state slot of a split tile, -1: not split
+  int32_t* walk;       // [T] how far the forward pass walked the tile (largest contributor index): the backward plan
+  int32_t* items1;     // forward, launches 0 and 1: DIRECT / SPEC
+  int32_t* items3;     // forward, launch 2: COMPOSE(nspec), one per split tile
+  int32_t* itemsB;     // backward: DIRECT / SPEC
+  int32_t* tmp;        // [T] plan scratch: (bin, rank inside the bin) of the tile's items
+  int32_t* tmp2;       // [T] plan scratch: the tile's item count (-1: one DIRECT item)
+  float4* st4;         // [slot][256] (C_local.rgb, tau_local) -> after COMPOSE (G.rgb, T_end)
+  float* st1;          // [slot][256] last contributor (int bits) -> T_end
+  float* st2;          // [slot][256] transmittance in FRONT of the segment (launch 3: the running product of the taus)
+  int slot_cap, item_cap;
+  int32_t* hist_walk;  // nullable: the camera's own walk array (the NEXT render's prediction)
+};
+static int g_seg_L = 256, g_seg_min = 1024;
+static void seg_config_env() {
+  static const bool once = [] {
+    const char* a = getenv("EGS_SEG_L");
+    const char* b = getenv("EGS_SEG_MIN");
+    if (a && atoi(a) >= 64) { g_seg_L = 64; while (2 * g_seg_L <= atoi(a) && g_seg_L < 65536) g_seg_L *= 2; }
+    if (b && atoi(b) > 0) g_seg_min = atoi(b);
+    if (g_seg_min < g_seg_L) g_seg_min = g_seg_L;
+    return true;
+  }();
+  (void)once;
+}
+static size_t seg_fixed_words(int T) { return (size_t)SEG_HDR + 48 + 5 * (size_t)align_up((size_t)T, 64); }
+static size_t seg_ws_bytes_for(int64_t slots, int T) {
+  return 4 * (seg_fixed_words(T) + 2 * ((size_t)T + (size_t)slots + 64)) + (size_t)slots * SEG_SLOT_FLOATS * 4 + 1024;
+}
+static bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
+  if (!ws || bytes < seg_ws_bytes_for(16, T)) return false;
+  const size_t per_slot = SEG_SLOT_FLOATS * 4 + 8;
+  const int64_t slots = (int64_t)((bytes - seg_ws_bytes_for(0, T)) / per_slot);
+  if (slots < 16) return false;
+  const size_t Tp = align_up((size_t)T, 64);
+  int32_t* w = (int32_t*)ws;
+  a->hdr = w; w += SEG_HDR + 48;
+  a->seg_base = w; w += Tp;
+  a->walk = w; w += Tp;
+  a->items3 = w; w += Tp;
+  a->tmp = w; w += Tp;
+  a->tmp2 = w; w += Tp;
+  a->item_cap = (int)std::min<int64_t>((int64_t)T + slots, (int64_t)1 << 20);
+  a->slot_cap = (int)std::min<int64_t>(slots, (int64_t)a->item_cap - T);
+  a->items1 = w; w += (size_t)T + (size_t)slots + 64;
+  a->itemsB = w; w += (size_t)T + (size_t)slots + 64;
+  a->st4 = (float4*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
+  a->st1 = (float*)(a->st4 + (size_t)a->slot_cap * 256);
+  a->st2 = a->st1 + (size_t)a->slot_cap * 256;
+  a->hist_walk = nullptr;
+  return (char*)(a->st2 + (size_t)a->slot_cap * 256) <= (char*)ws + bytes;
+}
+
+// One workgroup plans a launch: which tiles are split (forward only: state slots are handed out here), the work items,
+// longest first (counting sort on the estimated walk, as k_tile_order), and the list statistics the host steers by.
+//   backward == 0:  ranges (+ hist: the walks this camera's previous render measured) -> seg_base, items1, items3, hdr
+//   backward == 1:  seg_base + walk (this render's) -> itemsB
+// Segment 0 of a split tile is ALWAYS a SPEC item: it starts from tau = 1 like the unsplit walk, so it is exact and
+// never wasted; further SPEC items follow the prediction (walk + a quarter), the COMPOSE item walks on where they end.
+constexpr int SP_REGS = 8;     // tiles per thread and round whose inputs are requested together (the kernel is a chain
+                               // of latencies: 8160 tiles are ONE round of 1024 x 8)
+// (L is a power of two: a segment index is a shift -- an integer division is ~40 instructions on this part, and the plan
+// kernel's first version spent 26 of its 37 us dividing)
+__device__ __forceinline__ int seg_nspec(const int32_t* __restrict__ hist, int h, int n, int nseg, int L, int Ls) {
+  if (!hist) return 1;
+  const int w = min(max(h, 0), n);
+  return max(1, min(nseg, (w + (w >> 2) + L) >> Ls));
+}
+__global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restrict__ ranges,
+                                                   const int32_t* __restrict__ hist, int L, int split_min, SegArgs a,
+                                                   int backward, uint32_t* __restrict__ hint_host) {
+  constexpr int NB = 4096;
+  __shared__ uint32_t bins[NB];
+  __shared__ uint32_t wsum[16];
+  __shared__ int s_slots, s_n3, s_max;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
+  if (tid == 0) { s_slots = 0; s_n3 = 0; s_max = 0; }
+  if (backward) { L = a.hdr[SH_L]; split_min = a.hdr[SH_MIN]; }
+  const int Ls = 31 - __clz(L);
+  __syncthreads();
+  auto bin_of = [&](int est) { return NB - 1 - min(max(est, 0) >> 3, NB - 1); };
+  // the SPEC items of all split tiles are equal work: spread them over a few bins (they would all meet in one)
+  auto jitter = [&](int t) { return (int)(((uint32_t)t * 2654435761u) >> 25) - 64; };
+  // pass 1: per tile its item count and estimated walk -> (bin, rank inside the bin) parked in tmp[]
+  // (what every tile adds to ONE counter -- slots, compose items, the maxima -- is combined inside the wave first: 8160
+  // same-address LDS atomics are 8160 serial steps, 50 us of this kernel's first version)
+  for (int t0 = 0; t0 < T; t0 += 1024 * SP_REGS) {
+    int2 rr[SP_REGS];
+    int hh[SP_REGS], bb[SP_REGS];
+#pragma unroll
+    for (int q = 0; q < SP_REGS; ++q) {
+      const int t = min(t0 + q * 1024 + tid, T - 1);
+      rr[q] = reinterpret_cast<const int2*>(ranges)[t];
+      hh[q] = backward ? a.walk[t] : (hist ? hist[t] : 0);
+      bb[q] = backward ? a.seg_base[t] : -1;
+    }
+    if (!backward) {
+      // state slots and compose-item positions of the round's split tiles: ONE wave scan each over the threads' totals
+      // (cross-lane operations go through the LDS crossbar on this part: a scan per tile was 20 us of the kernel)
+      uint32_t want = 0u, nsp = 0u;
+      int mx = 0;
+#pragma unroll
+      for (int q = 0; q < SP_REGS; ++q) {
+        const int t = t0 + q * 1024 + tid, n = max(rr[q].y - rr[q].x, 0), nseg = (n + L - 1) >> Ls;
+        const bool split = t < T && n > split_min && nseg <= (int)SEG_SEG_MASK;
+        if (split) { want += (uint32_t)nseg; nsp += 1u; }
+        if (t < T) mx = max(mx, n);
+      }
+      const uint32_t both = (want << 10) | nsp;                // (at most 512 split tiles per wave and round; < 2^22 slots)
+      const uint32_t inc = wave_inclusive_scan(both);
+      uint32_t wb = 0u, w3 = 0u;
+      if (lane == 63 && inc) { wb = (uint32_t)atomicAdd(&s_slots, (int)(inc >> 10)); w3 = (uint32_t)atomicAdd(&s_n3, (int)(inc & 1023u)); }
+      wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+      w3 = (uint32_t)__builtin_amdgcn_readlane((int)w3, 63);
+      uint32_t sb = wb + ((inc - both) >> 10), s3 = w3 + ((inc - both) & 1023u);
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+      if (lane == 0) atomicMax(&s_max, mx);
+#pragma unroll
+      for (int q = 0; q < SP_REGS; ++q) {
+        const int t = t0 + q * 1024 + tid, n = max(rr[q].y - rr[q].x, 0), nseg = (n + L - 1) >> Ls;
+        const bool split = t < T && n > split_min && nseg <= (int)SEG_SEG_MASK;
+        bb[q] = -1;
+        if (split) {
+          // (a workspace of egs_seg_ws_bytes cannot run out of slots; if a caller's does, the tile stays unsplit)
+          if ((int)sb + nseg <= a.slot_cap) {
+            bb[q] = (int)sb;
+            a.items3[s3] = (int32_t)((uint32_t)t | ((uint32_t)seg_nspec(hist, hh[q], n, nseg, L, Ls) << 19) |
+                                     ((uint32_t)SEG_COMPOSE << 30));
+          } else {
+            a.items3[s3] = t;      // (no COMPOSE kind: the per-tile launches skip it)
+          }
+          s3 += 1u;
+          sb += (uint32_t)nseg;
+        }
+        if (t < T) a.seg_base[t] = bb[q];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < SP_REGS; ++q) {
+      const int t = t0 + q * 1024 + tid;
+      const bool valid = t < T;
+      const int n = max(rr[q].y - rr[q].x, 0);
+      int cnt = valid ? 1 : 0, est = n;
+      if (!backward) {
+        if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls); est = L + jitter(t); }
+        else if (hist) est = min(max(hh[q], 0), n);
+      } else if (valid) {
+        const int w = min(max(hh[q], 0), n);
+        est = w;
+        if (bb[q] >= 0) { cnt = (w + L - 1) >> Ls; est = min(w, L) + jitter(t); }
+      }
+      uint32_t packed = 0xFFFFFFFFu;
+      if (cnt > 0) {
+        const int b = bin_of(est);
+        packed = ((uint32_t)b << 20) | atomicAdd(&bins[b], (uint32_t)cnt);
+      }
+      if (valid) { a.tmp[t] = (int32_t)packed; a.tmp2[t] = bb[q] >= 0 ? cnt : -1; }
+    }
+  }
+  __syncthreads();
+  {  // exclusive scan of the bins: thread t owns bins [4 t, 4 t + 4)
+    uint32_t v[4], sum = 0u;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { v[k] = bins[4 * tid + k]; sum += v[k]; }
+    const uint32_t inc = wave_inclusive_scan(sum);
+    if ((tid & 63) == 63) wsum[tid >> 6] = inc;
+    __syncthreads();
+    uint32_t pre = 0u;
+    for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
+    uint32_t ex = pre + inc - sum;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { bins[4 * tid + k] = ex; ex += v[k]; }
+    __syncthreads();
+    if (tid == 1023) wsum[0] = ex;    // total number of items
+  }
+  __syncthreads();
+  const int total = (int)wsum[0];
+  int32_t* __restrict__ items = backward ? a.itemsB : a.items1;
+  // pass 2: a tile's items go to [start of its bin + its rank, + count)
+  for (int t0 = 0; t0 < T; t0 += 1024 * SP_REGS) {
+    uint32_t pp[SP_REGS];
+    int cc[SP_REGS];
+#pragma unroll
+    for (int q = 0; q < SP_REGS; ++q) {
+      const int t = min(t0 + q * 1024 + tid, T - 1);
+      pp[q] = (uint32_t)a.tmp[t];
+      cc[q] = a.tmp2[t];
+    }
+#pragma unroll
+    for (int q = 0; q < SP_REGS; ++q) {
+      const int t = t0 + q * 1024 + tid;
+      const bool has = t < T && pp[q] != 0xFFFFFFFFu;
+      const int slot = has ? (int)(bins[pp[q] >> 20] + (pp[q] & 0xFFFFFu)) : 0;
+      if (has && cc[q] < 0 && slot < a.item_cap) items[slot] = t;
+      // the items of a split tile are written by the whole wave (a lane filling its own tile's run is one store
+      // instruction per item and wave)
+      unsigned long long todo = __ballot(has && cc[q] > 0);
+      while (todo != 0ull) {
+        const int src = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int c = __builtin_amdgcn_readlane(cc[q], src), sl = __builtin_amdgcn_readlane(slot, src),
+                  tt = __builtin_amdgcn_readlane(t, src);
+        for (int u = lane; u < c; u += 64)      // backward: deepest segment first (it starts from the pixels' own final state)
+          if (sl + u < a.item_cap)
+            items[sl + u] = (int32_t)((uint32_t)tt | ((uint32_t)(backward ? c - 1 - u : u) << 19) | ((uint32_t)SEG_SPEC << 30));
+      }
+    }
+  }
+  if (tid == 0) {
+    if (!backward) {
+      a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
+      a.hdr[SH_MAXLEN] = s_max; a.hdr[SH_SPLIT] = s_n3; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
+      a.hdr[SH_ITEMSB] = 0;
+      if (hint_host) hint_host[0] = (uint32_t)s_max;      // page-locked: the host peeks at it before a LATER render
+    } else {
+      a.hdr[SH_ITEMSB] = min(total, a.item_cap);
+    }
+  }
+}
+
+// The forward kernels over work items (see above), tile-footprint policies with a skip threshold only (the pixel-box
+// policy of forward_cpu.py has no early stop to speak of and is not a training path).  Four launches, ROLE:
+//   0  items1: DIRECT tiles (== k_draw) and SPEC segments, blended from tau = 1 into their state slot
+//   3  items3, one wave per split tile: the transmittance in FRONT of every SPEC segment, T_0 = 1, T_(s+1) = T_s tau_s
+//      (a chain of loads, requested eight segments ahead)
+//   1  items1 again, SPEC items with s > 0 only: the pixels that FINISH inside this segment (T_s >= tau_stop > T_s tau_s:
+//      the wave of launch 0 could not know) are blended again from tau = T_s, which stops them exactly where the
+//      unsplit kernel does, and their state is replaced (last contributor stored NEGATIVE: "finished here").  Every
+//      pixel finishes once, and only the 8x8 blocks that hold such a pixel are live: a fraction of one more segment
+//      walk, all segments at once
+//   2  items3 (COMPOSE): composes the SPEC segments in order, walks on from there while a pixel is alive, writes the
+//      tile's pixels and turns the slots into the backward pass's segment-end states
+// The blend loop is k_draw's, unchanged (one stop threshold for the whole wave: a re-walk or a continuation starts
+// from the TRUE transmittance, not from 1).
+template <bool FLOOR, bool CLAMP, int ROLE>
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 8 : 5, 8))) void k_draw_seg(
+    DrawParams p, SegArgs sg, int32_t* __restrict__ ranges, const int32_t* __restrict__ gsid,
+    const float4* __restrict__ rec, float* __restrict__ image, int32_t* __restrict__ contrib,
+    float* __restrict__ final_tau) {
+  __shared__ float4 sA[64], sB[64], sC[64];
+  const int lane = threadIdx.x;
+  if (ROLE == 0 && p.zero_buf) {   // every workgroup of the grid clears its slice of the gradient records
+    const uint32_t z0 = blockIdx.x * p.zero_per, z1 = min(p.zero_n4, z0 + p.zero_per);
+    float4* __restrict__ zb = p.zero_buf;
+    for (uint32_t i = z0 + lane; i < z1; i += 64) zb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  constexpr bool PER_TILE = ROLE == 2 || ROLE == 3;
+  if ((int)blockIdx.x >= sg.hdr[PER_TILE ? SH_ITEMS3 : SH_ITEMS1]) return;
+  const uint32_t item = (uint32_t)(PER_TILE ? sg.items3 : sg.items1)[blockIdx.x];
+  const int tile = (int)(item & SEG_TILE_MASK), iseg = (int)((item >> 19) & SEG_SEG_MASK), kind = (int)(item >> 30);
+  if (tile >= p.T) return;
+  if (ROLE == 1 && (kind != SEG_SPEC || iseg == 0)) return;   // (segment 0 starts from T = 1: launch 0 was exact)
+  if (PER_TILE && kind != SEG_COMPOSE) return;
+  const int L = sg.hdr[SH_L];
+  const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
+  const int n = r1 - r0;
+  const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
+  const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
+  const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
+  const size_t HW = (size_t)p.W * p.H;
+  // (recomputed where they are used: nothing of this stays in registers across the blend loop)
+  auto inside_px = [&](int k) { return (pxb[k & 1] < p.W) && (pyb[k >> 1] < p.H); };
+  auto pix_of = [&](int k) { return (size_t)min(pyb[k >> 1], p.H - 1) * p.W + min(pxb[k & 1], p.W - 1); };
+  if (n <= 0) {  // (DIRECT only) empty tile: zeros, final_tau = 0, ranges (0, 0) -- as k_draw
+    if (ROLE != 0) return;
+    if (p.work_out && lane == 0) p.work_out[tile] = 0;
+    if (lane == 0) { sg.walk[tile] = 0; if (sg.hist_walk) sg.hist_walk[tile] = 0; }
+    if (lane == 0 && (r0 != 0 || r1 != 0)) { ranges[2 * (size_t)tile] = 0; ranges[2 * (size_t)tile + 1] = 0; }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (inside_px(k)) {
+        image[pix_of(k)] = 0.f; image[HW + pix_of(k)] = 0.f; image[2 * HW + pix_of(k)] = 0.f;
+        contrib[pix_of(k)] = 0; final_tau[pix_of(k)] = 0.f;
+      }
+    return;
+  }
+  const int slot0 = sg.seg_base[tile];
+  const float stop = p.tau_stop, lthr = p.lskip;
+  if constexpr (ROLE == 3) {   // T_s for the SPEC segments of this tile
+    const int nspec = iseg;
+    float T[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T[k] = inside_px(k) ? 1.f : -1.f;
+    constexpr int AHEAD = 8;
+    for (int s0 = 0; s0 < nspec; s0 += AHEAD) {
+      float tl[AHEAD][4];
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) {
+        const size_t so = ((size_t)(slot0 + min(s0 + u, nspec - 1))) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tl[u][k] = sg.st4[so + 64 * k].w;
+      }
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) {
+        if (s0 + u < nspec) {
+          const size_t so = ((size_t)(slot0 + s0 + u)) * 256 + lane;
+#pragma unroll
+          for (int k = 0; k < 4; ++k) { sg.st2[so + 64 * k] = T[k]; T[k] *= tl[u][k]; }
+        }
+      }
+    }
+    return;
+  }
+  const float X[2] = {(float)(lane & 7) - 7.5f, (float)(lane & 7) + 0.5f};
+  const float Y[2] = {(float)(lane >> 3) - 7.5f, (float)(lane >> 3) + 0.5f};
+  const float XX[2] = {X[0] * X[0], X[1] * X[1]}, YY[2] = {Y[0] * Y[0], Y[1] * Y[1]};
+  const float XY[4] = {X[0] * Y[0], X[1] * Y[0], X[0] * Y[1], X[1] * Y[1]};
+  constexpr float L99 = -0.014499569695115089f;
+  const float cx0 = (float)tx0 + 7.5f, cy0 = (float)ty0 + 7.5f;
+  float tau[4], cr[4], cg[4], cb[4];   // blend state of one walk; a pixel that does not take part holds tau = -1
+  int cont[4];
+  // ROLE 2: the transmittance in front of the current segment; negative: the pixel is finished (or outside the image),
+  // |Tf| its final transmittance.  ROLE 1: the transmittance in front of segment iseg for the pixels to blend again.
+  float Tf[4];
+  int nseg = 1, nspec = 0, sdone = 0;
+  if (ROLE == 1) {
+    const size_t so = ((size_t)(slot0 + iseg)) * 256 + lane;
+    bool ev = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float T = sg.st2[so + 64 * k], tl = sg.st4[so + 64 * k].w;
+      const bool e = (T >= stop) && (T * tl < stop);
+      Tf[k] = e ? T : -1.f;
+      ev = ev || e;
+    }
+    if (!__any(ev)) return;
+  }
+  if (ROLE == 2) {
+    // ---- compose the SPEC segments: colour and last contributor in registers, the states requested ahead ----
+    nseg = (n + L - 1) >> (31 - __clz(L)); nspec = iseg;
+    float ca[4][3];
+    int cc[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { Tf[k] = inside_px(k) ? 1.f : -1.f; ca[k][0] = 0.f; ca[k][1] = 0.f; ca[k][2] = 0.f; cc[k] = 0; }
+    float4 vn[4];
+    int cn[4];
+    {
+      const size_t so = ((size_t)slot0) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[so + 64 * k]; cn[k] = __float_as_int(sg.st1[so + 64 * k]); }
+    }
+    for (int s = 0; s < nspec; ++s) {
+      float4 v[4];
+      int c[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] = vn[k]; c[k] = cn[k]; }
+      {
+        const size_t so = ((size_t)(slot0 + min(s + 1, nspec - 1))) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[so + 64 * k]; cn[k] = __float_as_int(sg.st1[so + 64 * k]); }
+      }
+      bool alive = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) alive = alive || (Tf[k] >= stop);
+      if (!__any(alive)) break;
+      sdone = s + 1;
+      const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!(Tf[k] >= stop)) continue;
+        ca[k][0] = fmaf(Tf[k], v[k].x, ca[k][0]); ca[k][1] = fmaf(Tf[k], v[k].y, ca[k][1]); ca[k][2] = fmaf(Tf[k], v[k].z, ca[k][2]);
+        float tn = Tf[k] * v[k].w;
+        // (a negative contributor: launch 1 blended this pixel to its end inside the segment -- not decided again here
+        // from a product that may round the other way)
+        if (c[k] < 0 || tn < stop) tn = -fmaxf(tn, 1.0e-30f);
+        if (c[k] != 0) cc[k] = abs(c[k]);
+        Tf[k] = tn;
+        sg.st1[so + 64 * k] = fabsf(tn);     // transmittance at the END of segment s
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (inside_px(k)) {
+        image[pix_of(k)] = ca[k][0]; image[HW + pix_of(k)] = ca[k][1]; image[2 * HW + pix_of(k)] = ca[k][2];
+        contrib[pix_of(k)] = cc[k];
+      }
+  }
+  // ---- walks: launch 0 (a tile or one segment from tau = 1), launch 1 (one segment again, the finishing pixels from
+  // their true transmittance), launch 2 (the segments behind the SPEC ones, one after the other, while a pixel is alive)
+  for (int s = (ROLE == 2 ? nspec : 0); s < nseg; ++s) {
+    int e0 = 0, e1 = n;
+    if (ROLE != 2 && kind == SEG_SPEC) { e0 = iseg * L; e1 = min(n, e0 + L); }
+    if (ROLE == 2) {
+      if (sdone < s) break;          // (the composition above ended early: every pixel is finished)
+      bool alive = false;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) alive = alive || (Tf[k] >= stop);
+      if (!__any(alive)) break;
+      e0 = s * L; e1 = min(n, e0 + L);
+      sdone = s + 1;
+    }
+    int live = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (ROLE == 0) tau[k] = inside_px(k) ? 1.f : -1.f;
+      else tau[k] = (Tf[k] >= stop) ? Tf[k] : -1.f;      // the TRUE transmittance in front of the segment
+      cr[k] = 0.f; cg[k] = 0.f; cb[k] = 0.f; cont[k] = 0;
+      if (__any(tau[k] >= stop)) live |= 1 << k;
+    }
+    // ---- the blend loop of k_draw over entries [e0, e1) ----
+    int gnext = (e0 + lane < e1) ? gsid[r0 + e0 + lane] : 0;
+    for (int base = e0; base < e1 && live != 0; base += 64) {
+      __syncthreads();
+      int mymask = 0;
+      const int gm = gnext;
+      const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
+      if (base + 64 + lane < e1) gnext = gsid[r0 + base + 64 + lane];
+      if (base + lane < e1) {
+        const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+        if (C.w < INFINITY) mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<false>(A, C, tx0, ty0);
+        const float la = lthr - C.w;
+        float cap = 3.0e38f;
+        if (FLOOR) cap = CLAMP ? fminf(la, L99) : la;
+        else if (CLAMP) cap = L99;
+        const float Dx = cx0 - A.x, Dy = cy0 - A.y;
+        const float c0 = la + (A.z * Dx * Dx + A.w * Dx * Dy + B.x * Dy * Dy);
+        const float c1 = 2.f * A.z * Dx + A.w * Dy, c2 = 2.f * B.x * Dy + A.w * Dx;
+        sA[lane] = make_float4(A.z, A.w, B.x, cap);
+        sB[lane] = make_float4(c0, c1, c2, B.z);
+        *reinterpret_cast<float2*>(&sC[lane]) = make_float2(B.w, C.x);
+      }
+      __syncthreads();
+      int pk = mymask;
+      pk |= __shfl_down(pk, 1, 64) << 4;
+      pk |= __shfl_down(pk, 2, 64) << 8;
+      pk |= __shfl_down(pk, 4, 64) << 16;
+      const int m = __builtin_amdgcn_readfirstlane(min(64, e1 - base));
+      for (int j0 = 0; j0 < m && live != 0; j0 += 8) {
+        const uint32_t act = (uint32_t)__builtin_amdgcn_readlane(pk, j0) & ((uint32_t)live * 0x11111111u);
+        if (act != 0u) {
+          const int vidx0 = base + j0 + 1;
+#pragma unroll
+          for (int t = 0; t < 8; ++t) {
+            const int reach = (int)((act >> (4 * t)) & 0xFu);
+            if (reach != 0) {
+              const int j = j0 + t;
+              const float4 Q = sA[j], Pq = sB[j];
+              const float2 gb = *reinterpret_cast<const float2*>(&sC[j]);
+              const int idx = vidx0 + t;
+#pragma unroll
+              for (int k = 0; k < 4; ++k) {
+                const int bx = k & 1, by = k >> 1;
+                if (reach & (1 << k)) {
+                  float e = fmaf(Pq.z, Y[by], Pq.x);
+                  e = fmaf(Pq.y, X[bx], e);
+                  e = fmaf(Q.z, YY[by], e);
+                  e = fmaf(Q.y, XY[k], e);
+                  e = fmaf(Q.x, XX[bx], e);
+                  if ((tau[k] >= stop) && (e >= lthr)) {
+                    if (FLOOR || CLAMP) e = min_hi(e, Q.w);
+                    const float w = tau[k] * __builtin_amdgcn_exp2f(e);
+                    cr[k] += w * Pq.w; cg[k] += w * gb.x; cb[k] += w * gb.y;
+                    tau[k] -= w;
+                    cont[k] = idx;
+                  }
+                }
+              }
+            }
+          }
+#pragma unroll
+          for (int k = 0; k < 4; ++k)
+            if ((live & (1 << k)) && !__any(tau[k] >= stop)) live &= ~(1 << k);
+        }
+      }
+    }
+    if (ROLE == 0 && kind == SEG_SPEC) {     // the segment's local state: (colour, tau) and its last contributor
+      const size_t so = ((size_t)(slot0 + iseg)) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sg.st4[so + 64 * k] = make_float4(cr[k], cg[k], cb[k], tau[k]);
+        sg.st1[so + 64 * k] = __int_as_float(cont[k]);
+      }
+      return;
+    }
+    if (ROLE == 1) {     // the pixels that finish inside this segment, blended from their true transmittance
+      const size_t so = ((size_t)(slot0 + iseg)) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (Tf[k] >= stop) {
+          const float rt = 1.f / Tf[k];      // back into the segment's local frame (Tf >= tau_stop: no blow-up)
+          sg.st4[so + 64 * k] = make_float4(cr[k] * rt, cg[k] * rt, cb[k] * rt, tau[k] * rt);
+          // negative: "finished here"; a pixel the walk did not finish after all stays an ordinary one
+          sg.st1[so + 64 * k] = __int_as_float(tau[k] < stop ? -cont[k] : cont[k]);
+        }
+      return;
+    }
+    if (ROLE == 2) {     // a continuation segment, walked right here from Tf: absolute colour, exact stop
+      const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (!(Tf[k] >= stop)) {   // (the scan below wants finite numbers in every slot it reads)
+          sg.st4[so + 64 * k] = make_float4(0.f, 0.f, 0.f, 1.f);
+          continue;
+        }
+        const float rt = 1.f / Tf[k];
+        sg.st4[so + 64 * k] = make_float4(cr[k] * rt, cg[k] * rt, cb[k] * rt, tau[k] * rt);
+        image[pix_of(k)] += cr[k]; image[HW + pix_of(k)] += cg[k]; image[2 * HW + pix_of(k)] += cb[k];
+        if (cont[k] > 0) contrib[pix_of(k)] = cont[k];
+        Tf[k] = (tau[k] < stop) ? -fmaxf(tau[k], 1.0e-30f) : tau[k];
+        sg.st1[so + 64 * k] = fabsf(Tf[k]);     // transmittance at the END of segment s
+      }
+    }
+  }
+  // ---- the tile's pixels -------------------------------------------------------------------------------------
+  int cfin[4];
+  if (ROLE == 0) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cfin[k] = cont[k];
+      if (inside_px(k)) {
+        image[pix_of(k)] = cr[k]; image[HW + pix_of(k)] = cg[k]; image[2 * HW + pix_of(k)] = cb[k];
+        contrib[pix_of(k)] = cont[k]; final_tau[pix_of(k)] = tau[k];
+      }
+    }
+  } else {
+    // COMPOSE: what the backward pass needs at the end of segment s -- the transmittance there (already in st1) and
+    // G_s, the colour of everything behind it seen from there: G_last = 0, G_(s-1) = C_s + tau_s G_s over the
+    // segments the pixel was alive in (it finished in the segment of its last contributor, if it finished).
+    float G[4][3];
+    int sstar[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cfin[k] = inside_px(k) ? contrib[pix_of(k)] : 0;
+      if (inside_px(k)) final_tau[pix_of(k)] = fabsf(Tf[k]);
+      sstar[k] = (Tf[k] < stop) ? (max(cfin[k] - 1, 0) >> (31 - __clz(L))) : sdone - 1;
+      G[k][0] = 0.f; G[k][1] = 0.f; G[k][2] = 0.f;
+    }
+    float4 vn[4];
+    float tn[4];
+    if (sdone > 0) {
+      const size_t so = ((size_t)(slot0 + sdone - 1)) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[so + 64 * k]; tn[k] = sg.st1[so + 64 * k]; }
+    }
+    for (int s = sdone - 1; s >= 0; --s) {
+      float4 vv[4];
+      float te[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { vv[k] = vn[k]; te[k] = tn[k]; }
+      {
+        const size_t sp = ((size_t)(slot0 + max(s - 1, 0))) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[sp + 64 * k]; tn[k] = sg.st1[sp + 64 * k]; }
+      }
+      const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sg.st4[so + 64 * k] = make_float4(G[k][0], G[k][1], G[k][2], te[k]);
+        if (s <= sstar[k]) {
+          G[k][0] = fmaf(vv[k].w, G[k][0], vv[k].x); G[k][1] = fmaf(vv[k].w, G[k][1], vv[k].y);
+          G[k][2] = fmaf(vv[k].w, G[k][2], vv[k].z);
+        }
+      }
+    }
+  }
+  {   // how far the tile was walked: the work measure of the dispatch orders and the backward pass's segment count
+    int w = 0, wmax = 0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      int mx = cfin[k];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+      w += mx;
+      wmax = max(wmax, mx);
+    }
+    if (lane == 0) {
+      if (p.work_out) p.work_out[tile] = w + 2 * wmax;
+      sg.walk[tile] = wmax;
+      if (sg.hist_walk) sg.hist_walk[tile] = wmax;
+    }
+  }
+}
+
+// ============================================================================
 // draw backward: per-tile back-to-front gradients        (reference kernel.cu:809-950)
 // ============================================================================
 // gfx950 cross-half / cross-row swaps (v_permlane32_swap_b32, v_permlane16_swap_b32)
@@ -1655,24 +2274,46 @@ __device__ __forceinline__ float rows_to_lanes9_bank(const float (&q)[9], int c1
 //   du = -cinv (M1x, M1y), dcinv = -(M2xx/2, M2xy, M2yy/2), applied once per entry)
 // The 9 partials are reduced across the wave 4 entries at a time (transposing reduction below) and nine
 // lanes per entry issue the 9 atomics as one instruction: one atomic set per (tile, Gaussian).
-template <bool BOX, bool FLOOR, bool CLAMP, int RED>
+// SEG: the launch runs over the work items of k_seg_plan (backward == 1) instead of tiles: DIRECT(tile) is the kernel
+// as it always was; SPEC(tile, s) walks entries [s L, (s + 1) L) of a split tile only, and a pixel whose last
+// contributor lies BEHIND the segment starts from the state the forward pass's COMPOSE item left for the segment's end
+// -- the transmittance there and G, the colour of everything behind it (lq = dL/dgamma . G) -- where the unsplit kernel
+// starts every pixel from (final_tau, 0) at its last contributor.
+template <bool BOX, bool FLOOR, bool CLAMP, int RED, bool SEG = false>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_draw_bwd(DrawParams p, const int32_t* __restrict__ ranges,
                                                  const int32_t* __restrict__ gsid,
                                                  const float4* __restrict__ rec,
                                                  const float* __restrict__ final_tau,
                                                  const int32_t* __restrict__ contrib,
                                                  const float* __restrict__ dLdg,
-                                                 float* __restrict__ gpack) {
+                                                 float* __restrict__ gpack, SegArgs sg) {
   __shared__ float4 sA[64], sB[64], sC[64], sD[64];  // sD = {cinv.x, cinv.y, cinv.z, gsid}
   __shared__ float4 szero[3];                        // a line of zeros (see the accumulator reset below)
   constexpr bool ZLDS = (RED & 2) != 0, LAZY = (RED & 4) != 0;
   if (ZLDS && threadIdx.x < 3) szero[threadIdx.x] = make_float4(0.f, 0.f, 0.f, 0.f);
   const uint32_t zaddr = (uint32_t)(uintptr_t)szero;   // LDS byte offset of the zero line
-  const int tile = xcd_tile(blockIdx.x, p);
-  if (tile < 0) return;
+  int tile, seg_lo = 0, seg_hi = 0x7fffffff;   // SEG: the entries [seg_lo, seg_hi) of the tile's list are this wave's
+  size_t seg_state = 0;
+  bool seg_item = false;
+  if constexpr (SEG) {
+    if ((int)blockIdx.x >= sg.hdr[SH_ITEMSB]) return;
+    const uint32_t item = (uint32_t)sg.itemsB[blockIdx.x];
+    tile = (int)(item & SEG_TILE_MASK);
+    if (tile >= p.T) return;
+    if ((item >> 30) == (uint32_t)SEG_SPEC) {
+      const int L = sg.hdr[SH_L], sidx = (int)((item >> 19) & SEG_SEG_MASK);
+      seg_item = true;
+      seg_lo = sidx * L; seg_hi = seg_lo + L;
+      seg_state = ((size_t)(sg.seg_base[tile] + sidx)) * 256 + threadIdx.x;
+    }
+  } else {
+    tile = xcd_tile(blockIdx.x, p);
+    if (tile < 0) return;
+  }
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
   const int n = r1 - r0;
   if (n <= 0) return;
+  if (SEG) seg_hi = min(seg_hi, n);
   const int lane = threadIdx.x;
   const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
   const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
@@ -1697,10 +2338,26 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     lr[k] = dLdg[pix]; lg[k] = dLdg[HW + pix]; lb[k] = dLdg[2 * HW + pix];
     lq[k] = 0.f;
   }
+  float4 segE[4];
+  if constexpr (SEG) {   // (requested with the loads above; a DIRECT item or the last segment never uses them)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) segE[k] = seg_item ? sg.st4[seg_state + 64 * k] : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
     const int px = pxb[k & 1], py = pyb[k >> 1];
     if (!(px < p.W && py < p.H)) { tau[k] = 0.f; cont[k] = 0; lr[k] = 0.f; lg[k] = 0.f; lb[k] = 0.f; }
+    if constexpr (SEG) {
+      if (seg_item) {
+        if (cont[k] > seg_hi) {          // contributors behind this segment: start from the state at its end
+          tau[k] = segE[k].w;
+          lq[k] = lr[k] * segE[k].x + lg[k] * segE[k].y + lb[k] * segE[k].z;
+          cont[k] = seg_hi;
+        } else if (cont[k] <= seg_lo) {  // the pixel never got this far
+          cont[k] = 0;
+        }
+      }
+    }
     int mx = cont[k];
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
@@ -1732,13 +2389,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
 
   const int c_first = (maxcont - 1) >> 6;
   int gnext = (c_first * 64 + lane < n) ? gsid[r0 + c_first * 64 + lane] : 0;   // one chunk ahead, as in k_draw
-  for (int c = c_first; c >= 0; --c) {
+  const int c_last = SEG ? (seg_lo >> 6) : 0;
+  for (int c = c_first; c >= c_last; --c) {
     __syncthreads();
     const int idx = c * 64 + lane;
     int mymask = 0;  // reach mask of the entry THIS lane staged (lane j <-> entry c*64 + j)
     const int gm = gnext;
     const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
-    if (c > 0) gnext = gsid[r0 + idx - 64];
+    if (c > c_last) gnext = gsid[r0 + idx - 64];
     if (idx < n) {
       const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
       mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<BOX>(A, C, tx0, ty0);
@@ -2082,7 +2740,26 @@ extern "C" size_t egs_splat_bin_ws_bytes(int n) { return bin_ws_bytes(n); }
 // a caller-held tile_order buffer: [dispatch order of the forward draw | per-tile work it measured (T ints)]
 extern "C" size_t egs_tile_order_len(int width, int height) {
   const int gx = div_up(width, EGS_TILE), gy = div_up(height, EGS_TILE);
-  return (size_t)tile_order_len(gx, gy) + (size_t)gx * gy;
+  return (size_t)tile_order_len(gx, gy) + 2 * (size_t)gx * gy;
+}
+
+// ---- long lists split over several waves (k_seg_plan / k_draw_seg / k_draw_bwd<SEG>) ----
+extern "C" size_t egs_seg_ws_bytes(int64_t patch_capacity, int width, int height) {
+  seg_config_env();
+  const int T = div_up(width, EGS_TILE) * div_up(height, EGS_TILE);
+  const int64_t P = patch_capacity > 0 ? patch_capacity : 1;
+  return seg_ws_bytes_for(P / g_seg_L + P / g_seg_min + 64, T);
+}
+extern "C" int egs_seg_config(int segment_len, int split_min, int* out2) {
+  seg_config_env();
+  if (out2) { out2[0] = g_seg_L; out2[1] = g_seg_min; }
+  if (segment_len > 0) {
+    EGS_CHECK_ARG(segment_len >= 64 && segment_len <= 65536 && (segment_len & (segment_len - 1)) == 0);
+    g_seg_L = segment_len;
+  }
+  if (split_min > 0) g_seg_min = split_min;
+  if (g_seg_min < g_seg_L) g_seg_min = g_seg_L;
+  return 0;
 }
 extern "C" size_t egs_splat_draw_ws_bytes(int n, int64_t patches, int width, int height) {
   return draw_ws_bytes(n, patches, width, height);
@@ -2238,7 +2915,11 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            float* final_tau, int32_t* patch_range_per_tile, int32_t* gsid_per_patch,
                            void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
                            float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr,
-                           int order_ready = 0, int flags = 0, int32_t* gsid_plain = nullptr) {
+                           int order_ready = 0, int flags = 0, int32_t* gsid_plain = nullptr, void* seg_ws = nullptr,
+                           size_t seg_ws_bytes = 0, uint32_t* seg_hint = nullptr) {
+  // seg_ws != NULL (egs_seg_ws_bytes): long lists are split over several waves (k_draw_seg; the backward pass then
+  // takes the same workspace); flags & EGS_DRAW_SEG_HISTORY: the walk part of tile_order holds what an earlier render of
+  // this camera measured.  seg_hint (nullable, page-locked): receives the longest list of this render.
   // gsid_plain (nullable, with EGS_DRAW_MASKED_LISTS): receives the list values without their masks
   // flags & EGS_DRAW_CULLED_LISTS: the binning stage counted the footprint-culled tiles (egs_fused_forward with
   // cull_lists): the lists are emitted with block masks in the high bits of their values and drawn from those
@@ -2274,7 +2955,11 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
         const int rc = tile_order_enqueue(dp, 0, tile_order, olen, patch_range_per_tile, s, nullptr);
         if (rc) return rc;
       }
-      EGS_HIP(hipMemsetAsync(tile_order + olen, 0, (size_t)dp.T * 4, s));
+      EGS_HIP(hipMemsetAsync(tile_order + olen, 0, (size_t)dp.T * 8, s));   // work and walk
+    }
+    if (seg_ws) {   // a backward pass may still be handed the workspace: no items, nothing split
+      SegArgs sa;
+      if (seg_carve(seg_ws, seg_ws_bytes, dp.T, &sa)) EGS_HIP(hipMemsetAsync(sa.hdr, 0, SEG_HDR * 4, s));
     }
     return 0;
   }
@@ -2311,6 +2996,52 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   if (!EGS_RANGES_FOLD)
     EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(patches, 1024)), dim3(256), s, patches, D.tkeys,
                patch_range_per_tile, patches_dev, (const uint32_t*)(gsid_plain ? gsid_per_patch : nullptr), gsid_plain);
+  SegArgs sga;
+  const bool seg = seg_ws && pol->footprint == 0 && pol->alpha_skip > 0.f && pol->tau_stop > 0.f &&
+                   dp.T <= (int)SEG_TILE_MASK && seg_carve(seg_ws, seg_ws_bytes, dp.T, &sga);
+  if (seg_ws && !seg) {
+    set_error(EGS_ERR_WORKSPACE, "segment workspace too small (or a policy without a skip / stop threshold)", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  if (seg) {
+    seg_config_env();
+    const size_t olen = (size_t)tile_order_len(dp.gx, dp.gy);
+    const int32_t* hist = (tile_order && (flags & EGS_DRAW_SEG_HISTORY)) ? tile_order + olen + dp.T : nullptr;
+    sga.hist_walk = tile_order ? tile_order + olen + dp.T : nullptr;
+    EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, hist, g_seg_L, g_seg_min,
+               sga, 0, seg_hint);
+    if (tile_order) dp.work_out = tile_order + olen;
+    // items <= tiles + segments <= T + P / L + P / split_min: the launch covers the bound, surplus workgroups exit
+    const int64_t bound = (int64_t)dp.T + patches / g_seg_L + patches / g_seg_min + 2;
+    const int grid1 = (int)std::min<int64_t>(bound, sga.item_cap);
+    if (grad_records) {
+      dp.zero_buf = (float4*)grad_records;
+      dp.zero_n4 = (uint32_t)(3 * (size_t)n);
+      dp.zero_per = (dp.zero_n4 + (uint32_t)grid1 - 1) / (uint32_t)grid1;
+    }
+#define EGS_DRAWS(FLOOR, CLAMP, ROLE, NAME, GRID)                                                                \
+    EGS_LAUNCH(NAME, (k_draw_seg<FLOOR, CLAMP, ROLE>), dim3(GRID), dim3(64), s, dp, sga, patch_range_per_tile,      \
+               gsid_per_patch, rec, image, contrib, final_tau)
+#define EGS_DRAWS3(FLOOR, CLAMP)                                                                                  \
+    do {                                                                                                          \
+      EGS_DRAWS(FLOOR, CLAMP, 0, "k_draw_seg", grid1);                                                            \
+      if (hist) {   /* (no prediction: segment 0 is the only SPEC item of a tile, and it is exact) */               \
+        EGS_DRAWS(FLOOR, CLAMP, 3, "k_draw_seg_prefix", dp.T);                                                    \
+        EGS_DRAWS(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid1);                                                      \
+      }                                                                                                           \
+      EGS_DRAWS(FLOOR, CLAMP, 2, "k_draw_seg_compose", dp.T);                                                     \
+    } while (0)
+    switch ((pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0)) {
+      case 0: EGS_DRAWS3(false, false); break;
+      case 1: EGS_DRAWS3(false, true); break;
+      case 2: EGS_DRAWS3(true, false); break;
+      default: EGS_DRAWS3(true, true); break;
+    }
+#undef EGS_DRAWS3
+#undef EGS_DRAWS
+    EGS_LAUNCH_OK();
+    return 0;
+  }
   if (order_ready && tile_order && tile_order_mode(0) > 0 && dp.T <= TILE_ORDER_MAX_T) {
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(0) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
@@ -2437,6 +3168,20 @@ extern "C" int egs_splat_draw_rec_dev_plain(int n, int64_t patch_capacity, const
                          nullptr, 0, flags, gsid_plain);
 }
 
+// the draw stage of egs_splat_draw_rec / _dev (total_patches NULL: `patches` is exact) with a segment workspace
+extern "C" int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* total_patches, int width, int height,
+                                      const void* rec, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                                      size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                                      int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
+                                      float* grad_records, const int32_t* prev_tile_work, int order_ready, int flags,
+                                      void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint, void* stream) {
+  EGS_CHECK_ARG((rec || n == 0) && (!total_patches || patches > 0));
+  return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin, ws_draw,
+                         ws_draw_bytes, (const float4*)rec, image, contrib, final_tau, patch_range_per_tile,
+                         gsid_per_patch, stream, total_patches, tile_order, grad_records, prev_tile_work, order_ready,
+                         flags, nullptr, seg_ws, seg_ws_bytes, seg_hint);
+}
+
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]
 constexpr size_t BWD_ORDER_CAP = (size_t)1 << 18;   // tiles: up to 8192 x 8192 pixels
 extern "C" size_t egs_splat_bwd_ws_bytes(int n) {
@@ -2449,7 +3194,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                      float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order,
-                     float* grad_records, bool keep_forward_order, bool masked_lists) {
+                     float* grad_records, bool keep_forward_order, bool masked_lists, void* seg_ws,
+                     size_t seg_ws_bytes) {
   hipStream_t s = (hipStream_t)stream;
   const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
   // [N][12] packed gradient records: the caller's (already zeroed by the forward draw kernel) or a piece of ws
@@ -2468,6 +3214,31 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     EGS_LAUNCH("k_pack_records", k_pack_records, dim3(div_up(n, 256)), dim3(256), s, n, width, height,
                pol->footprint, pol->alpha_skip, us, cinv2ds, alphas, colors, areas, (float4*)ws, (uint32_t*)nullptr, (const uint32_t*)nullptr,
                (uint8_t*)nullptr);
+  static const int red = [] { const char* e = getenv("EGS_DRAWB_RED"); return e ? atoi(e) : EGS_DRAWB_RED_DEFAULT; }();
+  if (seg_ws) {   // the forward pass split its long lists (egs_splat_draw_rec_seg): one wave per segment
+    SegArgs sga;
+    if (pol->footprint != 0 || !seg_carve(seg_ws, seg_ws_bytes, dp.T, &sga)) {
+      set_error(EGS_ERR_WORKSPACE, "segment workspace too small", __FILE__, __LINE__);
+      return EGS_ERR_WORKSPACE;
+    }
+    seg_config_env();
+    EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, (const int32_t*)nullptr, 0,
+               0, sga, 1, (uint32_t*)nullptr);
+    const int64_t bound = (int64_t)dp.T + patches / g_seg_L + patches / g_seg_min + 2;
+    const int grid = (int)std::min<int64_t>(bound, sga.item_cap);
+#define EGS_DRAWBS(FLOOR, CLAMP)                                                                            \
+    EGS_LAUNCH("k_draw_bwd_seg", (k_draw_bwd<false, FLOOR, CLAMP, 7, true>), dim3(grid), dim3(64), s, dp,    \
+               patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, gpack, sga)
+    switch ((pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0)) {
+      case 0: EGS_DRAWBS(false, false); break;
+      case 1: EGS_DRAWBS(false, true); break;
+      case 2: EGS_DRAWBS(true, false); break;
+      default: EGS_DRAWBS(true, true); break;
+    }
+#undef EGS_DRAWBS
+    EGS_LAUNCH_OK();
+    return 0;
+  }
   static const int by_work = [] { const char* e = getenv("EGS_DRAWB_BY_WORK"); return e ? atoi(e) : 1; }();
   const bool same_mode = tile_order_mode(0) == tile_order_mode(1) && tile_order_mode(1) > 0;
   if (tile_order && keep_forward_order && same_mode) {
@@ -2504,21 +3275,21 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   // variants of the backward kernel (bit 0: in-row merges of the wave reduction with bank-masked DPP adds instead
   // of selects; bit 1: accumulator zeros loaded from LDS instead of moved; bit 2: exponent per evaluated block);
   // EGS_DRAWB_RED = 0 | 3 | 7 overrides
-  static const int red = [] { const char* e = getenv("EGS_DRAWB_RED"); return e ? atoi(e) : EGS_DRAWB_RED_DEFAULT; }();
+  const SegArgs nosg = {};
 #define EGS_DRAWB(BOX, FLOOR, CLAMP)                                                                      \
   do {                                                                                                    \
     if (red == 0)                                                                                         \
       EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 0>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
-                     dloss_dgammas, gpack);                                                               \
+                     dloss_dgammas, gpack, nosg);                                                               \
     else if (red == 3)                                                                                    \
       EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 3>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
-                     dloss_dgammas, gpack);                                                               \
+                     dloss_dgammas, gpack, nosg);                                                               \
     else                                                                                                  \
       EGS_LAUNCH_LDS("k_draw_bwd", (k_draw_bwd<BOX, FLOOR, CLAMP, 7>), dim3(draw_grid(dp)), dim3(64),     \
                      draw_lds_pad(1), s, dp, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, \
-                     dloss_dgammas, gpack);                                                               \
+                     dloss_dgammas, gpack, nosg);                                                               \
   } while (0)
   const int sel = (pol->footprint == 1 ? 4 : 0) | (pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0);
   switch (sel) {

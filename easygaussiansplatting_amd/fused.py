@@ -36,6 +36,10 @@ ORDER_REFRESH = max(2, int(os.environ.get("EGS_TILE_ORDER_REFRESH", "4")))   # r
 TILE_WORK_CACHE = os.environ.get("EGS_TILE_WORK_CACHE", "1") != "0"  # A/B knob: forward dispatch order by remembered work
 SAVE_DCOLOR = os.environ.get("EGS_SAVE_DCOLOR", "1") != "0"          # A/B knob: forward keeps dcolor/dpw for backward
 CULL_LISTS = os.environ.get("EGS_CULL_LISTS", "1") != "0"            # A/B knob: footprint-culled tile lists
+# long tile lists split over several waves (include/egs_hip.h egs_splat_draw_rec_seg): "auto" = whenever the longest list
+# of the scene's last render exceeded the split threshold (and at first sight), "1" always, "0" never
+SEGMENTS = os.environ.get("EGS_SEGMENTS", "auto")
+SEG_HISTORY = 4           # include/egs_hip.h EGS_DRAW_SEG_HISTORY
 CULLED_LISTS = 32         # include/egs_hip.h EGS_BWD_CULLED_LISTS
 ACCUMULATE = 64           # include/egs_hip.h EGS_BWD_ACCUMULATE
 FACTORED_SH = 128         # include/egs_hip.h EGS_BWD_FACTORED_SH
@@ -47,7 +51,8 @@ class FusedState:
     """Tensors the backward pass needs (all produced by ``forward``).  ``ticket`` is set while the render's
     patch count has not been validated yet (deferred validation, see ``deferred``)."""
     __slots__ = ("us", "depths", "cinv2ds", "colors", "areas", "rec", "contrib", "final_tau", "ranges", "gsid",
-                 "order", "order_by_work", "gpack", "dcw", "culled", "width", "height", "ticket", "_patches", "_keep")
+                 "order", "order_by_work", "gpack", "dcw", "culled", "width", "height", "ticket", "_patches", "_keep",
+                 "seg")
 
     def patch_count(self) -> int:
         """P of this render (waits for its read-back if it has not been looked at yet)."""
@@ -91,6 +96,7 @@ class _DeviceCtx:
         # (camera, stream) -> (weakref, its [order | work] buffer, renders so far, problem size): the dispatch order
         # of the tiles is kept between the renders of a camera (a trainer meets every view again each epoch)
         self.tile_work = {}
+        self.seg_hint = {}      # (N, W, H) -> mailbox slot kept as the landing zone of "longest list of the last render"
         self.lock = threading.RLock()
 
 
@@ -211,6 +217,29 @@ def commit(device=None):
     return [t.state for t in bad]
 
 
+def _seg_decision(ctx, lib, key, pol_):
+    """-> (use the segment path for this render, device-visible address of the hint slot or None).  The kernels of a
+    segment render leave the longest list of the render in a page-locked slot kept per problem size; a later render
+    looks at it WITHOUT waiting (it may be a render or two old -- it only selects between two exact paths): lists that
+    all fit the split threshold take the unsplit kernels (two launches less)."""
+    if SEGMENTS == "0" or pol_.footprint != 0 or not (pol_.alpha_skip > 0) or not (pol_.tau_stop > 0):
+        return False, None
+    with ctx.lock:
+        slot = ctx.seg_hint.get(key)
+        if slot is None:
+            if len(ctx.free) <= MAILBOX_SLOTS // 2:      # (never starve the renders of their read-back slots)
+                return SEGMENTS == "1", None
+            slot = ctx.seg_hint[key] = ctx.free.pop()
+            _lib.check(lib.egs_mailbox_clear(ctx.mb, slot))
+    out = (C.c_uint32 * 4)()
+    _lib.check(lib.egs_mailbox_peek(ctx.mb, slot, out))
+    cfg = (C.c_int * 2)()
+    _lib.check(lib.egs_seg_config(0, 0, cfg))
+    longest = int(out[0])
+    use = SEGMENTS == "1" or longest == 0xFFFFFFFF or longest > cfg[1]
+    return use, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot))
+
+
 def _split_sh(low_shs, high_shs, n):
     low = _chk(low_shs, "low_shs", torch.float32, (n, 3))
     high = _chk(high_shs, "high_shs", torch.float32, (n, None))
@@ -251,7 +280,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     f32, i32 = torch.float32, torch.int32
     S = FusedState()
     S.width, S.height = W, H
-    S.ticket, S._patches, S._keep = None, None, None
+    S.ticket, S._patches, S._keep, S.seg = None, None, None, None
     # the draw kernels (forward and backward) work from the packed records alone: us / cinv2ds / colors /
     # areas are not materialised
     S.us = S.cinv2ds = S.colors = S.areas = None
@@ -284,10 +313,17 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     def draw_exact(patches):
         S.gsid = torch.empty(patches, dtype=i32, device=dev)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
+        if use_seg:
+            S.seg = torch.empty(lib.egs_seg_ws_bytes(max(patches, 1), W, H), dtype=torch.uint8, device=dev)
+            _lib.check(lib.egs_splat_draw_rec_seg(n, patches, None, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
+                                                  ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
+                                                  _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
+                                                  order_ready, draw_flags, _ptr(S.seg), S.seg.numel(), seg_hint, st))
+            return
         _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
                                           ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                           _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
-                                          order_ready, 1 if S.culled else 0, st))
+                                          order_ready, draw_flags, st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -308,6 +344,8 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     # no order kernel at all on most renders (10 us forward, 8 us backward at 1080p).
     prev_work, order_ready = None, 0
     cache_entry = None        # registered only AFTER the draw stage that writes the order buffer was enqueued
+    use_seg, seg_hint = _seg_decision(ctx, lib, key, pol_) if n > 0 else (False, None)
+    walk_known = False        # the camera's last render went through the segment path: its walk lengths are on record
     if TILE_WORK_CACHE and n > 0:
         ck = (id(cam), int(st.value or 0))              # one entry per camera and stream, whatever the scene size
         olen = lib.egs_tile_order_len(W, H)
@@ -316,6 +354,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             if hit is not None and hit[0]() is cam and hit[1].numel() == olen and hit[3] == (n, W, H):
                 S.order = hit[1]
                 renders = hit[2] + 1
+                walk_known = bool(hit[4])
                 if renders == 2 or renders % ORDER_REFRESH == 0:
                     prev_work = C.c_void_p(S.order.data_ptr() + 4 * (olen - _tiles(W, H)))   # its own work part
                 else:
@@ -347,8 +386,9 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         except TypeError:                               # a camera object that cannot be weakly referenced
             return
         with ctx.lock:
-            tw[ck] = (ref, S.order, renders, (n, W, H))
+            tw[ck] = (ref, S.order, renders, (n, W, H), use_seg)
     S.order_by_work = prev_work is not None or order_ready == 1
+    draw_flags = (1 if S.culled else 0) | (SEG_HISTORY if (use_seg and walk_known) else 0)
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
     def render_exact():
@@ -394,10 +434,18 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             host_slot[0] = None   # (a later synchronous re-render must not write into a slot that was handed back)
         gsid_full = torch.empty(cap, dtype=i32, device=dev)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
-                                              _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
-                                              _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
-                                              _ptr(S.gpack), prev_work, order_ready, 1 if S.culled else 0, st))
+        if use_seg:
+            S.seg = torch.empty(lib.egs_seg_ws_bytes(cap, W, H), dtype=torch.uint8, device=dev)
+            _lib.check(lib.egs_splat_draw_rec_seg(n, cap, _ptr(total), W, H, _ptr(S.rec), pol, _ptr(ws_bin),
+                                                  _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
+                                                  _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
+                                                  _ptr(S.gpack), prev_work, order_ready, draw_flags, _ptr(S.seg),
+                                                  S.seg.numel(), seg_hint, st))
+        else:
+            _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
+                                                  _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
+                                                  _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
+                                                  _ptr(S.gpack), prev_work, order_ready, draw_flags, st))
     except BaseException:
         # Whatever was enqueued before the failure (the arm, the binning chain) still stores {P, max key} into the
         # slot: it goes back on the free list only once those kernels have run -- otherwise a render on another
@@ -584,16 +632,18 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
            ws_bytes, _ptr(dpws), _ptr(dshs))
     st = _stream()
     gpack, S.gpack = S.gpack, None      # zeroed by the forward draw kernel: good for ONE backward pass
+    seg = getattr(S, "seg", None)       # the forward pass split its long lists: the backward pass walks its segments
+    seg_bytes = seg.numel() if seg is not None else 0
     if raw:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward_raw(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), _ptr(high_shs), *mid,
             _ptr(dhigh), _ptr(dalphas), _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack),
-            _ptr(getattr(S, "dcw", None)), phase, b, c, st))
+            _ptr(getattr(S, "dcw", None)), phase, b, c, _ptr(seg), seg_bytes, st))
     else:
         launch = lambda phase, b, c: _lib.check(lib.egs_fused_backward(
             n, K, S.gsid.shape[0], W, H, _ptr(pws), _ptr(rots), _ptr(scales), _ptr(shs), *mid, _ptr(dalphas),
             _ptr(dscales), _ptr(drots), _ptr(dus), _ptr(S.order), _ptr(gpack), _ptr(getattr(S, "dcw", None)), phase,
-            b, c, st))
+            b, c, _ptr(seg), seg_bytes, st))
     # the forward pass was dispatched by remembered work: the backward pass keeps its order (no second order kernel)
     keep = KEEP_FORWARD_ORDER if (REUSE_ORDER and getattr(S, "order_by_work", False)) else 0
     if getattr(S, "culled", False):

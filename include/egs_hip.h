@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 6
+#define EGS_ABI_VERSION 7
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -297,7 +297,36 @@ int egs_splat_draw_rec(int n, int64_t patches, int width, int height, const void
  * The draw kernels hand the tiles to the SIMDs longest list first (k_tile_order, one workgroup, after the
  * tile ranges are known).  tile_order (nullable, egs_tile_order_len(width, height) ints) receives that dispatch
  * order so that egs_fused_backward can reuse it instead of computing its own. */
-size_t egs_tile_order_len(int width, int height);   /* ints: [forward dispatch order | per-tile work measured by the draw] */
+size_t egs_tile_order_len(int width, int height);   /* ints: [forward dispatch order | per-tile work measured by the
+                                                      * draw | per-tile walk length (segment path only)] */
+/* Long lists split over several waves (reference: 256 threads per tile, kernel.cu:152-271 launched (16, 16) at
+ * gausplat.cu:94; here a tile is ONE wave64 whose run time is the length of its walk, so a heavy-tailed scene -- a few
+ * tiles with 10 000 entries, nothing saturating after reset_alpha, gsmodel.py:320-324 -- ends when its longest tile
+ * ends).  egs_splat_draw_rec_seg is egs_splat_draw_rec (total_patches == NULL: `patches` exact) / egs_splat_draw_rec_dev
+ * (total_patches on the device, `patches` the capacity) with a workspace of egs_seg_ws_bytes(patch capacity, ..) bytes:
+ * tiles of more than `split_min` entries are walked in segments of `segment_len` entries -- front-to-back blending is
+ * associative on (colour, tau) pairs -- by one wave each where this camera's previous render predicts the walk
+ * (flags & EGS_DRAW_SEG_HISTORY: the walk part of tile_order is that render's), sequentially otherwise; either way the
+ * workspace then holds, per segment end and pixel, the transmittance and the colour of everything behind it, and
+ * egs_fused_backward(_raw) given the SAME workspace walks every segment with a wave of its own (no sequential
+ * dependence is left in the backward pass).  Tile-footprint policies with alpha_skip > 0 and tau_stop > 0 only.
+ * Images / contrib / final_tau equal the unsplit kernels' up to the rounding of  sum_s T_s C_s  against one running sum.
+ * seg_hint (nullable, page-locked host memory, e.g. a mailbox slot): receives the longest list of this render -- a
+ * host that finds it below split_min may drop the workspace for later renders of the scene (the unsplit kernels are
+ * then the same work with two launches less).  prev_tile_work / order_ready are ignored when the lists are split
+ * (the work items are re-planned per render, by k_seg_plan). */
+#define EGS_DRAW_SEG_HISTORY 4
+size_t egs_seg_ws_bytes(int64_t patch_capacity, int width, int height);
+/* segment_len (a power of two >= 64) / split_min: 0 keeps the current value; out2 (nullable) receives the values BEFORE the
+ * call.  Process-wide tuning knob (defaults 256 / 1024, or EGS_SEG_L / EGS_SEG_MIN from the environment); a workspace
+ * must be sized and used under one setting. */
+int egs_seg_config(int segment_len, int split_min, int* out2);
+int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* total_patches /*nullable*/, int width, int height,
+                           const void* rec, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
+                           size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
+                           int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
+                           float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/, int order_ready,
+                           int flags, void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint /*nullable*/, void* stream);
 /* As egs_splat_draw_rec, for a host that enqueues the draw stage BEFORE it has read total_patches (no GPU
  * idle time around the read-back): patch_capacity sizes gsid_per_patch and ws_draw
  * (egs_splat_draw_ws_bytes(n, patch_capacity, ..)), the real patch count is taken from total_patches[0] on
@@ -337,6 +366,10 @@ int egs_mailbox_post(void* mailbox, int slot, const uint32_t* total_patches, voi
 uint32_t* egs_mailbox_slot(void* mailbox, int slot);
 int egs_mailbox_arm(void* mailbox, int slot, void* stream);
 int egs_mailbox_fetch(void* mailbox, int slot, int blocking, uint32_t* out2);
+/* the four words of a slot as they stand right now (no waiting, no state change): for slots used as a landing zone of
+ * hints (egs_splat_draw_rec_seg's seg_hint); egs_mailbox_clear sets them to 0xFFFFFFFF ("nothing yet"). */
+int egs_mailbox_peek(void* mailbox, int slot, uint32_t* out4);
+int egs_mailbox_clear(void* mailbox, int slot);
 size_t egs_fused_backward_ws_bytes(int n);
 /* OR-ed into `phase`: the forward pass that filled tile_order was itself dispatched by measured work
  * (prev_tile_work != NULL), so the backward pass keeps that order instead of sorting the tiles again by the
@@ -389,7 +422,8 @@ int egs_fused_backward(int n, int sh_dim, int64_t patches, int width, int height
                        float* dloss_drots, float* dloss_dus, const int32_t* tile_order /*nullable*/,
                        float* grad_records /*nullable: zeroed by the forward draw*/,
                        const float* dcolor_dpws /*nullable: left by egs_fused_forward*/, int phase, int row_begin,
-                       int row_count, void* stream);
+                       int row_count, void* seg_ws /*nullable: the forward's egs_splat_draw_rec_seg workspace*/,
+                       size_t seg_ws_bytes, void* stream);
 
 /* The same pair on the OPTIMIZER's tensors (gsplat/gsmodel.py:96-129: alphas_raw, scales_raw, rots_raw,
  * low_shs [N,3], high_shs [N,sh_dim-3]): the activations of gsplat/utils.py:121-150 (sigmoid, exp,
@@ -415,7 +449,7 @@ int egs_fused_backward_raw(int n, int sh_dim, int64_t patches, int width, int he
                            float* dloss_dscales_raw, float* dloss_drots_raw, float* dloss_dus,
                            const int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/,
                            const float* dcolor_dpws /*nullable*/, int phase, int row_begin, int row_count,
-                           void* stream);
+                           void* seg_ws /*nullable*/, size_t seg_ws_bytes, void* stream);
 /* The SH-coefficient gradient of a step from the factored form EGS_BWD_FACTORED_SH leaves:
  *     dloss_dshs[i][c][rgb] (+)= scale * sum_v  rows[v][3 i + rgb] * basis_c(pws[i] - twc_v)
  * rows: `views` rows of `row_stride` floats, row v = { dL/dcolour of view v [N][3], twc_v[3], padding } -- this rank's

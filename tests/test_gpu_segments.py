@@ -1,0 +1,147 @@
+"""Long tile lists split over several waves (include/egs_hip.h ``egs_splat_draw_rec_seg``; the reference spends 256
+threads on a tile, kernel.cu:152-271 -- here a tile is one wave64 and a long list is walked in segments).
+
+What is checked: the segment path -- every kind of work item (DIRECT tiles, SPEC segments blended from tau = 1 with the
+re-walk of the pixels that finish inside them, COMPOSE with sequential continuation) and the backward pass that walks
+every segment with a wave of its own -- gives the images, contributor counts, final transmittances and parameter
+gradients of the unsplit kernels (which the rest of the suite pins against the oracle), and the oracle's on sampled
+tiles including the longest list.  Small segments (64 / 128 entries) put dozens of segment boundaries into ordinary
+scenes; the heavy-tailed 1080p scene runs at the production setting."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from easygaussiansplatting_amd import scene as S
+from oracle import gs_oracle as O
+from tests.gradcheck import assert_grad_close
+
+pytestmark = pytest.mark.gpu
+
+torch = pytest.importorskip("torch")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from easygaussiansplatting_amd import _lib, fused, gsplatcu
+    gsplatcu.set_policy("gsplatcu")
+    lib = _lib.load()
+    before = (C.c_int * 2)()
+    _lib.check(lib.egs_seg_config(0, 0, before))
+    keep = fused.SEGMENTS
+    yield fused, lib
+    fused.SEGMENTS = keep
+    _lib.check(lib.egs_seg_config(before[0], before[1], None))
+
+
+def dev(a, dtype=np.float32):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype)).cuda()
+
+
+def host(t):
+    return t.detach().cpu().numpy()
+
+
+def run(fused, sc, cam, dl, renders=1):
+    """forward + backward of ``sc`` through GSFunction (fused); ``renders`` > 1: the same camera object again, so that
+    the later renders find the walk lengths of the earlier ones (SPEC items).  -> dict of the last render."""
+    from easygaussiansplatting_amd.function import GSFunction
+    GSFunction.mode = "fused"
+    out = None
+    for _ in range(renders):
+        P = dict(pws=dev(sc.pws), shs=dev(sc.shs), alphas=dev(sc.alphas).reshape(-1, 1), scales=dev(sc.scales),
+                 rots=dev(sc.rots))
+        for p in P.values():
+            p.requires_grad_(True)
+        us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+        image, mask = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+        image.backward(dl)
+        out = dict(image=host(image), grads={k: host(v.grad) for k, v in P.items()} | {"us": host(us0.grad)})
+    # the state of an identical render (same kernels): contrib / final_tau / lists
+    with torch.no_grad():
+        d = {k: v.detach() for k, v in P.items()}
+        img2, _, st = fused.forward(d["pws"], d["shs"], d["alphas"], d["scales"], d["rots"], cam, need_grad=True)
+    out.update(contrib=host(st.contrib), tau=host(st.final_tau), ranges=host(st.ranges), ids=host(st.gaussian_ids()),
+               image2=host(img2), seg=st.seg is not None)
+    return out
+
+
+def compare(a, b, label, flips=8, tol_max=1e-4):
+    """segment path ``a`` against the unsplit kernels ``b``: same lists; the image differs by the rounding of the
+    composed sum; a pixel may stop one entry earlier or later where T * tau_local straddles tau_stop (counted)."""
+    assert np.array_equal(a["ranges"], b["ranges"]) and np.array_equal(a["ids"], b["ids"])
+    d = np.abs(a["image"] - b["image"]).max(0)
+    flip = (a["contrib"] != b["contrib"])
+    assert flip.sum() <= flips, (label, int(flip.sum()))
+    assert d[~flip].max() < 2e-5 and d.max() < 2e-3, (label, d[~flip].max(), d.max())
+    assert np.abs(a["tau"] - b["tau"])[~flip].max() < 1e-5, label
+    assert np.abs(a["image2"] - a["image"]).max() < 1e-6, label       # (a later render of the same camera: SPEC items)
+    for k in a["grads"]:
+        # (the unsplit backward pass un-does tau by thousands of divisions from final_tau; a segment starts from the
+        # forward pass's own transmittance at its end: the two differ by that accumulated rounding, 6e-5 of the maximum
+        # on 3 000-entry lists of opacity 0.01)
+        assert_grad_close(a["grads"][k], b["grads"][k], label + ":" + k, tol_max=tol_max, med_rel=2e-5, max_rel=2e-3,
+                          outliers=max(2, flips))
+
+
+@pytest.mark.parametrize("seg_len,split_min", [(64, 64), (128, 200), (64, 500)])
+@pytest.mark.parametrize("reset", [False, True])
+def test_segments_equal_the_unsplit_kernels(fx, seg_len, split_min, reset):
+    """A dense 60 k scene on 320 x 240 (lists of up to a few thousand entries): every tile above ``split_min`` entries is
+    walked in segments of ``seg_len``.  ``reset``: every opacity at most 0.01 (nothing saturates: no re-walks, every
+    tile walks its whole list); otherwise most pixels finish somewhere inside a segment."""
+    fused, lib = fx
+    from easygaussiansplatting_amd import _lib
+    from easygaussiansplatting_amd.function import Camera
+    W, H = 320, 240
+    sc = S.small_scene(60_000, W, H, 12, seed=5)
+    sc.scales[:] = sc.scales * 2.2
+    if reset:
+        sc.alphas[:] = np.minimum(sc.alphas, 0.01)
+    dl = dev(S.normal(3, 21, (3, H, W)).astype(np.float32) / (3 * H * W))
+    fused.SEGMENTS = "0"
+    ref = run(fused, sc, Camera.from_scene(sc.cam), dl)
+    assert not ref["seg"]
+    lens = ref["ranges"][:, 1] - ref["ranges"][:, 0]
+    assert lens.max() > 4 * seg_len and (lens > split_min).sum() > 20, (lens.max(), (lens > split_min).sum())
+    fused.SEGMENTS = "1"
+    _lib.check(lib.egs_seg_config(seg_len, split_min, None))
+    for renders in (1, 3):       # first sight (COMPOSE walks the tile, the backward pass is split) / with history (SPEC)
+        got = run(fused, sc, Camera.from_scene(sc.cam), dl, renders)
+        assert got["seg"]
+        compare(got, ref, "seg%d/%d/%s/r%d" % (seg_len, split_min, "reset" if reset else "opaque", renders))
+
+
+def test_segments_skewed_scene_full_size(fx):
+    """scene.skewed_scene right after reset_alpha (1.5 M Gaussians, 1080p, lists up to ~13 600 entries, the longest
+    walk > 8 000) at the production setting: segment path == unsplit kernels over the whole image and all five
+    parameter gradients, and the oracle's blend on four tiles incl. the longest list."""
+    fused, lib = fx
+    from easygaussiansplatting_amd.function import Camera
+    sc = S.skewed_scene(reset_alpha=True)
+    W, H = sc.cam.width, sc.cam.height
+    dl = dev(S.normal(3, 22, (3, H, W)).astype(np.float32) / (3 * H * W))
+    fused.SEGMENTS = "0"
+    ref = run(fused, sc, Camera.from_scene(sc.cam), dl)
+    fused.SEGMENTS = "auto"
+    got = run(fused, sc, Camera.from_scene(sc.cam), dl, 2)
+    assert got["seg"]
+    lens = ref["ranges"][:, 1] - ref["ranges"][:, 0]
+    assert lens.max() > 10_000 and ref["contrib"].max() > 6_000
+    compare(got, ref, "skewed_reset", flips=64, tol_max=4e-4)   # (8 000 divisions in the unsplit pass: see compare)
+    # the oracle on the longest tile, its right neighbour and two others (float64 2D Gaussians of the oracle's own)
+    from tests.test_gpu_parity import _oracle_2d
+    o_us, o_ci, o_col, _, _ = _oracle_2d(sc, sc.cam)
+    tl = int(np.argmax(lens))
+    sel = np.array([tl, tl + 1, 0, lens.size // 2], np.int64)
+    o_img, o_cont, o_tau = O.draw(W, H, got["ranges"], got["ids"], o_us, o_ci, sc.alphas.astype(np.float64), o_col, None,
+                                  O.POLICY_G, tiles=sel)
+    gx = (W + 15) // 16
+    for t in sel:
+        ty, tx = divmod(int(t), gx)
+        ys = slice(ty * 16, min(ty * 16 + 16, H)); xs = slice(tx * 16, tx * 16 + 16)
+        d = np.abs(got["image"][:, ys, xs] - o_img[:, ys, xs]).max(0)
+        flip = got["contrib"][ys, xs] != o_cont[ys, xs]
+        assert flip.sum() <= 8 and d[~flip].max() < 1e-4, (t, int(flip.sum()), d.max())
