@@ -1008,7 +1008,12 @@ __device__ __forceinline__ int tile_len(const int32_t* __restrict__ ranges, cons
 }
 __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__ ranges,
                                                      const int32_t* __restrict__ work, int T, int gx, int mode,
-                                                     int period, int32_t* __restrict__ order, int ngrid) {
+                                                     int period, int32_t* __restrict__ order, int ngrid,
+                                                     const int32_t* __restrict__ walk = nullptr,
+                                                     uint32_t* __restrict__ hint = nullptr) {
+  // walk / hint (nullable): hint[1] receives the longest WALK of the camera's previous render (walk[T], next to its work),
+  // hint[0] the longest list when the tiles are sorted by length -- page-locked words the host steers by (fused.py: long
+  // walks take the segment path)
   // 8192 bins in all: one class of 8192 (global modes) or eight of 1024 (per-XCD modes).
   // ONE LDS atomic per tile: the returning add that counts a bin also hands the tile its rank inside the bin
   // (arrival order -- any order inside a bin will do); after the scan of the bins its slot is start + rank.
@@ -1032,6 +1037,24 @@ __global__ __launch_bounds__(1024) void k_tile_order(const int32_t* __restrict__
   for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
   if (per_xcd)   // classes are padded to the largest one: slots without a tile stay -1
     for (int i = tid; i < ngrid; i += 1024) order[i] = -1;
+  if (hint) {
+    int mx = 0;
+    if (walk) { for (int t = tid; t < T; t += 1024) mx = max(mx, walk[t]); }
+    else if (!work) {
+#pragma unroll
+      for (int r = 0; r < TO_REGS; ++r) mx = max(mx, lenr[r]);
+      for (int t = tid + TO_REGS * 1024; t < T; t += 1024) mx = max(mx, tile_len(ranges, work, t));
+    }
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+    if ((tid & 63) == 0) wsum[tid >> 6] = (uint32_t)mx;
+  }
+  __syncthreads();
+  if (hint && tid == 0 && (walk || !work)) {
+    uint32_t mx = 0u;
+    for (int w = 0; w < 16; ++w) mx = max(mx, wsum[w]);
+    hint[walk ? 1 : 0] = mx;
+  }
   __syncthreads();
   auto key_of = [&](int t, int len) {
     const int q = min(max(len, 0) >> shift, cbins - 1);
@@ -1237,6 +1260,7 @@ struct DrawParams {
   // k_draw only (nullable): per-tile work measure for the backward pass's dispatch order -- how far the tile
   // actually walked its list (early termination makes that 0.6 .. 1.0 of the list length, tile by tile)
   int32_t* work_out;
+  int32_t* walk_out;   // nullable, next to work_out: the largest contributor index of the tile (how far it was walked)
   // the list values carry the tile's 4-bit block mask in their high bits (culled lists of the fused path, k_bin_emit):
   // the kernels take it from there instead of testing the record's certain-miss box per entry
   int masked;
@@ -1355,7 +1379,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
   if (n <= 0) {  // empty tile: image = 0, contrib = 0 and final_tau = 0 (NOT 1), exactly what the
                  // reference's early return leaves in its zero-filled outputs (kernel.cu:182)
-    if (p.work_out && lane == 0) p.work_out[tile] = 0;
+    if (p.work_out && lane == 0) { p.work_out[tile] = 0; if (p.walk_out) p.walk_out[tile] = 0; }
     // a tile without patches still holds the (INT_MAX, 0) the binning initialised it with: (0, 0), as the reference
     if (lane == 0 && (r0 != 0 || r1 != 0)) { ranges[2 * (size_t)tile] = 0; ranges[2 * (size_t)tile + 1] = 0; }
     const size_t HW0 = (size_t)p.W * p.H;
@@ -1533,7 +1557,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
       w += mx;
       wmax = max(wmax, mx);
     }
-    if (lane == 0) p.work_out[tile] = w + 2 * wmax;
+    if (lane == 0) { p.work_out[tile] = w + 2 * wmax; if (p.walk_out) p.walk_out[tile] = wmax; }
   }
   const size_t HW = (size_t)p.W * p.H;
 #pragma unroll
@@ -1589,7 +1613,8 @@ constexpr int SEG_HDR = 16;          // header words: see SegLayout
 constexpr int SEG_SLOT_FLOATS = 256 * 6;
 constexpr uint32_t SEG_TILE_MASK = 0x7FFFFu, SEG_SEG_MASK = 0x7FFu;   // item = tile | seg << 19 | kind << 30
 constexpr int SEG_SPEC = 1, SEG_COMPOSE = 2;   // (0: a DIRECT item, the bare tile index)
-enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_ITEMSB = 5, SH_L = 6, SH_MIN = 7 };
+enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_ITEMSB = 5, SH_L = 6, SH_MIN = 7,
+       SH_HINT = 10 /* two words: the host's hint slot */ };
 struct SegArgs {
   int32_t* hdr;        // SEG_HDR words
   int32_t* seg_base;   // [T] first state slot of a split tile, -1: not split
@@ -1666,10 +1691,11 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
   constexpr int NB = 4096;
   __shared__ uint32_t bins[NB];
   __shared__ uint32_t wsum[16];
-  __shared__ int s_slots, s_n3, s_max;
+  __shared__ int s_slots, s_n3, s_max, s_mw;
   const int tid = threadIdx.x, lane = tid & 63;
+  int mw = 0;     // longest walk seen by this thread (forward: the previous render's; backward: this render's)
   for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
-  if (tid == 0) { s_slots = 0; s_n3 = 0; s_max = 0; }
+  if (tid == 0) { s_slots = 0; s_n3 = 0; s_max = 0; s_mw = 0; }
   if (backward) { L = a.hdr[SH_L]; split_min = a.hdr[SH_MIN]; }
   const int Ls = 31 - __clz(L);
   __syncthreads();
@@ -1700,6 +1726,11 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
         const bool split = t < T && n > split_min && nseg <= (int)SEG_SEG_MASK;
         if (split) { want += (uint32_t)nseg; nsp += 1u; }
         if (t < T) mx = max(mx, n);
+      }
+      if (hist) {
+#pragma unroll
+        for (int q = 0; q < SP_REGS; ++q)
+          if (t0 + q * 1024 + tid < T) mw = max(mw, hh[q]);
       }
       const uint32_t both = (want << 10) | nsp;                // (at most 512 split tiles per wave and round; < 2^22 slots)
       const uint32_t inc = wave_inclusive_scan(both);
@@ -1742,6 +1773,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
         else if (hist) est = min(max(hh[q], 0), n);
       } else if (valid) {
         const int w = min(max(hh[q], 0), n);
+        mw = max(mw, w);
         est = w;
         if (bb[q] >= 0) { cnt = (w + L - 1) >> Ls; est = min(w, L) + jitter(t); }
       }
@@ -1753,6 +1785,9 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       if (valid) { a.tmp[t] = (int32_t)packed; a.tmp2[t] = bb[q] >= 0 ? cnt : -1; }
     }
   }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mw = max(mw, __shfl_xor(mw, d, 64));
+  if (lane == 0 && mw > 0) atomicMax(&s_mw, mw);
   __syncthreads();
   {  // exclusive scan of the bins: thread t owns bins [4 t, 4 t + 4)
     uint32_t v[4], sum = 0u;
@@ -1807,9 +1842,14 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
       a.hdr[SH_MAXLEN] = s_max; a.hdr[SH_SPLIT] = s_n3; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
       a.hdr[SH_ITEMSB] = 0;
-      if (hint_host) hint_host[0] = (uint32_t)s_max;      // page-locked: the host peeks at it before a LATER render
+      // page-locked words the host peeks at before a LATER render: the longest list, and the longest walk of the
+      // camera's previous render (the backward plan overwrites it with this render's)
+      if (hint_host) { hint_host[0] = (uint32_t)s_max; if (hist) hint_host[1] = (uint32_t)s_mw; }
+      *reinterpret_cast<uint32_t**>(a.hdr + SH_HINT) = hint_host;
     } else {
       a.hdr[SH_ITEMSB] = min(total, a.item_cap);
+      uint32_t* hh_ = *reinterpret_cast<uint32_t**>(a.hdr + SH_HINT);
+      if (hh_) hh_[1] = (uint32_t)s_mw;
     }
   }
 }
@@ -2657,6 +2697,7 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
   p.zero_n4 = 0;
   p.zero_per = 0;
   p.work_out = nullptr;
+  p.walk_out = nullptr;
   p.masked = 0;
   p.hit_bits = nullptr;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
@@ -2675,7 +2716,8 @@ static int tile_order_mode(int which) {
   return mode[which];
 }
 static int tile_order_enqueue(DrawParams& p, int which, int32_t* buf, size_t buf_len,
-                              const int32_t* ranges, hipStream_t s, const int32_t* work = nullptr) {
+                              const int32_t* ranges, hipStream_t s, const int32_t* work = nullptr,
+                              const int32_t* walk = nullptr, uint32_t* hint = nullptr) {
   const int mode = tile_order_mode(which);
   if (mode <= 0 || !buf) return 0;
   const bool per_xcd = mode >= 3;
@@ -2683,7 +2725,8 @@ static int tile_order_enqueue(DrawParams& p, int which, int32_t* buf, size_t buf
   if ((size_t)ngrid > buf_len || p.T > TILE_ORDER_MAX_T) return 0;   // (larger images keep the plain map)
   static const int serp = [] { const char* e = getenv("EGS_TILE_SERP"); return e ? atoi(e) : 0; }();
   const int period = serp > 0 ? serp : (per_xcd ? 128 : 1024);   // SIMDs per XCD / per chip
-  EGS_LAUNCH("k_tile_order", k_tile_order, dim3(1), dim3(1024), s, ranges, work, p.T, p.gx, mode, period, buf, ngrid);
+  EGS_LAUNCH("k_tile_order", k_tile_order, dim3(1), dim3(1024), s, ranges, work, p.T, p.gx, mode, period, buf, ngrid,
+             walk, hint);
   EGS_LAUNCH_OK();
   p.order = buf;
   p.ngrid = ngrid;
@@ -3046,11 +3089,13 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     dp.order = tile_order;
     dp.ngrid = tile_order_mode(0) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
   } else {
+    // (prev_tile_work is the work part of a camera's own buffer: its walk part lies T ints behind it)
     rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
-                            patch_range_per_tile, s, prev_tile_work);
+                            patch_range_per_tile, s, prev_tile_work,
+                            (prev_tile_work && seg_hint) ? prev_tile_work + dp.T : nullptr, seg_hint);
     if (rc) return rc;
   }
-  if (tile_order) dp.work_out = tile_order + tile_order_len(dp.gx, dp.gy);
+  if (tile_order) { dp.work_out = tile_order + tile_order_len(dp.gx, dp.gy); dp.walk_out = dp.work_out + dp.T; }
   if (grad_records) {
     dp.zero_buf = (float4*)grad_records;
     dp.zero_n4 = (uint32_t)(3 * (size_t)n);

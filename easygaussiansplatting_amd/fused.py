@@ -218,10 +218,12 @@ def commit(device=None):
 
 
 def _seg_decision(ctx, lib, key, pol_):
-    """-> (use the segment path for this render, device-visible address of the hint slot or None).  The kernels of a
-    segment render leave the longest list of the render in a page-locked slot kept per problem size; a later render
-    looks at it WITHOUT waiting (it may be a render or two old -- it only selects between two exact paths): lists that
-    all fit the split threshold take the unsplit kernels (two launches less)."""
+    """-> (use the segment path for this render, device-visible address of the hint slot or None).  The draw stage
+    leaves two numbers in a page-locked slot kept per problem size -- the longest list, and the longest WALK (largest
+    contributor index of a tile) of a recent render -- and a later render looks at them WITHOUT waiting (they may be a
+    render or two old; they only select between two exact paths): a scene whose tiles are all walked for less than the
+    split threshold takes the unsplit kernels (three launches less), at first sight and from then on long walks take
+    the segment path."""
     if SEGMENTS == "0" or pol_.footprint != 0 or not (pol_.alpha_skip > 0) or not (pol_.tau_stop > 0):
         return False, None
     with ctx.lock:
@@ -235,9 +237,26 @@ def _seg_decision(ctx, lib, key, pol_):
     _lib.check(lib.egs_mailbox_peek(ctx.mb, slot, out))
     cfg = (C.c_int * 2)()
     _lib.check(lib.egs_seg_config(0, 0, cfg))
-    longest = int(out[0])
-    use = SEGMENTS == "1" or longest == 0xFFFFFFFF or longest > cfg[1]
+    walk = int(out[1])
+    use = SEGMENTS == "1" or walk == 0xFFFFFFFF or walk > cfg[1]
     return use, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot))
+
+
+def seg_hint(device=None, key=None):
+    """(longest list, longest walk) the draw stage last reported for problem size ``key`` = (N, W, H) on ``device``
+    (None: nothing yet / no slot) -- what ``_seg_decision`` steers by; for bench lines and tests."""
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    ctx = _contexts.get(index)
+    if ctx is None:
+        return None
+    with ctx.lock:
+        slot = ctx.seg_hint.get(key)
+    if slot is None:
+        return None
+    out = (C.c_uint32 * 4)()
+    _lib.check(ctx.lib.egs_mailbox_peek(ctx.mb, slot, out))
+    f = lambda v: None if v == 0xFFFFFFFF else int(v)
+    return f(out[0]), f(out[1])
 
 
 def _split_sh(low_shs, high_shs, n):
@@ -315,15 +334,12 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
         if use_seg:
             S.seg = torch.empty(lib.egs_seg_ws_bytes(max(patches, 1), W, H), dtype=torch.uint8, device=dev)
-            _lib.check(lib.egs_splat_draw_rec_seg(n, patches, None, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
-                                                  ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
-                                                  _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
-                                                  order_ready, draw_flags, _ptr(S.seg), S.seg.numel(), seg_hint, st))
-            return
-        _lib.check(lib.egs_splat_draw_rec(n, patches, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
-                                          ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
-                                          _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
-                                          order_ready, draw_flags, st))
+        # (seg_ws NULL: the unsplit kernels; the hint slot still learns how far this camera's tiles are walked)
+        _lib.check(lib.egs_splat_draw_rec_seg(n, patches, None, W, H, _ptr(S.rec), pol, _ptr(ws_bin), _ptr(ws_draw),
+                                              ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
+                                              _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
+                                              order_ready, draw_flags, _ptr(S.seg),
+                                              S.seg.numel() if S.seg is not None else 0, seg_hint, st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -345,7 +361,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     prev_work, order_ready = None, 0
     cache_entry = None        # registered only AFTER the draw stage that writes the order buffer was enqueued
     use_seg, seg_hint = _seg_decision(ctx, lib, key, pol_) if n > 0 else (False, None)
-    walk_known = False        # the camera's last render went through the segment path: its walk lengths are on record
+    walk_known = False        # the camera was rendered before: its walk lengths are on record
     if TILE_WORK_CACHE and n > 0:
         ck = (id(cam), int(st.value or 0))              # one entry per camera and stream, whatever the scene size
         olen = lib.egs_tile_order_len(W, H)
@@ -353,15 +369,18 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             hit = ctx.tile_work.get(ck)
             if hit is not None and hit[0]() is cam and hit[1].numel() == olen and hit[3] == (n, W, H):
                 S.order = hit[1]
-                renders = hit[2] + 1
-                walk_known = bool(hit[4])
-                if renders == 2 or renders % ORDER_REFRESH == 0:
-                    prev_work = C.c_void_p(S.order.data_ptr() + 4 * (olen - _tiles(W, H)))   # its own work part
-                else:
-                    order_ready = 1
+                # `renders` counts the renders that wrote the ORDER part (the segment path plans its own work items and
+                # leaves it alone; work and walk are written by both paths)
+                renders = hit[2] + (0 if use_seg else 1)
+                walk_known = True
+                if not use_seg:
+                    if renders <= 2 or renders % ORDER_REFRESH == 0:   # [order | work | walk]: its own work part
+                        prev_work = C.c_void_p(S.order.data_ptr() + 4 * (olen - 2 * _tiles(W, H)))
+                    else:
+                        order_ready = 1
             else:
                 S.order = torch.empty(olen, dtype=i32, device=dev)
-                renders = 1
+                renders = 0 if use_seg else 1
         cache_entry = (ck, renders)
     if S.order is None:
         S.order = torch.empty(lib.egs_tile_order_len(W, H), dtype=i32, device=dev)
@@ -386,7 +405,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         except TypeError:                               # a camera object that cannot be weakly referenced
             return
         with ctx.lock:
-            tw[ck] = (ref, S.order, renders, (n, W, H), use_seg)
+            tw[ck] = (ref, S.order, renders, (n, W, H))
     S.order_by_work = prev_work is not None or order_ready == 1
     draw_flags = (1 if S.culled else 0) | (SEG_HISTORY if (use_seg and walk_known) else 0)
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
@@ -436,16 +455,11 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, cap, W, H), dtype=torch.uint8, device=dev)
         if use_seg:
             S.seg = torch.empty(lib.egs_seg_ws_bytes(cap, W, H), dtype=torch.uint8, device=dev)
-            _lib.check(lib.egs_splat_draw_rec_seg(n, cap, _ptr(total), W, H, _ptr(S.rec), pol, _ptr(ws_bin),
-                                                  _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
-                                                  _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
-                                                  _ptr(S.gpack), prev_work, order_ready, draw_flags, _ptr(S.seg),
-                                                  S.seg.numel(), seg_hint, st))
-        else:
-            _lib.check(lib.egs_splat_draw_rec_dev(n, cap, _ptr(total), None, W, H, _ptr(S.rec), pol, _ptr(ws_bin),
-                                                  _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
-                                                  _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
-                                                  _ptr(S.gpack), prev_work, order_ready, draw_flags, st))
+        _lib.check(lib.egs_splat_draw_rec_seg(n, cap, _ptr(total), W, H, _ptr(S.rec), pol, _ptr(ws_bin),
+                                              _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
+                                              _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
+                                              _ptr(S.gpack), prev_work, order_ready, draw_flags, _ptr(S.seg),
+                                              S.seg.numel() if S.seg is not None else 0, seg_hint, st))
     except BaseException:
         # Whatever was enqueued before the failure (the arm, the binning chain) still stores {P, max key} into the
         # slot: it goes back on the free list only once those kernels have run -- otherwise a render on another

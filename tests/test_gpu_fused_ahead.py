@@ -161,6 +161,14 @@ def test_tile_dispatch_order_is_a_sorted_permutation():
     args, cam = _scene(20000, 640, 368, 4)
     T = (640 // 16) * (368 // 16)
     snaps, imgs = [], []
+    keep_seg, fused.SEGMENTS = fused.SEGMENTS, "0"           # (the segment path plans its own work items: test_gpu_segments)
+    try:
+        _order_protocol(fused, args, cam, T, snaps, imgs)
+    finally:
+        fused.SEGMENTS = keep_seg
+
+
+def _order_protocol(fused, args, cam, T, snaps, imgs):
     with torch.no_grad():
         for rep in range(fused.ORDER_REFRESH + 1):
             img, _, st = fused.forward(*args, cam)
@@ -171,18 +179,23 @@ def test_tile_dispatch_order_is_a_sorted_permutation():
             assert st.order_by_work == (rep > 0)
             prev = st.order
     lens = (st.ranges[:, 1] - st.ranges[:, 0]).cpu().numpy()
+    wk = lambda buf: buf[len(buf) - 2 * T:len(buf) - T]      # [order | work | walk]
+    cont = st.contrib.cpu().numpy()
+    gx = 640 // 16
+    walked = np.array([cont[(t // gx) * 16:(t // gx) * 16 + 16, (t % gx) * 16:(t % gx) * 16 + 16].max() for t in range(T)])
     for rep, buf in enumerate(snaps):
-        order, work = buf[:T], buf[-T:]
+        order, work = buf[:T], wk(buf)
         assert np.array_equal(np.sort(order), np.arange(T))
         assert (work >= 0).all() and (work[lens == 0] == 0).all() and work.max() <= 6 * lens.max()
-        np.testing.assert_array_equal(work, snaps[0][-T:])   # same image, same work
+        np.testing.assert_array_equal(work, wk(snaps[0]))    # same image, same work
+        np.testing.assert_array_equal(buf[-T:], walked)      # the walk part: the tile's largest contributor index
         np.testing.assert_array_equal(imgs[rep], imgs[0])
     assert (np.diff(lens[snaps[0][:T]]) <= 0).all()          # first render: by list length
     by_work = snaps[1][:T]                                   # second render: by the first one's work, bins of 4
-    assert (np.diff((snaps[0][-T:] // 4)[by_work]) <= 0).all()
+    assert (np.diff((wk(snaps[0]) // 4)[by_work]) <= 0).all()
     for rep in range(2, fused.ORDER_REFRESH + 1):
         if (rep + 1) % fused.ORDER_REFRESH == 0:             # refreshed (ties may land in another sequence)
-            assert (np.diff((snaps[0][-T:] // 4)[snaps[rep][:T]]) <= 0).all()
+            assert (np.diff((wk(snaps[0]) // 4)[snaps[rep][:T]]) <= 0).all()
         else:                                                # kept as it stands
             np.testing.assert_array_equal(snaps[rep][:T], snaps[rep - 1][:T])
     other = torch.cuda.Stream()                              # another stream: its own buffer
