@@ -36,11 +36,31 @@ def host(t):
     return t.detach().cpu().numpy()
 
 
-# Fused path against the float64 oracle at 1 M / 1080p: the device's 2D Gaussians are float32 -- pixel coordinates of
-# O(1000) carry 6e-5 px, 2-3e-5 of a weight for a Gaussian of sigma ~ 2.7 px: median relative error 1.6-2e-5 measured
-# (profiles/r4_grad_errors.jsonl), the largest entry off by up to 2.1e-4 of the tensor's maximum (dL/dscale).  The
-# seven-op path fed the device's OWN 2D Gaussians sits at 3e-7 and keeps the default rule.
-FUSED_1M_TOL = dict(tol_max=5e-4, med_rel=1e-4, max_rel=5e-3, near_frac=0.05)
+# Threshold-flip Gaussians of the like-for-like comparisons (oracle stages in float32): numpy's float32 and the kernels'
+# differ in the order of their roundings, so a Gaussian within 3e-4 (relative) of the alpha' >= 0.002 test may sit on the
+# other side of it for some pixel (measured at 1.5e-4: one of 124 k large dL/dpw entries at 7.6e-3, an unflagged flip).
+# 2-3 % of the Gaussians with a gradient are that close for SOME pixel of some tile (15 428 of 659 825 over all tiles of
+# view 0; 46 of 1 536 in ring view 2's windows): they are compared too, by the loose bound of assert_grad_close_flips.
+# Everything else passes the default rule with NO outliers.  (The seven-op comparisons, fed the device's own 2D
+# Gaussians, use the oracle's default margin 1e-4 and near_frac 0.02.)
+LIKE_MARGIN = 3e-4
+LIKE_NEAR_FRAC = 0.035
+
+
+def record_grad_error(name, got, ref, near=None):
+    """A stated-precision MEASUREMENT, never a gate: the numbers of tests/gradcheck.report appended to the file
+    EGS_GRAD_STATS names (profiles/r5_grad_errors.jsonl was collected this way), nothing otherwise."""
+    import json
+    import os
+    from tests.gradcheck import report
+    path = os.environ.get("EGS_GRAD_STATS")
+    if not path:
+        return
+    got = np.asarray(got, np.float64); ref = np.asarray(ref, np.float64)
+    if near is not None:
+        got, ref = got[~np.asarray(near, bool)], ref[~np.asarray(near, bool)]
+    with open(path, "a") as f:
+        f.write(json.dumps(dict(name=str(name), measurement_only=True, **report(got, ref))) + "\n")
 
 
 def window_tiles(gx, gy, cx, cy, w=6, h=4):
@@ -705,22 +725,26 @@ def test_full_size_policy_g_sampled_tiles_and_invariants(gsc, big):
         assert r["n_big"] > 100, r
 
 
-def _oracle_2d(sc, cam, rows=None, calc_J=False):
-    """The oracle's per-Gaussian stages (float64, policy G) for all Gaussians or for ``rows``."""
+def _oracle_2d(sc, cam, rows=None, calc_J=False, dtype=np.float64):
+    """The oracle's per-Gaussian stages (policy G) for all Gaussians or for ``rows``.  ``dtype=np.float32``: the stages
+    evaluated in the DEVICE's precision (the fused path keeps its 2D Gaussians in float32: a pixel coordinate of
+    O(1000) carries 6e-5 px) -- what a like-for-like gradient comparison feeds the oracle's float64 blend; the results
+    come back as float64 arrays holding float32 values."""
     sel = slice(None) if rows is None else rows
     P = O.POLICY_G
-    out = O.project(sc.pws[sel], cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P, calc_J)
+    f64 = lambda a: np.asarray(a, np.float64)
+    out = O.project(sc.pws[sel], cam.Rcw, cam.tcw, cam.fx, cam.fy, cam.cx, cam.cy, P, calc_J, dtype)
     us, pcs, depths = out[:3]
-    c3 = O.compute_cov3d(sc.rots[sel], sc.scales[sel], depths, P, calc_J)
+    c3 = O.compute_cov3d(sc.rots[sel], sc.scales[sel], depths, P, calc_J, dtype)
     c2 = O.compute_cov2d(c3[0] if calc_J else c3, pcs, cam.Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, P,
-                         calc_J)
-    col = O.sh2color(sc.shs[sel], sc.pws[sel], cam.twc, calc_J)
-    ci = O.inverse_cov2d((c2[0] if calc_J else c2), depths.copy(), P, calc_J)
+                         calc_J, dtype)
+    col = O.sh2color(sc.shs[sel], sc.pws[sel], cam.twc, calc_J, dtype)
+    ci = O.inverse_cov2d((c2[0] if calc_J else c2), depths.copy(), P, calc_J, dtype)
     if not calc_J:
-        return us, ci[0], col, depths, ci[1]
+        return f64(us), f64(ci[0]), f64(col), f64(depths), ci[1]
     J = dict(du_dpcs=out[3], dcov3d_drots=c3[1], dcov3d_dscales=c3[2], dcov2d_dcov3ds=c2[1], dcov2d_dpcs=c2[2],
              dcolor_dshs=col[1], dcolor_dpws=col[2], dcinv2d_dcov2ds=ci[2])
-    return us, ci[0], col[0], depths, J
+    return f64(us), f64(ci[0]), f64(col[0]), f64(depths), {k: f64(v) for k, v in J.items()}
 
 
 def check_culled_lists(st, tiles, us, cinv2ds, alphas, depths32, rects, width, skip=0.002):
@@ -821,21 +845,32 @@ def test_full_size_fused_and_raw_paths(gsc, big):
     assert nflip <= 12, nflip                                          # threshold flips (fp32 vs fp64 2D Gaussians)
     # gradients: the Gaussians complete inside three contiguous windows of tiles (centre, ragged bottom row, longest
     # list) -- thousands; the oracle's 2D Gaussians are float64, the device's float32: wider threshold margin
+    # LIKE FOR LIKE: the device keeps its 2D Gaussians in float32, so the oracle's blend (float64) and chain rule are fed
+    # the oracle's stages evaluated in float32 -- the comparison then passes the DEFAULT rule of tests/gradcheck.py
+    # (2e-4 of the maximum, median 1e-4: the reference's own 1e-4 `check`, backward_cpu.py:61-65, made relative).  The
+    # float64 stages are compared too, as a stated-precision measurement (EGS_GRAD_STATS), not as the gate.
     sub = gradient_windows(rg, gx, (H + 15) // 16)
-    near = np.zeros(sc.n, bool)
-    o_g2 = O.draw_backward(W, H, rg, gs, o_us, o_ci, alphas64, o_col, hcont, htau, dl.astype(np.float64), None,
-                           O.POLICY_G, tiles=sub, near_out=near, near_margin=3e-4)
     full = complete_inside(gs, rg, sub, sc.n)
     assert full.size > 2000, full.size
-    _, _, _, _, J = _oracle_2d(sc, sc.cam, full, True)
-    g = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], sc.cam.Rcw, J)
-    want = dict(pws=g["dpws"], shs=g["dshs"], alphas=g["dalphas"][:, None], scales=g["dscales"], rots=g["drots"],
-                us=o_g2[0][full])
     got = {k: host(v.grad)[full] for k, v in P.items()} | {"us": host(us0.grad)[full]}
-    for k in want:
-        assert got[k].shape == want[k].shape, k
-        r = assert_grad_close_flips(got[k], want[k], near[full], "full_size_fused:" + k, **FUSED_1M_TOL)
-        assert r["n_big"] > 100, (k, r)
+    for dtype, gate in ((np.float32, True), (np.float64, False)):
+        q_us, q_ci, q_col, _, _ = (o_us, o_ci, o_col, None, None) if dtype is np.float64 else \
+            _oracle_2d(sc, sc.cam, dtype=dtype)
+        near = np.zeros(sc.n, bool)
+        o_g2 = O.draw_backward(W, H, rg, gs, q_us, q_ci, alphas64, q_col, hcont, htau, dl.astype(np.float64), None,
+                               O.POLICY_G, tiles=sub, near_out=near, near_margin=LIKE_MARGIN if gate else 3e-4)
+        _, _, _, _, J = _oracle_2d(sc, sc.cam, full, True, dtype)
+        g = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], sc.cam.Rcw, J)
+        want = dict(pws=g["dpws"], shs=g["dshs"], alphas=g["dalphas"][:, None], scales=g["dscales"], rots=g["drots"],
+                    us=o_g2[0][full])
+        for k in want:
+            assert got[k].shape == want[k].shape, k
+            if gate:
+                r = assert_grad_close_flips(got[k], want[k], near[full], "full_size_fused_f32_stages:" + k,
+                                            near_frac=LIKE_NEAR_FRAC)
+                assert r["n_big"] > 100, (k, r)
+            else:
+                record_grad_error("full_size_fused_f64_stages:" + k, got[k], want[k], near[full])
     # --- raw path at the same size: activations inside the kernels == torch activations around the fused path
     a = torch.from_numpy(sc.alphas.astype(np.float32)).clamp(1e-4, 1 - 1e-4)
     raw = dict(pws=dev(sc.pws), low_shs=dev(sc.shs[:, :3]), high_shs=dev(sc.shs[:, 3:]),
@@ -1044,17 +1079,17 @@ def test_full_size_every_gaussian_every_tile_gradients(gsc, big):
     us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
     img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, camt)
     img.backward(dev(dl))
-    o_us, o_ci, o_col, o_depths, J = _oracle_2d(sc, cam, None, True)
+    # like for like (see test_full_size_fused_and_raw_paths): the oracle's stages in the device's float32, its blend and
+    # chain rule in float64 -- the DEFAULT rule, no outliers
+    o_us, o_ci, o_col, o_depths, J = _oracle_2d(sc, cam, None, True, np.float32)
     o = draw_backward_tiles(W, H, host(st.ranges), host(st.gaussian_ids()), o_us, o_ci, sc.alphas.astype(np.float64), o_col,
-                            host(st.contrib), host(st.final_tau), dl.astype(np.float64), near_margin=3e-4)
+                            host(st.contrib), host(st.final_tau), dl.astype(np.float64), near_margin=LIKE_MARGIN)
     og = O.chain_rule(o[0], o[1], o[2], o[3], cam.Rcw, J)
     want = dict(pws=og["dpws"], shs=og["dshs"], alphas=og["dalphas"][:, None], scales=og["dscales"], rots=og["drots"],
                 us=o[0])
     got = {k: host(v.grad) for k, v in P.items()} | {"us": host(us0.grad)}
     for k in want:
-        # (measured: 6 of 1.5 M large dL/dsh entries and 1 of 134 k dL/dscale entries beyond 5e-3, largest 7.9e-3:
-        # Gaussians on a threshold the 3e-4 margin does not flag; at most 1e-5 of the large entries may be such)
-        r = assert_grad_close_flips(got[k], want[k], o[4], "all_tiles_fused:" + k, outliers=1e-5, **FUSED_1M_TOL)
+        r = assert_grad_close_flips(got[k], want[k], o[4], "all_tiles_fused_f32_stages:" + k, near_frac=LIKE_NEAR_FRAC)
         assert r["n_big"] > 20000, (k, r)
 
 

@@ -29,7 +29,7 @@ from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
 from tests.conftest import load_golden
 from tests.gradcheck import assert_grad_close_flips
-from tests.test_gpu_parity import (FUSED_1M_TOL, _oracle_2d, check_against_g11, check_culled_lists, complete_inside,
+from tests.test_gpu_parity import (LIKE_MARGIN, LIKE_NEAR_FRAC, _oracle_2d, check_against_g11, check_culled_lists, complete_inside,
                                    dev, gradient_windows, host)
 
 pytestmark = pytest.mark.gpu
@@ -144,16 +144,20 @@ def test_eight_ring_views_full_size():
         assert full.size > 500, (v, full.size)
         dl64 = host(dls[v]).astype(np.float64)
         near = np.zeros(sc.n, bool)
-        o_g2 = O.draw_backward(W, H, rg, gs, o_us, o_ci, alphas64, o_col, hcont, htau, dl64, None, O.POLICY_G,
-                               tiles=sub, near_out=near, near_margin=3e-4)
-        _, _, _, _, J = _oracle_2d(sc, cnp, full, True)
+        # like for like (tests/test_gpu_parity.py::test_full_size_fused_and_raw_paths): the oracle's stages in the
+        # device's float32, its blend and chain rule in float64 -- the default rule of tests/gradcheck.py
+        q_us, q_ci, q_col, _, _ = _oracle_2d(sc, cnp, dtype=np.float32)
+        o_g2 = O.draw_backward(W, H, rg, gs, q_us, q_ci, alphas64, q_col, hcont, htau, dl64, None, O.POLICY_G,
+                               tiles=sub, near_out=near, near_margin=LIKE_MARGIN)
+        _, _, _, _, J = _oracle_2d(sc, cnp, full, True, np.float32)
         og = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], cnp.Rcw, J)
         want = dict(pws=og["dpws"], shs=og["dshs"], alphas=og["dalphas"][:, None], scales=og["dscales"],
                     rots=og["drots"], us=o_g2[0][full])
         got = {k: host(g[k])[full] for k in NAMES} | {"us": host(dus)[full]}
         for k in want:
             assert got[k].shape == want[k].shape, (v, k)
-            r = assert_grad_close_flips(got[k], want[k], near[full], "ring_view%d:%s" % (v, k), **FUSED_1M_TOL)
+            r = assert_grad_close_flips(got[k], want[k], near[full], "ring_view%d_f32_stages:%s" % (v, k),
+                                        near_frac=LIKE_NEAR_FRAC)
             assert r["n_big"] > 50, (v, k, r)
     # the views really are different workloads
     assert len({s[0] for s in stats}) == N_VIEWS, stats
