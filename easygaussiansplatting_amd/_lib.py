@@ -21,7 +21,8 @@ class EgsPolicy(C.Structure):
     _fields_ = [("near_cull", C.c_int32), ("fov_mode", C.c_int32), ("det_eps", C.c_float),
                 ("nan_cull", C.c_int32), ("radius_mode", C.c_int32), ("footprint", C.c_int32),
                 ("far_cull", C.c_int32), ("maha_floor", C.c_int32), ("alpha_clamp", C.c_int32),
-                ("alpha_skip", C.c_float), ("tau_stop", C.c_float), ("depth_key", C.c_int32)]
+                ("alpha_skip", C.c_float), ("tau_stop", C.c_float), ("depth_key", C.c_int32),
+                ("nan_maha", C.c_int32)]
 
 
 class EgsGaussianParams(C.Structure):

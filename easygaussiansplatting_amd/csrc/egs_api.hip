@@ -296,6 +296,7 @@ extern "C" void egs_policy_gsplatcu(EgsPolicy* p) {
   p->alpha_skip = 0.002f;
   p->tau_stop = 0.0001f;
   p->depth_key = 0;
+  p->nan_maha = 0;
 }
 
 // forward_cpu.py semantics (reference gsplat/gausplat.py).
@@ -312,4 +313,5 @@ extern "C" void egs_policy_forward_cpu(EgsPolicy* p) {
   p->alpha_skip = 0.f;
   p->tau_stop = 0.f;
   p->depth_key = 1;
+  p->nan_maha = 1;     // (numpy's exp(-0.5 * NaN) is NaN: gausplat.py has no defined result there; NaN pixels are skipped)
 }

@@ -1249,6 +1249,7 @@ struct DrawParams {
   float alpha_skip, tau_stop;
   float lskip;   // log2(alpha_skip), -inf when there is no skip test
   int maha_floor, alpha_clamp;
+  int nan_blend;  // EgsPolicy.nan_maha == 0: an entry whose conic or centre holds a NaN blends at min(0.99, alpha) everywhere
   int map_mode;  // 0: tile = block; 1: contiguous band per XCD; 2: tile rows interleaved over XCDs
   // longest-list-first dispatch (k_tile_order): workgroup b draws tile order[b] (-1: padding) when set
   const int32_t* order;
@@ -1348,6 +1349,20 @@ __device__ __forceinline__ int reach_mask(const float4& A, const float4& C, int 
          ((int)(okx[1] && oky[1]) << 3);
 }
 
+// CUDA's max(0.0f, NaN) == 0 (kernel.cu:243-246, 909-913): a Mahalanobis term that is NaN counts as 0 and the Gaussian
+// blends at min(0.99, alpha).  A NaN in the conic or the centre of an entry makes EVERY pixel's term NaN, so the lane that
+// stages the entry decides it once: conic := 0, centre := 0 -- the exponent is then log2(alpha) everywhere (forward) and
+// the power 0 (backward).  Per entry, 64 entries in parallel, nothing in the blend loops.  (A NaN that arises at single
+// pixels from inf * 0 is not covered: EgsPolicy.nan_maha.)
+__device__ __forceinline__ bool nan_entry_fix(float4& A, float4& B) {
+  if (A.x != A.x || A.y != A.y || A.z != A.z || A.w != A.w || B.x != B.x) {
+    A = make_float4(0.f, 0.f, 0.f, 0.f);
+    B.x = 0.f;
+    return true;
+  }
+  return false;
+}
+
 // min(x, hi) as ONE v_med3_f32 (fminf() costs a canonicalising v_max + v_min in IEEE mode; the
 // low bound is finite so the compiler cannot fold the median back into a min)
 __device__ __forceinline__ float min_hi(float x, float hi) {
@@ -1439,10 +1454,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
     const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
     if (base + 64 + lane < n) gnext = gsid[r0 + base + 64 + lane];
     if (base + lane < n) {
-      const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+      float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1];
+      const float4 C = rec[3 * (size_t)g + 2];
+      const bool nanfix = p.nan_blend && nan_entry_fix(A, B);
       // the record's thr = log2(skip / alpha), +inf for an entry that never blends (alpha < skip, or
       // alpha < 0 when there is no skip test): such an entry reaches nothing
       if (C.w < INFINITY) mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<BOX>(A, C, tx0, ty0);
+      if (nanfix && !BOX && !p.masked && C.w < INFINITY) mymask = 0xF;
       // alpha' = exp2(e), e = log2(alpha) + log2 exp(-maha/2) (F.5.1, common.cuh:85-88, pre-scaled conic):
       // no multiply by alpha; the floor (maha >= 0) and the 0.99 clamp are ONE min against `cap`
       const float la = SKIP ? lskip - C.w : __builtin_amdgcn_logf(B.y);
@@ -2042,7 +2060,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
       const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
       if (base + 64 + lane < e1) gnext = gsid[r0 + base + 64 + lane];
       if (base + lane < e1) {
-        const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+        float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1];
+        const float4 C = rec[3 * (size_t)g + 2];
+        if (p.nan_blend) nan_entry_fix(A, B);
         if (C.w < INFINITY) mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<false>(A, C, tx0, ty0);
         const float la = lthr - C.w;
         float cap = 3.0e38f;
@@ -2438,8 +2458,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     const int g = p.masked ? (int)((uint32_t)gm & EGS_GSID_MASK) : gm;
     if (c > c_last) gnext = gsid[r0 + idx - 64];
     if (idx < n) {
-      const float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1], C = rec[3 * (size_t)g + 2];
+      float4 A = rec[3 * (size_t)g], B = rec[3 * (size_t)g + 1];
+      const float4 C = rec[3 * (size_t)g + 2];
+      constexpr float INVQ = 1.f / EGS_NHL2E;
+      // (cinv from the record as it is: an entry with a NaN conic hands NaN to du = -cinv M1, as kernel.cu:926-933 does)
+      const float4 Dc = make_float4(A.z * INVQ, A.w * (0.5f * INVQ), B.x * INVQ, __int_as_float(g));
+      const bool nanfix = p.nan_blend && nan_entry_fix(A, B);
       mymask = p.masked ? (int)((uint32_t)gm >> EGS_GSID_BITS) : reach_mask<BOX>(A, C, tx0, ty0);
+      if (nanfix && !BOX && !p.masked) mymask = 0xF;
 #if EGS_PROBE_HIT_BITS   // (measurement builds only: even this wave-uniform test cost the production kernel two spilled registers)
       if (p.hit_bits) {
         const uint32_t gi = (uint32_t)(r0 + idx);
@@ -2451,8 +2477,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
       sC[lane] = C;
       // cinv back out of the pre-scaled conic of the record (q = -0.5 log2(e) (cinv.x, 2 cinv.y, cinv.z)):
       // no second 12-B gather per patch (131 MB of sector traffic at P = 4.1 M)
-      constexpr float INVQ = 1.f / EGS_NHL2E;
-      sD[lane] = make_float4(A.z * INVQ, A.w * (0.5f * INVQ), B.x * INVQ, __int_as_float(g));
+      sD[lane] = Dc;
     }
     __syncthreads();
     // Which entries of this chunk can contribute at all?  Every lane answers for the entry it staged: its
@@ -2703,6 +2728,7 @@ static DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool back
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;
   p.maha_floor = pol->maha_floor; p.alpha_clamp = pol->alpha_clamp;
+  p.nan_blend = pol->nan_maha == 0 && pol->maha_floor;
   return p;
 }
 

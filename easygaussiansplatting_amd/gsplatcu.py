@@ -49,16 +49,19 @@ def _pol() -> EgsPolicy:
 def set_policy(name: str) -> None:
     """Select which of the reference's pipeline definitions the ops follow:
     ``"gsplatcu"`` (gsplatcu/kernel.cu; default) or ``"forward_cpu"``
-    (gsplat/gausplat.py as driven by forward_cpu.py)."""
+    (gsplat/gausplat.py as driven by forward_cpu.py).  ``"gsplatcu_nan_skip"``: the default with one opt-in
+    deviation -- a Gaussian whose conic holds a NaN is skipped instead of blended at min(0.99, alpha) (the CUDA
+    extension's ``max(0.0f, NaN) == 0``, kernel.cu:243-246): no NaN colour can reach the image."""
     global _policy, _policy_name
     lib = _lib.load()
     p = EgsPolicy()
-    if name == "gsplatcu":
+    if name in ("gsplatcu", "gsplatcu_nan_skip"):
         lib.egs_policy_gsplatcu(C.byref(p))
+        p.nan_maha = 1 if name == "gsplatcu_nan_skip" else 0
     elif name == "forward_cpu":
         lib.egs_policy_forward_cpu(C.byref(p))
     else:
-        raise ValueError("unknown raster policy %r (expected 'gsplatcu' or 'forward_cpu')" % (name,))
+        raise ValueError("unknown raster policy %r (expected 'gsplatcu', 'gsplatcu_nan_skip' or 'forward_cpu')" % (name,))
     _policy, _policy_name = p, name
 
 

@@ -58,6 +58,10 @@ typedef struct EgsPolicy {
   float alpha_skip;    /* skip alpha' < 0.002                              (kernel.cu:246)            */
   float tau_stop;      /* pixel done when tau < 1e-4                       (kernel.cu:256)            */
   int32_t depth_key;   /* 0: uint32(depth*1000) (kernel.cu:73)  1: raw fp32 bits (== argsort, gausplat.py:192) */
+  int32_t nan_maha;    /* 0: a Gaussian whose conic or centre holds a NaN blends at min(0.99, alpha) into every pixel of
+                          its tiles -- CUDA's max(0.0f, NaN) == 0 (kernel.cu:243-246, 909-913); 1: such pixels are
+                          skipped (no NaN ever reaches the image).  Either way a NaN that arises at single pixels from
+                          inf * 0 is skipped (oracle/gs_oracle.py NAN_MAHA)                                    */
 } EgsPolicy;
 
 void egs_policy_gsplatcu(EgsPolicy* p);

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Fixture G10: the NaN-Mahalanobis case (reference gsplatcu/kernel.cu:243-246), where this build DELIBERATELY
-deviates from the CUDA extension.
+"""Fixture G10: the NaN-Mahalanobis case (reference gsplatcu/kernel.cu:243-246).  Since round 5 the build's default
+follows the CUDA extension for a Gaussian whose conic HOLDS a NaN (EgsPolicy.nan_maha = 0, oracle mode "entry"); what
+is left of the deviation is the inf * 0 pixel column of an infinite conic, and the opt-in "skip" policy.
 
     float maha_dist = max(0.0f, mahaSqDist(cinv, d));              // CUDA: max(0.f, NaN) == 0.f
     float alpha_prime = min(0.99f, alpha * exp(-0.5f * maha_dist)); //  -> min(0.99, alpha): the Gaussian BLENDS
@@ -32,7 +33,7 @@ colors = np.array([[0.9, 0.2, 0.1], [0.1, 0.8, 0.3], [0.2, 0.3, 0.9], [0.5, 0.5,
 depths = np.array([2.0, 1.0, 1.5, 3.0], np.float32)
 areas = np.array([[12, 14], [5, 9], [9, 9], [13, 10]], np.int32)
 out = dict(width=W, height=H, us=us, cinv2ds=cinv, alphas=alphas, colors=colors, depths=depths, areas=areas)
-for mode in ("skip", "cuda"):
+for mode in ("skip", "entry", "cuda"):
     O.NAN_MAHA = mode
     with np.errstate(all="ignore"):
         img, cont, tau, ranges, gsid = O.splat(H, W, us, cinv, alphas.astype(np.float64), depths.copy(), colors,
@@ -42,12 +43,15 @@ for mode in ("skip", "cuda"):
     out["tau_" + mode] = tau.astype(np.float32)
 O.NAN_MAHA = "skip"
 out["ranges"] = ranges; out["gsid"] = gsid
-assert np.isfinite(out["image_skip"]).all() and np.isfinite(out["image_cuda"]).all()
+assert all(np.isfinite(out["image_" + m]).all() for m in ("skip", "entry", "cuda"))
 d = np.abs(out["image_skip"] - out["image_cuda"]).max(0)
-print("pixels that differ:", int((d > 1e-6).sum()), "of", W * H, "max", d.max())
+print("pixels that differ, skip vs cuda:", int((d > 1e-6).sum()), "of", W * H, "max", d.max())
+d = np.abs(out["image_entry"] - out["image_cuda"]).max(0)
+print("pixels that differ, entry vs cuda:", int((d > 1e-6).sum()), "columns", np.unique(np.nonzero(d > 1e-6)[1]))
 O.NAN_MAHA = "cuda"
 from tests.golden import _recipe   # noqa: E402
 _recipe.begin("--check" in sys.argv[1:])
 _recipe.save("g10_nan_conic.npz", "G10: oracle/gs_oracle.py splat on four 2D Gaussians, two of them with a non-finite "
-             "conic: NAN_MAHA = 'skip' (this build) and 'cuda' (fmaxf(0, NaN) = 0, kernel.cu:243-246)", **out)
+             "conic: NAN_MAHA = 'cuda' (fmaxf(0, NaN) = 0, kernel.cu:243-246), 'entry' (the build's default: the same for the "
+             "NaN conic, the inf conic's inf * 0 pixels skipped) and 'skip' (opt-in policy gsplatcu_nan_skip)", **out)
 sys.exit(_recipe.finish())

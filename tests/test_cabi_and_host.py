@@ -59,14 +59,14 @@ def test_no_torch_or_python_dependency_in_the_shared_library():
 
 def test_policy_struct_layout_and_presets(lib):
     from easygaussiansplatting_amd._lib import EgsPolicy
-    assert C.sizeof(EgsPolicy) == 48
+    assert C.sizeof(EgsPolicy) == 52
     g = EgsPolicy(); lib.egs_policy_gsplatcu(C.byref(g))
     assert (g.near_cull, g.fov_mode, g.nan_cull, g.radius_mode, g.footprint, g.maha_floor, g.alpha_clamp,
-            g.depth_key) == (1, 0, 1, 0, 0, 1, 1, 0)
+            g.depth_key, g.nan_maha) == (1, 0, 1, 0, 0, 1, 1, 0, 0)
     assert abs(g.alpha_skip - 0.002) < 1e-9 and abs(g.tau_stop - 1e-4) < 1e-10 and g.det_eps == 0
     a = EgsPolicy(); lib.egs_policy_forward_cpu(C.byref(a))
     assert (a.near_cull, a.fov_mode, a.nan_cull, a.radius_mode, a.footprint, a.far_cull, a.maha_floor,
-            a.alpha_clamp, a.depth_key) == (0, 1, 0, 1, 1, 1, 0, 1, 1)
+            a.alpha_clamp, a.depth_key, a.nan_maha) == (0, 1, 0, 1, 1, 1, 0, 1, 1, 1)
     assert abs(a.det_eps - 1e-6) < 1e-12 and a.alpha_skip == 0 and a.tau_stop == 0
     # the oracle's policies are the same two rows of SURVEY §8a-R0
     from oracle import gs_oracle as O

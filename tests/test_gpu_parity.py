@@ -634,29 +634,45 @@ def test_fused_culled_lists_all_rect_sizes_vs_oracle(gsc):
     assert not np.isin(ids, np.arange(140, 200)).any()       # alpha < alpha_skip: emitted for no tile
 
 
-def test_nan_conic_is_skipped_not_blended(gsc):
-    """Fixture G10 (tests/golden/make_golden_nan.py): Gaussians whose conic holds inf / NaN -- every Mahalanobis term
-    they produce is NaN.  The CUDA extension's ``max(0.0f, NaN) == 0`` makes them blend at min(0.99, alpha)
-    (kernel.cu:243-246); this build skips them in ``splat`` AND ``splatB``: the image is the one of the two finite
-    Gaussians alone, every gradient is finite, the two degenerate Gaussians receive none.  DELIBERATE deviation."""
+def test_nan_conic_blends_like_the_cuda_extension(gsc):
+    """Fixture G10 (tests/golden/make_golden_nan.py): Gaussians whose conic holds inf / NaN.  The CUDA extension's
+    ``max(0.0f, NaN) == 0`` makes a NaN Mahalanobis term count as 0: the Gaussian blends at min(0.99, alpha)
+    (kernel.cu:243-246, 909-913).  Default policy (EgsPolicy.nan_maha = 0): the Gaussian with a NaN IN its conic does
+    exactly that in ``splat`` and ``splatB`` -- the image is the fixture's ``image_entry``, which equals the CUDA
+    arithmetic (``image_cuda``) everywhere except the one pixel column where the INFINITE conic of the other degenerate
+    Gaussian meets inf * 0 (skipped here: the remaining, documented difference).  ``set_policy("gsplatcu_nan_skip")``:
+    the opt-in that keeps every NaN pixel out (``image_skip``)."""
     g = load_golden("g10_nan_conic.npz")
     W, H = int(g["width"]), int(g["height"])
-    gsc.set_policy("gsplatcu")
     us, ci, al, col = dev(g["us"]), dev(g["cinv2ds"]), dev(g["alphas"]), dev(g["colors"])
-    depths, areas = dev(g["depths"]), dev(g["areas"], np.int32)
-    image, contrib, tau, ranges, gsid = gsc.splat(H, W, us, ci, al, depths, col, areas)
-    assert np.array_equal(host(ranges), g["ranges"]) and np.array_equal(host(gsid), g["gsid"])
-    him = host(image)
-    assert np.isfinite(him).all()
-    assert np.abs(him - g["image_skip"]).max() < 1e-5 and np.array_equal(host(contrib), g["contrib_skip"])
-    assert np.abs(host(tau) - g["tau_skip"]).max() < 1e-5
-    # ... and that IS a deviation from the reference's arithmetic: the CUDA result differs on every pixel of both tiles
-    assert (np.abs(him - g["image_cuda"]).max(0) > 1e-3).mean() > 0.9
     dl = dev(S.normal(4, 4, (3, H, W)).astype(np.float32))
-    grads = gsc.splatB(H, W, us, ci, al, depths, col, contrib, tau, ranges, gsid, dl)
-    for t in grads:
-        t = host(t).reshape(4, -1)
-        assert np.isfinite(t).all() and not t[1].any() and not t[2].any() and t[0].any() and t[3].any()
+    try:
+        for policy, tag in (("gsplatcu", "entry"), ("gsplatcu_nan_skip", "skip")):
+            gsc.set_policy(policy)
+            depths, areas = dev(g["depths"]), dev(g["areas"], np.int32)
+            image, contrib, tau, ranges, gsid = gsc.splat(H, W, us, ci, al, depths, col, areas)
+            assert np.array_equal(host(ranges), g["ranges"]) and np.array_equal(host(gsid), g["gsid"])
+            him = host(image)
+            assert np.isfinite(him).all()
+            assert np.abs(him - g["image_" + tag]).max() < 1e-5 and np.array_equal(host(contrib), g["contrib_" + tag])
+            assert np.abs(host(tau) - g["tau_" + tag]).max() < 1e-5
+            d = np.abs(him - g["image_cuda"]).max(0)
+            if tag == "entry":       # the reference's arithmetic but for the inf * 0 column of the infinite conic (u.x = 20)
+                assert set(np.nonzero(d > 1e-5)[1]) == {20} and (d > 1e-5).sum() <= H
+            else:                    # ... and the skip policy IS a deviation: it differs on every pixel of both tiles
+                assert (d > 1e-3).mean() > 0.9
+            grads = [host(t).reshape(4, -1) for t in gsc.splatB(H, W, us, ci, al, depths, col, contrib, tau, ranges,
+                                                                gsid, dl)]
+            for t in grads:          # the two finite Gaussians: finite, non-zero; the infinite conic blends nowhere
+                assert np.isfinite(t[[0, 3]]).all() and t[0].any() and t[3].any() and not t[1].any()
+            dus, dcinv, dalpha, dcolor = grads
+            if tag == "entry":       # the NaN conic: dalpha / dcolor / dcinv as kernel.cu:921-945 (g = 1), du = -cinv M1 is NaN
+                assert np.isfinite(dalpha[2]).all() and dalpha[2].any() and np.isfinite(dcolor[2]).all() and dcolor[2].any()
+                assert np.isfinite(dcinv[2]).all() and np.isnan(dus[2]).any()
+            else:
+                assert not any(t[2].any() for t in grads)
+    finally:
+        gsc.set_policy("gsplatcu")
     # the fused path never sees such conics (its 2D Gaussians come from its own preprocess kernel, where a NaN
     # determinant culls the Gaussian, kernel.cu:300-305)
 

@@ -246,12 +246,13 @@ def test_g7_gau_loss_and_gradient(tag):
 
 
 def test_g10_nan_conic_semantics():
-    """Fixture G10: a NaN Mahalanobis term is SKIPPED by this build's definition (oracle NAN_MAHA = "skip") where the
-    CUDA extension's max(0.f, NaN) = 0 blends the Gaussian at min(0.99, alpha) (kernel.cu:243-246, NAN_MAHA = "cuda")."""
+    """Fixture G10: the CUDA extension's max(0.f, NaN) = 0 blends a Gaussian with a NaN Mahalanobis term at
+    min(0.99, alpha) (kernel.cu:243-246, NAN_MAHA = "cuda"); the build's default does the same for a NaN IN the conic
+    and skips the inf * 0 pixels of an infinite one ("entry"); the opt-in policy skips every NaN pixel ("skip")."""
     g = load_golden("g10_nan_conic.npz")
     W, H = int(g["width"]), int(g["height"])
     try:
-        for mode in ("skip", "cuda"):
+        for mode in ("skip", "entry", "cuda"):
             O.NAN_MAHA = mode
             with np.errstate(all="ignore"):
                 img, cont, tau, ranges, gsid = O.splat(H, W, g["us"], g["cinv2ds"], g["alphas"].astype(np.float64),
@@ -266,3 +267,6 @@ def test_g10_nan_conic_semantics():
     assert np.abs(img2 - g["image_skip"]).max() < 1e-6
     # cuda: Gaussian 2 (NaN conic, alpha 0.5, in front of 0 and 3) tints EVERY pixel of both tiles
     assert (np.abs(g["image_cuda"] - g["image_skip"]).max(0) > 1e-3).all()
+    # entry == cuda but for the pixel column through the centre of the infinite conic (u.x = 20: inf * 0)
+    d = np.abs(g["image_entry"] - g["image_cuda"]).max(0)
+    assert set(np.nonzero(d > 1e-6)[1]) == {20}
