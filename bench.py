@@ -287,7 +287,7 @@ def main():
     import torch.distributed as dist
     from easygaussiansplatting_amd import _lib, scene as S
     from easygaussiansplatting_amd import gsplatcu as gsc
-    from easygaussiansplatting_amd.function import Camera, GSFunction, render
+    from easygaussiansplatting_amd.function import Camera, GSFunction, RenderOptions, render
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -319,7 +319,6 @@ def main():
 
     lib = _lib.load()
     gsc.set_policy("gsplatcu")
-    GSFunction.mode = a.mode
     from easygaussiansplatting_amd import dist_views as DV
     from easygaussiansplatting_amd import fused as fused_path
 
@@ -386,34 +385,46 @@ def main():
             p.grad = None
         for u in us_v:
             u.grad = None
+        # what every render of the step carries (function.RenderOptions: per call, no process-wide switch): gradients
+        # of further views added inside the chain-rule kernel, the SH gradient left factored in fx_v
+        o = RenderOptions(mode=a.mode, accumulate=True, sh_sink=fx_v)
+        if fx_v is not None:
+            fx_v.begin_step(sc.n, dev)      # (rows allocated on this stream, before the lanes fork)
         vs_v.begin()
-        with fused_path.accumulate_in_kernel(), (fx_v.attach() if fx_v is not None else contextlib.nullcontext()):
-            for i, c in enumerate(cams_v):
-                with vs_v.lane(i) as lv:
-                    image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_v[vs_v.lane_index(i)], c)
-                    image.backward(dl_v)
+        for i, c in enumerate(cams_v):
+            with vs_v.lane(i) as lv:
+                image, mask = GSFunction.apply(lv[0], lv[1], lv[2], lv[3], lv[4], us_v[vs_v.lane_index(i)], c, o)
+                image.backward(dl_v)
         vs_v.finish()
         if fx_v is not None and not (exchange and fx_v is fx):   # (the step's own sink under an exchange: finished
             fx_v.finish(params["pws"], params["shs"])            # there, it is a collective)
         return image
 
-    def render_step():
-        if vs is not None:
+    def render_step(mode=None, records=True):
+        """``mode`` / ``records``: the seven-op legs of the run (function.RenderOptions of THEIR calls; the headline's
+        stay ``a.mode``)"""
+        if vs is not None and mode is None:
             return render_views(my_cams, vs, us_lane, dl, fx)
         for p in params.values():
             p.grad = None
         for u in us_lane:
             u.grad = None
         # V views: forward + backward each; from the second view on the chain-rule kernel adds this view's gradients
-        # to the leaves' .grad itself (fused.accumulate_in_kernel) instead of autograd accumulating fresh tensors
-        with (fused_path.accumulate_in_kernel() if (V > 1 and a.mode == "fused") else contextlib.nullcontext()), \
-                (fx.attach() if fx is not None else contextlib.nullcontext()):
-            for c in my_cams:
-                image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
-                                               params["rots"], us0, c)
-                image.backward(dl)
-        if fx is not None and not exchange:
-            fx.finish(params["pws"], params["shs"])
+        # to the leaves' .grad itself instead of autograd accumulating fresh tensors
+        m = mode or a.mode
+        sink = fx if (m == "fused") else None
+        o = RenderOptions(mode=m, ops_use_records=records, accumulate=(V > 1 and m == "fused"), sh_sink=sink,
+                          exchange=overlap if (m == "fused" and sink is None) else None)
+        if sink is not None:
+            sink.begin_step(sc.n, dev)
+        if o.exchange is not None:
+            o.exchange.begin_step()
+        for c in my_cams:
+            image, mask = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
+                                           params["rots"], us0, c, o)
+            image.backward(dl)
+        if sink is not None and not exchange:
+            sink.finish(params["pws"], params["shs"])
         return image
 
     def step(timing=False):
@@ -427,8 +438,7 @@ def main():
                 redone[0] += 1
                 image = render_step()
         else:
-            with (overlap.attach() if overlap is not None else contextlib.nullcontext()):
-                image = render_step()
+            image = render_step()
         if timing:
             e1 = torch.cuda.Event(enable_timing=True); e1.record()
         if exchange:  # gradient exchange: 59 floats per Gaussian, SUM then mean
@@ -588,31 +598,28 @@ def main():
     # chain-rule kernel over the stored Jacobians) -- an extra, outside the timed region
     ops_ms, ops_kernels, ops_public_ms = None, None, None
     if a.mode == "fused" and not a.no_ops and rank == 0 and world == 1:
-        GSFunction.mode = "ops"
         for _ in range(8):        # (the first calls allocate the Jacobian tensors and learn the patch capacity)
-            render_step()
+            render_step("ops")
         torch.cuda.synchronize()
         to0 = time.perf_counter()
         for _ in range(40):
-            render_step()
+            render_step("ops")
         torch.cuda.synchronize()
         ops_ms = (time.perf_counter() - to0) / 40 * 1e3 / V      # per view
         # the same step WITHOUT the records handle: the public splat / splatB pair as an unmodified reference
         # GSFunction (gsmodel.py:6-93) calls it -- splatB packs its own records and walks the plain list
-        GSFunction.ops_use_records = False
         for _ in range(4):
-            render_step()
+            render_step("ops", records=False)
         torch.cuda.synchronize()
         to0 = time.perf_counter()
         for _ in range(40):
-            render_step()
+            render_step("ops", records=False)
         torch.cuda.synchronize()
         ops_public_ms = (time.perf_counter() - to0) / 40 * 1e3 / V
-        GSFunction.ops_use_records = True
         if prof:      # per-kernel table of the seven-op step (event-bracketed, outside the timing above)
             lib.egs_prof_set_filter(None); lib.egs_prof_reset(); lib.egs_prof_enable(1)
             for _ in range(3):
-                render_step()
+                render_step("ops")
             torch.cuda.synchronize()
             lib.egs_prof_enable(0)
             orep = read_report()
@@ -626,7 +633,6 @@ def main():
                     row["algorithmic_GBs"] = round(ab / (tot / c * 1e-3) / 1e9, 1)
                     row["frac_of_hbm_peak"] = round(ab / (tot / c * 1e-3) / 1e9 / HBM_PEAK_GBS, 3)
                 ops_kernels[k] = row
-        GSFunction.mode = a.mode
         for p in params.values():
             p.grad = None
         torch.cuda.empty_cache()

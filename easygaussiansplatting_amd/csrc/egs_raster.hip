@@ -1173,7 +1173,9 @@ static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
 // exponent test alone).  k_draw_bwd needs no flag: it walks `kept` either way, and what it walks is the caller's list.
 __global__ __launch_bounds__(256) void k_pair_fix(int64_t P, uint32_t* __restrict__ kept,
                                                   const int32_t* __restrict__ plain,
-                                                  const uint8_t* __restrict__ same) {
+                                                  const uint8_t* __restrict__ same, uint32_t n) {
+  // n: Gaussians (same[] has one byte per 256 of them): a list value beyond it -- a stale or foreign gsid tensor of the
+  // right length -- is never looked up; the entry degrades to the all-blocks mask like any other mismatch
   const int64_t p0 = 4 * ((int64_t)blockIdx.x * 256 + threadIdx.x);
   if (p0 >= P) return;
   uint32_t k[4], q[4];
@@ -1189,7 +1191,8 @@ __global__ __launch_bounds__(256) void k_pair_fix(int64_t P, uint32_t* __restric
   bool changed = false;
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
-    const bool good = (k[t] & EGS_GSID_MASK) == q[t] && same[(q[t] & EGS_GSID_MASK) >> 8] != 0;
+    const uint32_t gid = q[t] & EGS_GSID_MASK;
+    const bool good = (k[t] & EGS_GSID_MASK) == q[t] && gid < n && same[gid >> 8] != 0;
     if (!good) { k[t] = (q[t] & EGS_GSID_MASK) | (0xFu << EGS_GSID_BITS); changed = true; }
   }
   if (changed) {
@@ -3422,7 +3425,7 @@ extern "C" int egs_pack_records_validate(int n, int width, int height, const flo
              pol->alpha_skip, us, cinv2ds, alphas, colors, (const int32_t*)nullptr, (float4*)rec, stamp_b, stamp_a, same);
   if (patches > 0)
     EGS_LAUNCH("k_pair_fix", k_pair_fix, dim3(div_up(patches, 1024)), dim3(256), s, patches, (uint32_t*)kept, plain,
-               (const uint8_t*)same);
+               (const uint8_t*)same, (uint32_t)n);
   EGS_LAUNCH_OK();
   return 0;
 }

@@ -136,6 +136,11 @@ class ChunkedExchange:
                 fused._exchange_hook = prev
         return cm()
 
+    def begin_step(self):
+        """Start a step without ``attach()`` (a caller that names this object in its ``RenderOptions``)."""
+        self.backwards = 0
+        return self
+
     def begin_backward(self):
         """Called by ``fused.backward`` before it hands over the first chunk."""
         self.backwards += 1
@@ -292,6 +297,21 @@ class FactoredShGrad:
             finally:
                 fused._sh_sink = prev
         return cm()
+
+    def begin_step(self, n: Optional[int] = None, device=None):
+        """Start a step without ``attach()`` (a caller that names this object in its ``RenderOptions``): no row is
+        taken yet.  ``n`` / ``device``: allocate the row buffer NOW, on the caller's stream, before its views fork
+        onto side streams -- allocated lazily by the first backward pass it would come from the caching allocator on
+        whichever lane runs first, and a faster lane could write into a block the main stream's still-queued kernels
+        use."""
+        with self._lock:
+            self._next = 0
+            if n is not None and (self.rows is None or self.n != n or
+                                  (device is not None and self.rows.device != torch.device(device))):
+                self.rows = torch.empty((self.views, self.row_stride(n)), dtype=torch.float32,
+                                        device=device if device is not None else "cuda")
+                self.n = n
+        return self
 
     def restart(self):
         """Forget the rows of the step so far (the step is rendered again)."""

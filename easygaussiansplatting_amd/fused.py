@@ -538,29 +538,35 @@ def _engine_accumulates_into(node_ctx, count):
         return False
 
 
-def sh_sink_for(node_ctx, count, sh_tensors):
+DEFAULT = object()       # "no per-call choice": the process-wide attach() state applies
+
+
+def sh_sink_for(node_ctx, count, sh_tensors, explicit=None):
     """The attached ``dist_views.FactoredShGrad`` when the running backward pass may leave its SH gradient there: the
     SH inputs are leaves (``finish`` writes their ``.grad``; behind a torch ``cat`` the rows are needed here) and the
     engine accumulates into the node's ``count`` leaves (a ``.backward()`` of a training step -- never under
     ``torch.autograd.grad``, whose caller expects the rows returned)."""
-    sink = _sh_sink
+    # explicit = (sink, exchange) of the call's RenderOptions; None: whatever is attached process-wide
+    sink, hook = (_sh_sink, _exchange_hook) if explicit is None else explicit
     if sink is None or not all(t.is_leaf and t.requires_grad for t in sh_tensors) or \
             not _engine_accumulates_into(node_ctx, count):
         return None
-    if _exchange_hook is not None:
+    if hook is not None:
         raise RuntimeError("FactoredShGrad and ChunkedExchange cannot be attached together (the overlapped exchange "
                            "all-reduces the SH rows the factored form never writes)")
     return sink
 
 
-def accumulation_targets(leaves, node_ctx=None, count=None):
+def accumulation_targets(leaves, node_ctx=None, count=None, explicit=None):
     """The ``.grad`` tensors of ``leaves`` when the coming backward may add to them in place (see
     ``accumulate_in_kernel``), else None.  ``node_ctx``: the autograd node whose backward is running -- the in-kernel
     accumulation is only taken when the engine itself would accumulate into every leaf (never under
     ``torch.autograd.grad``, whose callers expect returned tensors and an untouched ``.grad``).  ``count``: how many
     inputs of the node are differentiated leaves (default ``len(leaves)``; larger when ``leaves`` leaves the SH
     tensors out because their gradient goes to a ``FactoredShGrad``)."""
-    if not getattr(_acc_flag, "on", False) or _exchange_hook is not None:
+    # explicit = (accumulate, exchange) of the call's RenderOptions; None: the process-wide block / attach() state
+    on, hook = (getattr(_acc_flag, "on", False), _exchange_hook) if explicit is None else explicit
+    if not on or hook is not None:
         return None
     if node_ctx is not None and not _engine_accumulates_into(node_ctx, len(leaves) if count is None else count):
         return None
@@ -577,7 +583,7 @@ def accumulation_targets(leaves, node_ctx=None, count=None):
 
 
 def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, high_shs=None, accumulate=None,
-             sh_sink=None):
+             sh_sink=None, exchange=DEFAULT):
     """-> (dloss_dpws[N,3], dloss_dshs[N,K], dloss_dalphas[N,1], dloss_dscales[N,3],
            dloss_drots[N,4], dloss_dus[N,2])  -- the gradient tuple of gsmodel.py:87-93.
     With ``high_shs`` (raw tensors, see ``forward``): -> (dpws, dlow_shs[N,3], dhigh_shs[N,K-3],
@@ -666,7 +672,7 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
         keep |= ACCUMULATE            # the outputs hold earlier views' gradients: add to them
     if sh_sink is not None:
         keep |= FACTORED_SH
-    hook = _exchange_hook
+    hook = _exchange_hook if exchange is DEFAULT else exchange      # (``exchange``: the call's own ChunkedExchange or None)
     if hook is not None and sh_sink is not None:
         raise RuntimeError("fused.backward: sh_sink and an attached ChunkedExchange exclude each other")
     chunks = hook.chunks if hook is not None else 1

@@ -285,14 +285,17 @@ def _alphas(alphas, n):
 #     Gaussian lies in a block with a different stamp becomes the caller's entry with all four blocks set.  No pointer
 #     or version is compared: a write through ``tensor.data``, another library's kernel, other tensors with the same
 #     values -- all handled by what the VALUES are.  The order buffer (any permutation is correct) and the cleared
-#     gradient records (data-independent, handed out once) need no validation.  ``set_memo(False)`` switches the
-#     keeping off (~80 MB per (device, stream) at 1 M Gaussians until the next splat).
+#     gradient records (data-independent, handed out once) need no validation.  OPT-IN since round 5
+#     (``set_memo(True)``): it is worth 1 % of a seven-op step (1.147-1.150 against 1.159 ms) and costs ~80 MB per
+#     (device, stream) at 1 M Gaussians of module-global state that a drop-in's callers know nothing about; at most
+#     ``MEMO_MAX`` (device, stream) entries are kept, the least recently used goes first.
 #   * the explicit HANDLE for a caller that OWNS the tensors between the two calls: ``splat_with_records`` returns a
 #     ``SplatRecords`` and ``splatB(..., records=handle)`` takes it back -- this package's GSFunction (mode "ops") does
 #     that with its own intermediates (us / cinv2ds / colors never leave the autograd node) and skips both the re-pack
 #     and the validation (21 + 10 us); the handle is checked by (data_ptr, _version, shape), policy, size and stream.
-_memo_enabled = True
-_splat_memo = {}
+_memo_enabled = False
+_splat_memo = {}        # (device, stream) -> SplatRecords, in order of last use
+MEMO_MAX = 8
 MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's list values (egs_splat_bin_pack)
 
 
@@ -310,7 +313,7 @@ class SplatRecords:
 
 
 def set_memo(on: bool) -> None:
-    """Switch the content-validated keeping of the public ``splat`` -> ``splatB`` pair on (default) or off."""
+    """Switch the content-validated keeping of the public ``splat`` -> ``splatB`` pair on or off (default: off)."""
     global _memo_enabled
     _memo_enabled = bool(on)
     if not on:
@@ -381,10 +384,11 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     out, h = _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep="public" if _memo_enabled else False)
     if _memo_enabled:
         key = (us.device.index, int(_stream().value or 0))
+        _splat_memo.pop(key, None)          # (an older entry must not outlive its splat; re-inserted = most recent)
         if h is not None:
             _splat_memo[key] = h
-        else:
-            _splat_memo.pop(key, None)      # (nothing kept this time: an older entry must not outlive its splat)
+            while len(_splat_memo) > MEMO_MAX:      # streams that are gone, one-off renders: least recently used first
+                _splat_memo.pop(next(iter(_splat_memo)))
     return out
 
 

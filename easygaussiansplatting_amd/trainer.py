@@ -33,7 +33,7 @@ import torch.distributed as dist
 from . import dist_views as DV
 from . import fused as _fused
 from .density import DensityControl, expon_lr
-from .function import Camera, GSFunction, GSRawFunction
+from .function import Camera, GSFunction, GSRawFunction, RenderOptions
 from .loss import gau_loss, gau_loss_with_grad
 from .optim import FusedAdam, adam_groups
 from .scene import gsdata_type
@@ -76,8 +76,13 @@ def make_optimizer(p, fused=True):
 class Trainer:
     def __init__(self, scene, cameras: Sequence, gt_images: Sequence[torch.Tensor], max_steps: int,
                  scene_size: float = 1.0, device="cuda", fused_adam: bool = True, seed: int = 0,
-                 fused_activations: bool = True, view_streams: int = 4, factored_sh: bool = True):
+                 fused_activations: bool = True, view_streams: int = 4, factored_sh: bool = True, mode: str = "fused"):
         self.device = device
+        # how THIS trainer's renders are evaluated (function.RenderOptions.mode; "ops" needs fused_activations=False):
+        # carried by every call, never by a process-wide switch -- two trainers in one process may differ
+        self.mode = mode
+        if mode != "fused" and fused_activations:
+            raise ValueError("Trainer(mode=%r) needs fused_activations=False (GSRawFunction is the fused path)" % (mode,))
         # a rank's views of a step go round-robin to this many HIP streams (dist_views.ViewStreams); 1 = one after
         # the other on the caller's stream
         self.view_streams = max(1, int(view_streams))
@@ -114,7 +119,7 @@ class Trainer:
         u.grad = None
         return u
 
-    def _render_views(self, mine, n_views):
+    def _render_views(self, mine, n_views, opts=None):
         """forward + loss + backward of this rank's views; leaves accumulate the mean over ALL views of the step.
         Two or more views: dealt to ``view_streams`` HIP streams (one gradient accumulator and one set of
         statistics per stream, added up at the end)."""
@@ -140,9 +145,9 @@ class Trainer:
                 us = self._us_leaf(k, n)                                             # gsmodel.py:198-199
                 if self.fused_activations:
                     image, mask = GSRawFunction.apply(p["pws"], p["low_shs"], p["high_shs"], p["alphas_raw"],
-                                                      p["scales_raw"], p["rots_raw"], us, self.cams[v])
+                                                      p["scales_raw"], p["rots_raw"], us, self.cams[v], opts)
                 else:
-                    image, mask = GSFunction.apply(*activate(p), us, self.cams[v])
+                    image, mask = GSFunction.apply(*activate(p), us, self.cams[v], opts)
                 # loss / n_views (train.py:52-57 with the mean over the step's views): the loss kernels produce the
                 # scaled dL/dimage themselves, backward starts at the image
                 stats, dimage = gau_loss_with_grad(image.detach(), self.gts[v], grad_scale=1.0 / n_views)
@@ -190,16 +195,20 @@ class Trainer:
             if self._fx is None or self._fx.views != vmax:
                 self._fx = DV.FactoredShGrad(vmax)
             fx = self._fx
-        with _fused.accumulate_in_kernel(), (fx.attach() if fx is not None else contextlib.nullcontext()):
-            with _fused.deferred() as d:
-                loss_sum, gnorm, count = self._render_views(mine, len(view_ids))
-                incomplete = d.commit()
-            if incomplete:
-                self.redone_steps += 1
-                self.opt.zero_grad(set_to_none=True)
-                if fx is not None:
-                    fx.restart()
-                loss_sum, gnorm, count = self._render_views(mine, len(view_ids))   # validated render by render
+        # every render of the step carries its own options (no process-wide switch): gradients of further views are
+        # added inside the chain-rule kernel, the SH gradient goes to this trainer's own FactoredShGrad
+        opts = RenderOptions(mode=self.mode, accumulate=True, sh_sink=fx)
+        if fx is not None:     # (rows allocated here, on the caller's stream, before the views fork onto their lanes)
+            fx.begin_step(self.params["pws"].shape[0], self.params["pws"].device)
+        with _fused.deferred() as d:
+            loss_sum, gnorm, count = self._render_views(mine, len(view_ids), opts)
+            incomplete = d.commit()
+        if incomplete:
+            self.redone_steps += 1
+            self.opt.zero_grad(set_to_none=True)
+            if fx is not None:
+                fx.restart()
+            loss_sum, gnorm, count = self._render_views(mine, len(view_ids), opts)   # validated render by render
         others = self.params
         sh_rows = None
         if fx is not None:   # (a collective when world > 1; the loss already carries 1 / views: a SUM over ranks)

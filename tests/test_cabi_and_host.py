@@ -196,3 +196,21 @@ def test_bench_relaunches_itself_under_the_launcher_for_several_gpus():
     # and the launcher really accepts that command line (parse only: --help of torch.distributed.run)
     out = subprocess.run(cmd[:3] + ["--help"], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "--nproc-per-node" in out.stdout.replace("_", "-")
+
+
+def test_public_pair_memo_is_opt_in():
+    """The content-validated ``splat`` -> ``splatB`` memo (module-global state in a drop-in) is OFF unless a caller asks
+    for it, and bounded when on (VERDICT r4 #8, ADVICE r4)."""
+    from easygaussiansplatting_amd import gsplatcu
+    assert gsplatcu._memo_enabled is False and gsplatcu._splat_memo == {} and gsplatcu.MEMO_MAX == 8
+
+
+def test_render_options_validate_and_default():
+    from easygaussiansplatting_amd.function import GSFunction, RenderOptions
+    o = RenderOptions()
+    assert (o.mode, o.ops_use_records, o.accumulate, o.sh_sink, o.exchange) == ("fused", True, False, None, None)
+    assert GSFunction.mode == "fused"
+    with pytest.raises(ValueError):
+        RenderOptions(mode="cuda")
+    with pytest.raises(ValueError):
+        RenderOptions(sh_sink=object(), exchange=object())
