@@ -54,6 +54,9 @@ __device__ __forceinline__ TileAt tile_at(int t, int gx, int gy, int H, int W) {
 #ifndef EGS_LOSS_XCD_BANDS
 #define EGS_LOSS_XCD_BANDS 1
 #endif
+// (Eight XCDs and the b % 8 dispatch are MI355X's -- this library is built for gfx950 only, csrc/Makefile.  The walk is
+// CORRECT for any mapping of workgroups to dies: on a part with another die count the bands would merely stop matching
+// the L2s, i.e. fall back to what the strided walk did.)
 struct TileWalk { int t, end, step; };
 __device__ __forceinline__ TileWalk tile_walk(int ntiles) {
   const int b = blockIdx.x, G = gridDim.x;

@@ -632,6 +632,10 @@ def backward(pws, shs, alphas, scales, rots, cam, S: FusedState, dloss_dgammas, 
             pk = (dev, n, tuple(widths))
             idx = _pad_index.get(pk)
             if idx is None:
+                # (one index tensor per device and layout: a densifying trainer changes N every few epochs, and the
+                # entries of the sizes it left behind would pile up)
+                for old in [q for q in _pad_index if q[0] == dev and q[2] == pk[2]]:
+                    del _pad_index[old]
                 idx = _pad_index[pk] = torch.tensor(pad, dtype=torch.int64, device=dev)
             flat.index_fill_(0, idx, 0.0)
         parts = [flat[a:a + n * w].view(n, w) for a, w in zip(starts, widths)]

@@ -54,27 +54,21 @@ class FusedAdam:
         for a mean over ranks, 1 for a sum) -- the SH tensors (``.grad`` None) are then updated by
         ``egs_adam_sh_factored``, which forms each Gaussian's gradient row in LDS instead of reading it from memory."""
         lib = _lib.load()
-        recs = []
-        keep = []          # keeps contiguous gradient copies alive until the launch is enqueued
+        # 1. validate EVERYTHING first: nothing of the optimizer's state may move for a step that is then refused (a
+        #    bumped ``step`` without an update would leave wrong bias corrections behind: ADVICE r4)
+        plain, keep = [], []      # keep: contiguous gradient copies, alive until the launch is enqueued
         for g in self.param_groups:
             for p in g["params"]:
                 if p.grad is None:
                     continue
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise ValueError("FusedAdam needs contiguous float32 device parameters")
-                st = self.state.get(p)
-                if st is None:
-                    st = self.state[p] = {"step": 0, "exp_avg": torch.zeros_like(p), "exp_avg_sq": torch.zeros_like(p)}
-                st["step"] = int(st["step"]) + 1
                 grad = p.grad.contiguous()
                 keep.append(grad)
-                recs.append(_lib.EgsAdamGroup(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
-                                              st["exp_avg_sq"].data_ptr(), p.numel(), float(g["lr"]), st["step"]))
-        stream = torch.cuda.current_stream().cuda_stream
+                plain.append((p, grad, float(g["lr"])))
+        sh = []
         if factored_sh is not None:
             rows, scale, pws, low, high = factored_sh
-            n = pws.shape[0]
-            groups = []
             for t in ((low, high) if (high is not None and high.shape[1] > 0) else (low,)):
                 if t.grad is not None:
                     raise ValueError("FusedAdam.step(factored_sh=...): an SH tensor already holds a .grad")
@@ -83,18 +77,40 @@ class FusedAdam:
                 lrs = [float(g["lr"]) for g in self.param_groups if any(q is t for q in g["params"])]
                 if len(lrs) != 1:
                     raise ValueError("FusedAdam.step(factored_sh=...): an SH tensor that is not in exactly one group")
-                lr = lrs[0]
-                st = self.state.get(t)
-                if st is None:
-                    st = self.state[t] = {"step": 0, "exp_avg": torch.zeros_like(t), "exp_avg_sq": torch.zeros_like(t)}
-                st["step"] = int(st["step"]) + 1
-                groups.append(_lib.EgsAdamGroup(t.data_ptr(), None, st["exp_avg"].data_ptr(),
-                                                st["exp_avg_sq"].data_ptr(), t.numel(), lr, st["step"]))
-            K = low.shape[1] + (high.shape[1] if high is not None else 0)
-            _lib.check(lib.egs_adam_sh_factored(
-                n, K, rows.shape[0], pws.data_ptr(), rows.data_ptr(), rows.shape[1], float(scale), groups[0],
-                groups[1] if len(groups) > 1 else None, self.betas[0], self.betas[1], self.eps, stream))
-        for i in range(0, len(recs), 8):
-            chunk = recs[i:i + 8]
-            arr = (_lib.EgsAdamGroup * len(chunk))(*chunk)
-            _lib.check(lib.egs_adam_step(len(chunk), arr, self.betas[0], self.betas[1], self.eps, stream))
+                sh.append((t, lrs[0]))
+        # 2. state and step counters, rolled back if a launch is refused after all (the C side checks alignment / counts)
+        bumped = []
+
+        def state_of(t):
+            st = self.state.get(t)
+            if st is None:
+                st = self.state[t] = {"step": 0, "exp_avg": torch.zeros_like(t), "exp_avg_sq": torch.zeros_like(t)}
+            st["step"] = int(st["step"]) + 1
+            bumped.append(st)
+            return st
+        stream = torch.cuda.current_stream().cuda_stream
+        try:
+            recs = []
+            for p, grad, lr in plain:
+                st = state_of(p)
+                recs.append(_lib.EgsAdamGroup(p.data_ptr(), grad.data_ptr(), st["exp_avg"].data_ptr(),
+                                              st["exp_avg_sq"].data_ptr(), p.numel(), lr, st["step"]))
+            if factored_sh is not None:
+                n = pws.shape[0]
+                groups = []
+                for t, lr in sh:
+                    st = state_of(t)
+                    groups.append(_lib.EgsAdamGroup(t.data_ptr(), None, st["exp_avg"].data_ptr(),
+                                                    st["exp_avg_sq"].data_ptr(), t.numel(), lr, st["step"]))
+                K = low.shape[1] + (high.shape[1] if high is not None else 0)
+                _lib.check(lib.egs_adam_sh_factored(
+                    n, K, rows.shape[0], pws.data_ptr(), rows.data_ptr(), rows.shape[1], float(scale), groups[0],
+                    groups[1] if len(groups) > 1 else None, self.betas[0], self.betas[1], self.eps, stream))
+            for i in range(0, len(recs), 8):
+                chunk = recs[i:i + 8]
+                arr = (_lib.EgsAdamGroup * len(chunk))(*chunk)
+                _lib.check(lib.egs_adam_step(len(chunk), arr, self.betas[0], self.betas[1], self.eps, stream))
+        except BaseException:
+            for st in bumped:
+                st["step"] -= 1
+            raise
