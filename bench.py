@@ -48,6 +48,7 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 HBM_PEAK_GBS = 8000.0    # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured float4 copy)
+VALU_BOUND = ("k_draw", "k_draw_bwd", "k_draw_seg", "k_draw_bwd_seg")   # kernels whose roofline is VALU issue
 XGMI_LINK_GBS = 153.0    # per link and direction, 7 links per GPU (prompt / SURVEY 8e)
 
 
@@ -685,7 +686,7 @@ def main():
 
     # achievable HBM bandwidth on THIS box: a device-to-device float4 copy ("confirm on the box
     # with a device-to-device copy kernel and report both")
-    peak_measured = None
+    peak_measured, clock_mhz = None, None
     if rank == 0:
         nb = 1 << 30
         src = torch.empty(nb, dtype=torch.uint8, device=dev).fill_(1)
@@ -706,6 +707,14 @@ def main():
             best = max(best, 2.0 * nb * reps / (c0.elapsed_time(c1) * 1e-3) / 1e9)   # read + write
         peak_measured = round(best, 1)
         del src, dst
+        # shader clock under full VALU load (a chain of dependent v_fma on every SIMD between the shader-clock counter and
+        # the constant 100-MHz one): what 1024 SIMDs x clock means on THIS box right now
+        cb = torch.zeros(8, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            _lib.check(lib.egs_clock_probe(ctypes.c_void_p(cb.data_ptr()), 20000, st))
+        torch.cuda.synchronize()
+        cbh = cb.cpu().numpy()
+        clock_mhz = round(float(cbh[1] - cbh[0]) / max(1.0, float(cbh[3] - cbh[2])) * 100.0, 1)
 
     # informative extra (outside the timed region): render + fused L1/SSIM loss + backward, i.e. a
     # training step without the optimizer (the torch loss of the reference costs 10.9 ms at 1080p)
@@ -800,9 +809,13 @@ def main():
         ab = algorithmic_bytes(dom, sc.n, P, T, HW, a.sh_dim)
         if ab is not None:
             ach = ab / avg_s / 1e9
-            roofline = {"kernel": dom, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS,
+            # what BOUNDS the dominant kernel: the two draw kernels issue VALU instructions 80-95 % of their SIMD cycles and
+            # move 1.3x / 2.5x their algorithmic bytes at 0.15 of the HBM peak -- `frac` (vs HBM, the contract's field) can
+            # never move for them; `valu.frac` (below, from the counter passes under profiles/) is their roofline
+            roofline = {"kernel": dom, "bound": "valu" if dom in VALU_BOUND else "hbm", "achieved": round(ach, 1),
+                        "peak": HBM_PEAK_GBS,
                         "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
-                        "peak_measured": peak_measured,
+                        "peak_measured": peak_measured, "clock_mhz": clock_mhz,
                         "frac_of_measured": None if not peak_measured else round(ach / peak_measured, 4),
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 1),
                         "launches": cnt, "share_of_step": round(tot / a.steps / ms, 3)}
@@ -814,9 +827,24 @@ def main():
                     tj = json.load(open(tpath))
                     if (tj.get("source_hash") == src_hash and tj.get("gaussians") == sc.n and
                             tj.get("width") == a.width and dom in tj.get("kernels", {})):
-                        roofline["traffic"] = tj["kernels"][dom]["hbm_bytes_per_launch"]
-                        if "valu_issue_util" in tj["kernels"][dom]:
-                            roofline["valu_issue_util"] = tj["kernels"][dom]["valu_issue_util"]
+                        kj = tj["kernels"][dom]
+                        roofline["traffic"] = kj["hbm_bytes_per_launch"]
+                        if "valu_issue_util" in kj:
+                            # frac: calibrated issue cycles of the VALU instructions the SQ counters saw (2.5 / 4.3 / 8.5
+                            # SIMD cycles for full / half / quarter rate, tools/ubench_calib.hip; quarter-rate count from
+                            # the counters, the half-rate share of the rest from the kernel's ISA, tools/valu_mix.py) over
+                            # the launch's SIMD cycles -- both in the counters' clock domain; band: every other
+                            # instruction full rate .. half rate
+                            roofline["valu"] = {
+                                "frac": kj.get("valu_frac"), "band": kj["valu_issue_util"],
+                                "insts_per_launch": kj.get("valu_insts_per_launch"),
+                                "quarter_rate_share": kj.get("valu_quarter_rate_share"),
+                                "half_rate_share_static": kj.get("valu_half_rate_share_static"),
+                                "simd_cycles_per_launch": kj.get("simd_cycles_per_launch"),
+                                "launch_us_in_counter_pass": kj.get("duration_us_in_counter_pass"),
+                                "gui_clock_mhz": kj.get("gui_clock_mhz"),
+                                "note": "SIMD-cycle share in which the VALU port issues; the rest is scalar / LDS issue and "
+                                        "stalls no other wave of the SIMD covers (DESIGN 3.4)"}
                 except Exception:
                     pass
 

@@ -98,6 +98,7 @@ SIGNATURES = {
     "egs_splat_draw_rec_dev": (_i, [_i, _i64, _P, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P,
                                     _i, _i, _P]),
     "egs_hbm_copy_probe": (_i, [_P, _P, _sz, _P]),
+    "egs_clock_probe": (_i, [_P, _i, _P]),
     "egs_mailbox_create": (_P, [_i]),
     "egs_mailbox_destroy": (None, [_P]),
     "egs_mailbox_post": (_i, [_P, _i, _P, _P]),

@@ -126,6 +126,34 @@ extern "C" int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void
   return 0;
 }
 
+// ---- shader clock under load: what bench.py prices a VALU roofline against ---------------------------------------
+namespace egs {
+// Every wave runs a chain of dependent v_fma (all SIMDs issue, as under the draw kernels); lane 0 of workgroup 0 reads the
+// shader-clock counter (s_memtime) and the constant 100-MHz counter (s_memrealtime) on both sides of it.
+__global__ __launch_bounds__(256) void k_clock_probe(unsigned long long* __restrict__ out, int iters, float seed) {
+  unsigned long long c0 = 0, r0 = 0;
+  if (blockIdx.x == 0 && threadIdx.x == 0) { c0 = __builtin_readcyclecounter(); r0 = wall_clock64(); }
+  float a = seed + (float)threadIdx.x, b = 1.0000001f;
+  for (int i = 0; i < iters; ++i) {
+#pragma unroll
+    for (int u = 0; u < 16; ++u) a = fmaf(a, b, 1.0e-7f);
+  }
+  if (a == 12345.678f) out[4] = 1ull;      // (keeps the chain alive)
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    out[0] = c0; out[1] = __builtin_readcyclecounter(); out[2] = r0; out[3] = wall_clock64();
+  }
+}
+}  // namespace egs
+
+// out: 8 uint64 in device memory; after the stream has run it, shader MHz = (out[1] - out[0]) / (out[3] - out[2]) * 100
+extern "C" int egs_clock_probe(void* out, int iters, void* stream) {
+  EGS_CHECK_ARG(out && iters > 0 && ((uintptr_t)out & 7) == 0);
+  hipLaunchKernelGGL(egs::k_clock_probe, dim3(256 * 8), dim3(256), 0, (hipStream_t)stream, (unsigned long long*)out,
+                     iters, 0.5f);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
 // ---- mailbox: page-locked landing slots for the read-back of the enqueue-ahead path ------------------
 namespace egs {
 struct Mailbox {

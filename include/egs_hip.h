@@ -347,6 +347,11 @@ int egs_splat_draw_rec_dev(int n, int64_t patch_capacity, const uint32_t* total_
 /* Measurement helper (bench.py): one device-to-device float4 copy of `bytes` (multiple of 16, both pointers
  * 16-B aligned) -- the achievable-HBM-bandwidth probe SURVEY 8(d) asks the roofline to be quoted against. */
 int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
+/* Measurement helper (bench.py): the shader clock under full VALU load -- a chain of dependent v_fma on every SIMD,
+ * bracketed by the shader-clock counter (s_memtime) and the constant 100-MHz counter (s_memrealtime).  out: 8 uint64 in
+ * device memory; once the stream has run it, MHz = (out[1] - out[0]) / (out[3] - out[2]) * 100.  What a VALU-bound
+ * kernel's roofline is priced against: 1024 SIMDs x this clock. */
+int egs_clock_probe(void* out8, int iters, void* stream);
 /* Measurement helper (tools/bwd_hit_stats.py): one bit per list entry of the NEXT backward draws of this process
  * (bit i = entry i of gsid_per_patch blended into some pixel of its tile; NULL switches the probe off).  Entries with
  * a 0 bit are dropped by k_draw_bwd before staging.  Prices a "the forward draw leaves a hit bit per entry" design

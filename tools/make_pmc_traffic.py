@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from tools/pmc_summary.py JSONs:
-   python tools/make_pmc_traffic.py <fetch_write.json> <sq_counters.json or -> <ubench_counters.json or -> <out.json>
+   python tools/make_pmc_traffic.py <fetch_write.json> <sq_counters.json or -> <ubench_counters.json or -> <out.json> [<valu_mix.json>]
 
 * HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes);
 * VALU issue utilisation per kernel from the SQ passes, CALIBRATED on single-instruction kernels
@@ -20,6 +20,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash  # noqa: E402
 
 src, sq, ub, dst = sys.argv[1:5]
+# static instruction mix of the draw kernels (tools/valu_mix.py on the ISA of THESE sources): the share of half-rate
+# instructions among the non-quarter-rate ones -- turns the band the counters leave into a point estimate
+mix = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else {}
+MIX_OF = {"k_draw_bwd": "k_draw_bwdILb0ELb1ELb1ELi7ELb0", "k_draw": "k_drawILb0ELb1ELb1ELb1",
+          "k_draw_bwd_seg": "k_draw_bwdILb0ELb1ELb1ELi7ELb1", "k_draw_seg": "k_draw_segILb1ELb1ELi0"}
 d = json.load(open(src))
 out = {"gaussians": 1000000, "width": 1920, "height": 1080, "source_hash": kernel_source_hash(),
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and SQ passes, "
@@ -53,6 +58,26 @@ if sq != "-":
         out["kernels"][name]["valu_busy_counter"] = round(active * 4 / simd_cycles, 3)
         out["kernels"][name]["valu_issue_util"] = [round(((insts - q) * 2.5 + q * 8.5) / simd_cycles, 3),
                                                    round(min(1.0, ((insts - q) * 4.3 + q * 8.5) / simd_cycles), 3)]
+        e = out["kernels"][name]
+        e["valu_quarter_rate_share"] = round(q / insts, 4) if insts else None
+        e["simd_cycles_per_launch"] = int(simd_cycles)
+        e["xcd_cycles_per_launch"] = int(c["GRBM_GUI_ACTIVE"] / 8)
+        if "duration_ns" in c:       # the clock of the counter pass itself: cycles of one XCD over the kernel's duration
+            e["duration_us_in_counter_pass"] = round(c["duration_ns"] / 1e3, 1)
+            e["gui_clock_mhz"] = round(c["GRBM_GUI_ACTIVE"] / 8 / c["duration_ns"] * 1e3, 1)
+        m = next((v for k, v in mix.items() if MIX_OF.get(name) and MIX_OF[name] in k), None)
+        if m:
+            h = m["half_share_of_non_quarter"]
+            cyc = (insts - q) * (2.5 + 1.8 * h) + q * 8.5
+            e["valu_half_rate_share_static"] = h
+            e["valu_cycles_per_launch_model"] = int(cyc)
+            # point estimate: calibrated cycles of the instructions the counters saw, with the static class mix, over the
+            # SIMD cycles of the launch (both in the clock domain of the counters: no MHz enters)
+            e["valu_frac"] = round(min(1.0, cyc / simd_cycles), 3)
+        for k2 in ("SQ_WAIT_INST_ANY", "SQ_WAVE_CYCLES", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_LDS", "SQ_INSTS_SALU",
+                   "SQ_INSTS_LDS", "SQ_INSTS_BRANCH"):
+            if k2 in c:
+                e[k2] = int(c[k2])
 if ub != "-":
     cal = {}
     for k, c in json.load(open(ub)).items():

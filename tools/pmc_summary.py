@@ -13,6 +13,17 @@ for d in sys.argv[1:]:
                 for c, x in v.items():
                     res[k][c] = x / len(disp[k])
                 res[k]["launches"] = len(disp[k])
+# kernel durations of the same passes (rocprofv3 --kernel-trace writes them next to the counters): what the cycle
+# counters of a pass are divided by to get the clock of THAT pass
+for d in sys.argv[1:]:
+    for f in glob.glob(d + "/*kernel_trace.csv"):
+        dur = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            dur[k].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+        for k, v in dur.items():
+            if k in res:
+                res[k].setdefault("duration_ns", sum(v) / len(v))
 if __name__ == "__main__":
     for k, v in res.items():
         if "--all" in sys.argv or "draw" in k:
