@@ -364,7 +364,7 @@ def main():
     # issued; with the overlapped exchange the collectives start inside backward, so renders are then
     # validated at once (the step is exchange-bound there and the host has time to spare)
     deferred = a.mode == "fused" and not a.immediate and overlap is None
-    ev_render, ev_done = [], []
+    ev_render, ev_done, ev_parts = [], [], []     # (ev_parts: render end, all-gather end, row kernel end)
     redone = [0]
     # V > 1: the views of a rank go round-robin to --view-streams HIP streams (dist_views.ViewStreams: a view is a
     # chain of dependent kernels, a quarter of it latency-bound; two views on two streams fill each other's gaps)
@@ -447,7 +447,13 @@ def main():
                 pass                  # issued chunk by chunk from inside backward; now complete
             else:
                 if fx is not None:        # all-gather of the views' dL/dcolour + one kernel: shs.grad = the mean rows
-                    fx.finish(params["pws"], params["shs"], average=True)
+                    if timing:
+                        eg = torch.cuda.Event(enable_timing=True); ek = torch.cuda.Event(enable_timing=True)
+                        fx.finish(params["pws"], params["shs"], average=True, on_gathered=eg.record)
+                        ek.record()
+                        ev_parts.append((e1, eg, ek))
+                    else:
+                        fx.finish(params["pws"], params["shs"], average=True)
                 names = rest if fx is not None else order
                 flat = fused_path.flat_grad_buffer([params[k] for k in names])
                 if flat is not None:      # the fused backward hands out slices of one buffer: ONE all-reduce
@@ -557,7 +563,22 @@ def main():
                             "11 floats per Gaussian + one kernel forming the rows",
                     "link_bytes_per_rank": ag + 2 * (world - 1) / world * rest_b,
                     "direct_bytes_per_link": V * 4 * DV.FactoredShGrad.row_stride(sc.n) + 2 * rest_b / world}
-        exch = {"bytes": nbytes, **form, "t_render_ms": [round(float(x[0]), 4) for x in allr],
+        # the two collectives of the factored form timed apart (the first real SCALE line should decide
+        # --factored-sh auto's threshold from the all-gather's and the all-reduce's own bus bandwidths, not from
+        # factored_exchange_pays()'s byte count): this rank's times; bytes a rank sends + receives per collective
+        parts = None
+        if fx is not None and ev_parts:
+            t_ag = float(np.mean([a_.elapsed_time(b_) for a_, b_, _ in ev_parts]))
+            t_rows = float(np.mean([b_.elapsed_time(c_) for _, b_, c_ in ev_parts]))
+            t_ar = float(np.mean([c_.elapsed_time(d_[1]) for (_, _, c_), d_ in zip(ev_parts, ev_done)]))
+            ag_b = (world - 1) * V * 4 * DV.FactoredShGrad.row_stride(sc.n)
+            ar_b = 2 * (world - 1) / world * 4 * 11 * sc.n
+            parts = {"all_gather": {"ms": round(t_ag, 4), "link_bytes_per_rank": ag_b,
+                                    "bus_GBs": round(ag_b / (t_ag * 1e-3) / 1e9, 1) if (world > 1 and t_ag > 0) else None},
+                     "rows_kernel_ms": round(t_rows, 4),
+                     "all_reduce": {"ms": round(t_ar, 4), "link_bytes_per_rank": ar_b,
+                                    "bus_GBs": round(ar_b / (t_ar * 1e-3) / 1e9, 1) if (world > 1 and t_ar > 0) else None}}
+        exch = {"bytes": nbytes, **form, "collectives": parts, "t_render_ms": [round(float(x[0]), 4) for x in allr],
                 "t_exchange_ms": [round(float(x[1]), 4) for x in allr],
                 "overlapped_with_backward": bool(overlap is not None and overlap.used),
                 "bus_GBs": round(form["link_bytes_per_rank"] / (te_max * 1e-3) / 1e9, 1) if world > 1 else None,

@@ -371,12 +371,14 @@ class FactoredShGrad:
         return rows, world
 
     def finish(self, pws: torch.Tensor, shs: torch.Tensor, high_shs: Optional[torch.Tensor] = None,
-               average: bool = True) -> None:
+               average: bool = True, on_gathered=None) -> None:
         """``shs.grad`` (raw layout: ``shs`` = low_shs [N,3] and ``high_shs`` [N,K-3]) += scale * the step's SH gradient
         over the views of ALL ranks; scale = 1 / ranks (``average``: what ``exchange_gradients`` does to the other
         tensors) or 1 (``Trainer``, whose loss already carries 1 / views).  A collective: every rank calls it."""
         from . import _lib
         taken = self.take()
+        if on_gathered is not None:      # (bench.py: an event between the all-gather and the kernel that forms the rows)
+            on_gathered()
         if taken is None:
             return
         rows, world = taken
