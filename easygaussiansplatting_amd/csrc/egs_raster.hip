@@ -1714,6 +1714,12 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
   __shared__ uint32_t wsum[16];
   __shared__ int s_slots, s_n3, s_max, s_mw;
   const int tid = threadIdx.x, lane = tid & 63;
+#ifdef EGS_PLAN_STAMPS
+#define PLAN_STAMP(k) do { if (tid == 0) a.hdr[16 + 2 * backward * 8 + (k)] = (int)wall_clock64(); } while (0)
+#else
+#define PLAN_STAMP(k) do { } while (0)
+#endif
+  PLAN_STAMP(0);
   int mw = 0;     // longest walk seen by this thread (forward: the previous render's; backward: this render's)
   for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
   if (tid == 0) { s_slots = 0; s_n3 = 0; s_max = 0; s_mw = 0; }
@@ -1809,6 +1815,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) mw = max(mw, __shfl_xor(mw, d, 64));
   if (lane == 0 && mw > 0) atomicMax(&s_mw, mw);
+  PLAN_STAMP(1);
   __syncthreads();
   {  // exclusive scan of the bins: thread t owns bins [4 t, 4 t + 4)
     uint32_t v[4], sum = 0u;
@@ -1828,7 +1835,15 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
   __syncthreads();
   const int total = (int)wsum[0];
   int32_t* __restrict__ items = backward ? a.itemsB : a.items1;
-  // pass 2: a tile's items go to [start of its bin + its rank, + count)
+  // pass 2: a tile's items go to [start of its bin + its rank, + count).  Only the HEAD of a run is written here (a
+  // lane filling its own tile's run is one store instruction per item and wave; the whole wave filling one run after
+  // the other is 40 instructions per split tile on the one CU this kernel runs on: 12 us per 1000 split tiles); pass 3
+  // fills the runs position by position: the slots are dense, so position i belongs to the last head at or before it.
+  const int ntot = min(total, a.item_cap);
+  PLAN_STAMP(2);
+  for (int i = tid; i < ntot; i += 1024) items[i] = -1;
+  __syncthreads();
+  PLAN_STAMP(3);
   for (int t0 = 0; t0 < T; t0 += 1024 * SP_REGS) {
     uint32_t pp[SP_REGS];
     int cc[SP_REGS];
@@ -1841,23 +1856,60 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
 #pragma unroll
     for (int q = 0; q < SP_REGS; ++q) {
       const int t = t0 + q * 1024 + tid;
-      const bool has = t < T && pp[q] != 0xFFFFFFFFu;
-      const int slot = has ? (int)(bins[pp[q] >> 20] + (pp[q] & 0xFFFFFu)) : 0;
-      if (has && cc[q] < 0 && slot < a.item_cap) items[slot] = t;
-      // the items of a split tile are written by the whole wave (a lane filling its own tile's run is one store
-      // instruction per item and wave)
-      unsigned long long todo = __ballot(has && cc[q] > 0);
-      while (todo != 0ull) {
-        const int src = (int)__builtin_ctzll(todo);
-        todo &= todo - 1ull;
-        const int c = __builtin_amdgcn_readlane(cc[q], src), sl = __builtin_amdgcn_readlane(slot, src),
-                  tt = __builtin_amdgcn_readlane(t, src);
-        for (int u = lane; u < c; u += 64)      // backward: deepest segment first (it starts from the pixels' own final state)
-          if (sl + u < a.item_cap)
-            items[sl + u] = (int32_t)((uint32_t)tt | ((uint32_t)(backward ? c - 1 - u : u) << 19) | ((uint32_t)SEG_SPEC << 30));
-      }
+      if (t >= T || pp[q] == 0xFFFFFFFFu) continue;
+      const int slot = (int)(bins[pp[q] >> 20] + (pp[q] & 0xFFFFFu));
+      if (slot >= ntot) continue;
+      // DIRECT: the bare tile index; split: segment 0 first (forward) / the deepest segment first (backward: it starts
+      // from the pixels' own final state)
+      items[slot] = cc[q] < 0 ? t : (int32_t)((uint32_t)t | ((uint32_t)(backward ? cc[q] - 1 : 0) << 19) |
+                                               ((uint32_t)SEG_SPEC << 30));
     }
   }
+  __syncthreads();
+  PLAN_STAMP(4);
+  {  // pass 3, in rounds of 1024 x 32 positions: thread t owns 32 consecutive ones, ALL requested before the first is
+     // looked at (a loop that loads, tests, stores position by position is a chain of L2 round trips: 14 us for 17)
+    constexpr int PB = 32;
+    __shared__ unsigned long long wlast[16];
+    __shared__ unsigned long long s_carry;
+    if (tid == 0) s_carry = 0ull;
+    for (int base = 0; base < ntot; base += 1024 * PB) {
+      const int i0 = base + tid * PB;
+      int v[PB];
+#pragma unroll
+      for (int k = 0; k < PB; ++k) v[k] = items[min(i0 + k, ntot - 1)];
+      unsigned long long mine = 0ull;    // (position + 1) << 32 | head value of the LAST head in my range; 0: none
+#pragma unroll
+      for (int k = 0; k < PB; ++k)
+        if (i0 + k < ntot && v[k] != -1) mine = ((unsigned long long)(i0 + k + 1) << 32) | (uint32_t)v[k];
+      // the last head in front of my range: an inclusive max-scan over (position, value) keys, then one step back
+      unsigned long long inc = mine;
+#pragma unroll
+      for (int d = 1; d < 64; d <<= 1) {
+        const unsigned long long o = __shfl_up(inc, d, 64);
+        if (lane >= d) inc = max(inc, o);
+      }
+      __syncthreads();                   // (s_carry of the previous round is written, wlast free again)
+      if (lane == 63) wlast[tid >> 6] = inc;
+      __syncthreads();
+      unsigned long long carry = __shfl_up(inc, 1, 64);
+      if (lane == 0) carry = 0ull;
+      carry = max(carry, s_carry);
+      for (int w = 0; w < (tid >> 6); ++w) carry = max(carry, wlast[w]);
+      int head = (int)(uint32_t)carry, hpos = (int)(carry >> 32) - 1;
+#pragma unroll
+      for (int k = 0; k < PB; ++k) {
+        const int i = i0 + k;
+        if (i < ntot) {
+          if (v[k] != -1) { head = v[k]; hpos = i; }
+          else if (hpos >= 0) items[i] = backward ? head - ((i - hpos) << 19) : head + ((i - hpos) << 19);
+        }
+      }
+      __syncthreads();
+      if (tid == 1023) s_carry = max(carry, inc);
+    }
+  }
+  PLAN_STAMP(5);
   if (tid == 0) {
     if (!backward) {
       a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
