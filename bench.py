@@ -859,7 +859,7 @@ def main():
                         roofline["traffic"] = kj["hbm_bytes_per_launch"]
                         if "valu_issue_util" in kj:
                             # frac: calibrated issue cycles of the VALU instructions the SQ counters saw (2.5 / 4.3 / 8.5
-                            # SIMD cycles for full / half / quarter rate, tools/ubench_calib.hip; quarter-rate count from
+                            # SIMD cycles for full / half / quarter rate, tools/lab/ubench_calib.hip; quarter-rate count from
                             # the counters, the half-rate share of the rest from the kernel's ISA, tools/valu_mix.py) over
                             # the launch's SIMD cycles -- both in the counters' clock domain; band: every other
                             # instruction full rate .. half rate

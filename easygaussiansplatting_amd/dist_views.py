@@ -417,7 +417,7 @@ class ViewStreams:
     short and latency-bound (a quarter of a view's time with most of the chip idle), the two draw kernels issue-bound.
     Views are independent until their gradients are added, so two of them on two streams fill each other's gaps:
     measured on the 1 M / 1080p scene, independent steps take 0.87 ms each on one stream, 0.76 on two, 0.74 on three
-    and 0.77 on four (tools/lab_two_streams.py).
+    and 0.77 on four (tools/lab/lab_two_streams.py).
 
     Every stream gets its own autograd leaves -- detached aliases of the parameters (same storage, separate
     ``.grad``) -- so the views of a stream accumulate among themselves (``fused.accumulate_in_kernel`` works per

@@ -85,7 +85,7 @@ if "--time" in sys.argv:
     dl = t(S.normal(1, 77, (3, H, W))) / (3 * H * W)
 
     if lib.egs_probe_set_hit_bits(None) != 0:
-        sys.exit("this libegs_hip.so was built without the probe: make FLAGS+=-DEGS_PROBE_HIT_BITS=1 (tools/lab_r4d.sh)")
+        sys.exit("this libegs_hip.so was built without the probe: make FLAGS+=-DEGS_PROBE_HIT_BITS=1 (tools/lab/lab_r4d.sh)")
 
     def run(probe, reps=40):
         lib.egs_probe_set_hit_bits(C.c_void_p(bits.data_ptr()) if probe else None)

@@ -6,4 +6,4 @@ for spec in "$@"; do
   name="${spec%%:*}"; args="${spec#*:}"
   $B $args > $O/$name.json 2> $O/$name.err
 done
-python tools/lab_summ.py $O/*.json
+python tools/lab/lab_summ.py $O/*.json

@@ -8,5 +8,5 @@ $B --width 3840 --height 2160 > $O/1m_4k.json 2>$O/4k.err
 $B --gaussians 8000000 --width 3840 --height 2160 > $O/8m_4k.json 2>$O/8m.err
 $B --sh-dim 3 > $O/1m_sh0.json 2>/dev/null
 $B --gaussians 10000 --width 256 --height 256 > $O/10k_256.json 2>/dev/null
-python tools/lab_summ.py $O/4m_1080.json $O/1m_4k.json $O/8m_4k.json $O/1m_sh0.json $O/10k_256.json
+python tools/lab/lab_summ.py $O/4m_1080.json $O/1m_4k.json $O/8m_4k.json $O/1m_sh0.json $O/10k_256.json
 tail -2 $O/8m.err

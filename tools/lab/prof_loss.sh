@@ -2,7 +2,7 @@
 # rocprofv3 kernel trace of the fused loss kernels (run on the GPU box via gpurun)
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/lp
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lp -- python $GRAFT_REPO_ROOT/tools/time_hip_loss.py > /tmp/lp.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lp -- python $GRAFT_REPO_ROOT/tools/lab/time_hip_loss.py > /tmp/lp.log 2>&1
 grep "hip gau_loss" /tmp/lp.log
 f=$(find /tmp/lp -name "*kernel_stats.csv" | head -1)
 python - "$f" <<PY

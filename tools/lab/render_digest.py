@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Digest of one forward (+ backward) of the bench scene and of the 10 k scene: image bytes (sha1), contrib / final_tau
-bytes, and the gradient sums -- to compare two builds of the library (python tools/render_digest.py > a.txt)."""
+bytes, and the gradient sums -- to compare two builds of the library (python tools/lab/render_digest.py > a.txt)."""
 import hashlib, os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

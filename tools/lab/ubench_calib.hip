@@ -4,7 +4,7 @@
 //   rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE
 // the ratio SQ_ACTIVE_INST_VALU x 4 / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the pure-FMA kernel is what the
 // counter reads at 100 % issue utilisation -- the factor every "VALU busy" figure under profiles/ is divided by.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_calib.hip -o gpurun_out/ubench_calib && gpurun_out/ubench_calib
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/ubench_calib.hip -o gpurun_out/ubench_calib && gpurun_out/ubench_calib
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 

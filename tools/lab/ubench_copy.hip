@@ -1,5 +1,5 @@
 // Device-to-device copy variants: which shape reaches the achievable HBM bandwidth on this box?
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_copy.hip -o /tmp/ubench_copy && /tmp/ubench_copy
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/ubench_copy.hip -o /tmp/ubench_copy && /tmp/ubench_copy
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 

@@ -3,7 +3,7 @@
 // s_mov_b64 exec, <mask>.  If the SIMD16 skipped 16-lane passes whose lanes are all disabled, "one quarter" would cost
 // a quarter of "all lanes"; if cost follows the NUMBER of enabled quarters, "one lane in every quarter" costs as much
 // as "all lanes".
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_exec.hip -o /tmp/ubench_exec && /tmp/ubench_exec
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/ubench_exec.hip -o /tmp/ubench_exec && /tmp/ubench_exec
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 

@@ -1,7 +1,7 @@
 // Micro-benchmark: issue cost of the VALU / LDS ops the draw kernels are made of,
 // at 8 waves/SIMD (2048 blocks x 256 threads on 256 CUs).  Prints cycles per
 // wave-instruction per SIMD assuming the reported clock.
-//   hipcc --offload-arch=gfx950 -O3 tools/ubench_valu.hip -o gpurun_out/ubench && gpurun_out/ubench
+//   hipcc --offload-arch=gfx950 -O3 tools/lab/ubench_valu.hip -o gpurun_out/ubench && gpurun_out/ubench
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>

@@ -4,7 +4,7 @@
 
 * HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes);
 * VALU issue utilisation per kernel from the SQ passes, CALIBRATED on single-instruction kernels
-  (tools/ubench_calib.hip): SQ_ACTIVE_INST_VALU counts 4 cycles for an instruction that really occupies the
+  (tools/lab/ubench_calib.hip): SQ_ACTIVE_INST_VALU counts 4 cycles for an instruction that really occupies the
   SIMD for 2.5 (add / mul / fma), 4.3 (DPP, cndmask, med3, min/max, cmp, readlane) and 8 for one that takes 8.5
   (exp, rcp, permlane swaps) -- "busy = counter x 4 / cycles" therefore reads 1.59 for a pure-FMA kernel at 100 %
   issue and cannot be quoted as a utilisation.  What is stored instead is the range the counters allow:
@@ -83,7 +83,7 @@ if ub != "-":
     for k, c in json.load(open(ub)).items():
         cal[k.split("<")[-1].rstrip(">")] = round(c["SQ_ACTIVE_INST_VALU"] * 4 / (1024 * c["GRBM_GUI_ACTIVE"] / 8), 3)
     out["valu_busy_counter_at_full_issue"] = {"by_ubench_op_index": cal,
-                                              "note": "tools/ubench_calib.hip kernels k_ub<OP>: 0 v_fma, 1 v_exp, 2 v_rcp, "
+                                              "note": "tools/lab/ubench_calib.hip kernels k_ub<OP>: 0 v_fma, 1 v_exp, 2 v_rcp, "
                                                       "3/4 permlane swaps, 5 dpp add, 6 cndmask, 7 readlane, 8 mov_b64, 9 med3"}
 json.dump(out, open(dst, "w"), indent=1)
 print({k: (v["hbm_bytes_per_launch"], v.get("valu_issue_util")) for k, v in out["kernels"].items()})

@@ -5,7 +5,7 @@
 
 What it is for: the SQ counters give a kernel's VALU instruction count and the number of quarter-rate
 ones (SQ_ACTIVE_INST_VALU - SQ_INSTS_VALU), but not how the rest splits into FULL-rate (2.5 SIMD cycles per wave64
-instruction measured, tools/ubench_calib.hip: v_add / v_mul / v_fma / v_sub / v_mad / v_lshl_add ...) and HALF-rate
+instruction measured, tools/lab/ubench_calib.hip: v_add / v_mul / v_fma / v_sub / v_mad / v_lshl_add ...) and HALF-rate
 ones (4.3: DPP forms, v_cndmask, v_med3, v_min / v_max, v_cmp*, v_readlane / v_readfirstlane, v_mov_b64, 64-bit
 integer ops).  The draw kernels are one loop; the static share of half-rate instructions among the non-quarter ones of
 that loop body narrows the issue-utilisation band the counters leave (0.81 .. 1.0) to a point with a stated error.
