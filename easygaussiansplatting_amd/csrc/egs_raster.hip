@@ -1635,6 +1635,7 @@ constexpr int SEG_SLOT_FLOATS = 256 * 6;
 constexpr uint32_t SEG_TILE_MASK = 0x7FFFFu, SEG_SEG_MASK = 0x7FFu;   // item = tile | seg << 19 | kind << 30
 constexpr int SEG_SPEC = 1, SEG_COMPOSE = 2;   // (0: a DIRECT item, the bare tile index)
 enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_ITEMSB = 5, SH_L = 6, SH_MIN = 7,
+       SH_MAXWALK = 8 /* longest walk of THIS render, gathered by the draw items */,
        SH_HINT = 10 /* two words: the host's hint slot */ };
 struct SegArgs {
   int32_t* hdr;        // SEG_HDR words
@@ -1701,14 +1702,17 @@ constexpr int SP_REGS = 8;     // tiles per thread and round whose inputs are re
                                // of latencies: 8160 tiles are ONE round of 1024 x 8)
 // (L is a power of two: a segment index is a shift -- an integer division is ~40 instructions on this part, and the plan
 // kernel's first version spent 26 of its 37 us dividing)
-__device__ __forceinline__ int seg_nspec(const int32_t* __restrict__ hist, int h, int n, int nseg, int L, int Ls) {
-  if (!hist) return 1;
+__device__ __forceinline__ int seg_nspec(const int32_t* __restrict__ hist, int h, int n, int nseg, int L, int Ls,
+                                         int speculate) {
+  // no walk on record for this camera: segment 0 only -- or, when the host knows the scene's tiles to be walked to
+  // (nearly) their ends (EGS_DRAW_SEG_SPECULATE: nothing saturates, e.g. right after reset_alpha), the whole list
+  if (!hist) return speculate ? nseg : 1;
   const int w = min(max(h, 0), n);
   return max(1, min(nseg, (w + (w >> 2) + L) >> Ls));
 }
 __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restrict__ ranges,
                                                    const int32_t* __restrict__ hist, int L, int split_min, SegArgs a,
-                                                   int backward, uint32_t* __restrict__ hint_host) {
+                                                   int backward, uint32_t* __restrict__ hint_host, int speculate) {
   constexpr int NB = 4096;
   __shared__ uint32_t bins[NB];
   __shared__ uint32_t wsum[16];
@@ -1778,7 +1782,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
           // (a workspace of egs_seg_ws_bytes cannot run out of slots; if a caller's does, the tile stays unsplit)
           if ((int)sb + nseg <= a.slot_cap) {
             bb[q] = (int)sb;
-            a.items3[s3] = (int32_t)((uint32_t)t | ((uint32_t)seg_nspec(hist, hh[q], n, nseg, L, Ls) << 19) |
+            a.items3[s3] = (int32_t)((uint32_t)t | ((uint32_t)seg_nspec(hist, hh[q], n, nseg, L, Ls, speculate) << 19) |
                                      ((uint32_t)SEG_COMPOSE << 30));
           } else {
             a.items3[s3] = t;      // (no COMPOSE kind: the per-tile launches skip it)
@@ -1796,7 +1800,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       const int n = max(rr[q].y - rr[q].x, 0);
       int cnt = valid ? 1 : 0, est = n;
       if (!backward) {
-        if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls); est = L + jitter(t); }
+        if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls, speculate); est = L + jitter(t); }
         else if (hist) est = min(max(hh[q], 0), n);
       } else if (valid) {
         const int w = min(max(hh[q], 0), n);
@@ -1914,7 +1918,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
     if (!backward) {
       a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
       a.hdr[SH_MAXLEN] = s_max; a.hdr[SH_SPLIT] = s_n3; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
-      a.hdr[SH_ITEMSB] = 0;
+      a.hdr[SH_ITEMSB] = 0; a.hdr[SH_MAXWALK] = 0;
       // page-locked words the host peeks at before a LATER render: the longest list, and the longest walk of the
       // camera's previous render (the backward plan overwrites it with this render's)
       if (hint_host) { hint_host[0] = (uint32_t)s_max; if (hist) hint_host[1] = (uint32_t)s_mw; }
@@ -2278,8 +2282,15 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
       if (p.work_out) p.work_out[tile] = w + 2 * wmax;
       sg.walk[tile] = wmax;
       if (sg.hist_walk) sg.hist_walk[tile] = wmax;
+      if (wmax > sg.hdr[SH_MAXWALK]) atomicMax(&sg.hdr[SH_MAXWALK], wmax);
     }
   }
+}
+
+// the longest walk of the render that just drew -> the host's hint slot (a forward-only caller has no backward plan to
+// report it; without it a scene of short walks would stay on the segment path for ever)
+__global__ void k_seg_report(const int32_t* __restrict__ hdr, uint32_t* __restrict__ hint_host) {
+  if (threadIdx.x == 0 && hint_host) hint_host[1] = (uint32_t)hdr[SH_MAXWALK];
 }
 
 // ============================================================================
@@ -3132,8 +3143,9 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     const size_t olen = (size_t)tile_order_len(dp.gx, dp.gy);
     const int32_t* hist = (tile_order && (flags & EGS_DRAW_SEG_HISTORY)) ? tile_order + olen + dp.T : nullptr;
     sga.hist_walk = tile_order ? tile_order + olen + dp.T : nullptr;
+    const int speculate = (!hist && (flags & EGS_DRAW_SEG_SPECULATE)) ? 1 : 0;
     EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, hist, g_seg_L, g_seg_min,
-               sga, 0, seg_hint);
+               sga, 0, seg_hint, speculate);
     if (tile_order) dp.work_out = tile_order + olen;
     // items <= tiles + segments <= T + P / L + P / split_min: the launch covers the bound, surplus workgroups exit
     const int64_t bound = (int64_t)dp.T + patches / g_seg_L + patches / g_seg_min + 2;
@@ -3149,7 +3161,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
 #define EGS_DRAWS3(FLOOR, CLAMP)                                                                                  \
     do {                                                                                                          \
       EGS_DRAWS(FLOOR, CLAMP, 0, "k_draw_seg", grid1);                                                            \
-      if (hist) {   /* (no prediction: segment 0 is the only SPEC item of a tile, and it is exact) */               \
+      if (hist || speculate) {   /* (else segment 0 is the only SPEC item of a tile, and it is exact) */            \
         EGS_DRAWS(FLOOR, CLAMP, 3, "k_draw_seg_prefix", dp.T);                                                    \
         EGS_DRAWS(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid1);                                                      \
       }                                                                                                           \
@@ -3163,6 +3175,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     }
 #undef EGS_DRAWS3
 #undef EGS_DRAWS
+    if (seg_hint) EGS_LAUNCH("k_seg_report", k_seg_report, dim3(1), dim3(64), s, (const int32_t*)sga.hdr, seg_hint);
     EGS_LAUNCH_OK();
     return 0;
   }
@@ -3349,7 +3362,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     }
     seg_config_env();
     EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, (const int32_t*)nullptr, 0,
-               0, sga, 1, (uint32_t*)nullptr);
+               0, sga, 1, (uint32_t*)nullptr, 0);
     const int64_t bound = (int64_t)dp.T + patches / g_seg_L + patches / g_seg_min + 2;
     const int grid = (int)std::min<int64_t>(bound, sga.item_cap);
 #define EGS_DRAWBS(FLOOR, CLAMP)                                                                            \

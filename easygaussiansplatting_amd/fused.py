@@ -40,6 +40,10 @@ CULL_LISTS = os.environ.get("EGS_CULL_LISTS", "1") != "0"            # A/B knob:
 # of the scene's last render exceeded the split threshold (and at first sight), "1" always, "0" never
 SEGMENTS = os.environ.get("EGS_SEGMENTS", "auto")
 SEG_HISTORY = 4           # include/egs_hip.h EGS_DRAW_SEG_HISTORY
+SEG_SPECULATE_FLAG = 8    # include/egs_hip.h EGS_DRAW_SEG_SPECULATE
+# a camera without a walk on record on the segment path: "auto" = all its segments at once when the scene's recent renders
+# walked at least half of their longest list (nothing saturates: reset_alpha), "1" always, "0" never (segment 0 only)
+SEG_SPECULATE = os.environ.get("EGS_SEG_SPECULATE", "auto")
 CULLED_LISTS = 32         # include/egs_hip.h EGS_BWD_CULLED_LISTS
 ACCUMULATE = 64           # include/egs_hip.h EGS_BWD_ACCUMULATE
 FACTORED_SH = 128         # include/egs_hip.h EGS_BWD_FACTORED_SH
@@ -224,6 +228,7 @@ def _seg_decision(ctx, lib, key, pol_):
     render or two old; they only select between two exact paths): a scene whose tiles are all walked for less than the
     split threshold takes the unsplit kernels (three launches less), at first sight and from then on long walks take
     the segment path."""
+    _tls.seg_speculate = SEG_SPECULATE == "1"
     if SEGMENTS == "0" or pol_.footprint != 0 or not (pol_.alpha_skip > 0) or not (pol_.tau_stop > 0):
         return False, None
     with ctx.lock:
@@ -237,8 +242,10 @@ def _seg_decision(ctx, lib, key, pol_):
     _lib.check(lib.egs_mailbox_peek(ctx.mb, slot, out))
     cfg = (C.c_int * 2)()
     _lib.check(lib.egs_seg_config(0, 0, cfg))
-    walk = int(out[1])
+    longest, walk = int(out[0]), int(out[1])
     use = SEGMENTS == "1" or walk == 0xFFFFFFFF or walk > cfg[1]
+    known = walk != 0xFFFFFFFF and longest != 0xFFFFFFFF
+    _tls.seg_speculate = SEG_SPECULATE == "1" or (SEG_SPECULATE == "auto" and known and 2 * walk >= longest)
     return use, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot))
 
 
@@ -407,7 +414,8 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         with ctx.lock:
             tw[ck] = (ref, S.order, renders, (n, W, H))
     S.order_by_work = prev_work is not None or order_ready == 1
-    draw_flags = (1 if S.culled else 0) | (SEG_HISTORY if (use_seg and walk_known) else 0)
+    draw_flags = (1 if S.culled else 0) | (SEG_HISTORY if (use_seg and walk_known) else 0) | \
+        (SEG_SPECULATE_FLAG if (use_seg and not walk_known and getattr(_tls, "seg_speculate", False)) else 0)
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
     def render_exact():

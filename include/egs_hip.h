@@ -320,6 +320,12 @@ size_t egs_tile_order_len(int width, int height);   /* ints: [forward dispatch o
  * then the same work with two launches less).  prev_tile_work / order_ready are ignored when the lists are split
  * (the work items are re-planned per render, by k_seg_plan). */
 #define EGS_DRAW_SEG_HISTORY 4
+/* flags of egs_splat_draw_rec_seg, for a camera WITHOUT a walk on record: take every tile's list length as its predicted
+ * walk (all its segments get a wave at once).  For scenes the host knows to be walked to (nearly) their ends -- the
+ * longest walk a recent render of the scene reported is a good part of its longest list, as right after reset_alpha --
+ * where the alternative (one wave continuing from segment 1) is the serial tail this path exists to remove.  On a
+ * saturating scene it would blend segments nobody looks at: exact either way, the balance is the host's call. */
+#define EGS_DRAW_SEG_SPECULATE 8
 size_t egs_seg_ws_bytes(int64_t patch_capacity, int width, int height);
 /* segment_len (a power of two >= 64) / split_min: 0 keeps the current value; out2 (nullable) receives the values BEFORE the
  * call.  Process-wide tuning knob (defaults 256 / 1024, or EGS_SEG_L / EGS_SEG_MIN from the environment); a workspace

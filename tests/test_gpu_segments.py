@@ -108,10 +108,18 @@ def test_segments_equal_the_unsplit_kernels(fx, seg_len, split_min, reset):
     assert lens.max() > 4 * seg_len and (lens > split_min).sum() > 20, (lens.max(), (lens > split_min).sum())
     fused.SEGMENTS = "1"
     _lib.check(lib.egs_seg_config(seg_len, split_min, None))
-    for renders in (1, 3):       # first sight (COMPOSE walks the tile, the backward pass is split) / with history (SPEC)
-        got = run(fused, sc, Camera.from_scene(sc.cam), dl, renders)
-        assert got["seg"]
-        compare(got, ref, "seg%d/%d/%s/r%d" % (seg_len, split_min, "reset" if reset else "opaque", renders))
+    keep = fused.SEG_SPECULATE
+    try:
+        # first sight: segment 0 + COMPOSE walking on alone (the backward pass is split regardless) / first sight with
+        # every segment of the list speculated (EGS_DRAW_SEG_SPECULATE: most of them wasted on the opaque scene, none on
+        # the reset one -- exact either way) / with the walks of earlier renders on record (SPEC items follow them)
+        for renders, spec in ((1, "0"), (1, "1"), (3, "auto")):
+            fused.SEG_SPECULATE = spec
+            got = run(fused, sc, Camera.from_scene(sc.cam), dl, renders)
+            assert got["seg"]
+            compare(got, ref, "seg%d/%d/%s/r%d/spec%s" % (seg_len, split_min, "reset" if reset else "opaque", renders, spec))
+    finally:
+        fused.SEG_SPECULATE = keep
 
 
 def test_segments_skewed_scene_full_size(fx):
