@@ -166,7 +166,7 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
     import ctypes
     import torch
     from easygaussiansplatting_amd import fused as fused_path, scene as S
-    from easygaussiansplatting_amd.function import Camera, GSFunction
+    from easygaussiansplatting_amd.function import Camera, GSFunction, RenderOptions
     cam = Camera.from_scene(sc.cam, dev)
     t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
     P = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1).clone(), scales=t(sc.scales),
@@ -177,11 +177,12 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
     W, H = sc.cam.width, sc.cam.height
     dl = torch.from_numpy(S.normal(1, 77, (3, H, W)).astype(np.float32)).to(dev) / (3 * H * W)
 
-    def once():
+    def once(opts=None):
         for p in P.values():
             p.grad = None
         us0.grad = None
-        img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+        args = (P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam) + ((opts,) if opts is not None else ())
+        img, _ = GSFunction.apply(*args)
         img.backward(dl)
 
     def step():
@@ -226,6 +227,18 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
     bwd = sum(v for k, v in kern.items() if k.startswith("k_draw_bwd")) + plan
     out["draw_fwd_us"], out["draw_bwd_us"] = round(fwd, 1), round(bwd, 1)
     out["segment_path"] = "k_draw_seg" in kern
+    # the seven-op drop-in surface on the same scene: with this package's records handle, and the plain public
+    # splat / splatB pair of an unmodified reference caller (which rebuilds the segment states in splatB)
+    for key, o in (("ops_ms_per_step", RenderOptions(mode="ops")),
+                   ("ops_public_pair_ms_per_step", RenderOptions(mode="ops", ops_use_records=False))):
+        for _ in range(4):
+            once(o)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(8):
+            once(o)
+        torch.cuda.synchronize()
+        out[key] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
     if iid_ref:
         r = out["pixel_gaussian_pairs"] / iid_ref["pairs"]
         out["pairs_ratio_to_iid"] = round(r, 3)

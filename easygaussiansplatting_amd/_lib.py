@@ -89,7 +89,10 @@ SIGNATURES = {
     "egs_seg_ws_bytes": (_sz, [_i64, _i, _i]),
     "egs_seg_config": (_i, [_i, _i, C.POINTER(C.c_int)]),
     "egs_splat_draw_rec_seg": (_i, [_i, _i64, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P,
-                                    _i, _i, _P, _sz, _P, _P]),
+                                    _i, _i, _P, _sz, _P, _P, _P]),
+    "egs_seg_rebuild_ws_bytes": (_sz, [_i64, _i, _i]),
+    "egs_splat_bwd_seg": (_i, [_i, _i64, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P,
+                               _P, _P, _P, _P, _i, _P, _sz, _i, _P, _P]),
     "egs_mailbox_peek": (_i, [_P, _i, C.POINTER(C.c_uint32)]),
     "egs_mailbox_clear": (_i, [_P, _i]),
     "egs_sh_grad_views": (_i, [_i, _i, _i, _P, _P, _i64, _f, _P, _P, _i, _P]),

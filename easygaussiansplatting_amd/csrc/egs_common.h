@@ -153,7 +153,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      bool keep_forward_order = false /* dispatch the tiles exactly as tile_order says */,
                      bool masked_lists = false /* gsid_per_patch carries block masks (culled lists, fused path) */,
                      void* seg_ws = nullptr /* the segment workspace the forward draw filled (egs_splat_draw_rec_seg) */,
-                     size_t seg_ws_bytes = 0);
+                     size_t seg_ws_bytes = 0, int rebuild = 0 /* seg_ws is fresh: rebuild the states from contrib first */,
+                     uint32_t* seg_hint = nullptr /* page-locked words that learn the longest walk */);
 
 // ---- device helpers ---------------------------------------------------------
 #ifdef __HIPCC__

@@ -1141,7 +1141,7 @@ constexpr int TILE_ORDER_MAX_T = (TO_REGS + 24) * 1024;   // what k_tile_order h
 // The per-tile work measure of k_draw (sum of the four blocks' largest contributor index + twice the tile's)
 // rebuilt from the `contrib` image, for a backward pass that was not handed the forward pass's record.
 __global__ __launch_bounds__(64) void k_tile_work(int W, int H, int gx, const int32_t* __restrict__ contrib,
-                                                  int32_t* __restrict__ work) {
+                                                  int32_t* __restrict__ work, int32_t* __restrict__ walk = nullptr) {
   const int tile = blockIdx.x, lane = threadIdx.x;
   const int tx0 = (tile % gx) * EGS_TILE, ty0 = (tile / gx) * EGS_TILE;
   int w = 0, wmax = 0;
@@ -1154,7 +1154,22 @@ __global__ __launch_bounds__(64) void k_tile_work(int W, int H, int gx, const in
     w += mx;
     wmax = max(wmax, mx);
   }
-  if (lane == 0) work[tile] = w + 2 * wmax;
+  if (lane == 0) { work[tile] = w + 2 * wmax; if (walk) walk[tile] = wmax; }
+}
+// ... and the tile's walk alone (its largest contributor index), for a splatB that rebuilds segment states
+__global__ __launch_bounds__(64) void k_tile_walk(int W, int H, int gx, const int32_t* __restrict__ contrib,
+                                                  int32_t* __restrict__ walk) {
+  const int tile = blockIdx.x, lane = threadIdx.x;
+  const int tx0 = (tile % gx) * EGS_TILE, ty0 = (tile / gx) * EGS_TILE;
+  int mx = 0;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int px = tx0 + (lane & 7) + 8 * (k & 1), py = ty0 + (lane >> 3) + 8 * (k >> 1);
+    if (px < W && py < H) mx = max(mx, contrib[(size_t)py * W + px]);
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
+  if (lane == 0) walk[tile] = mx;
 }
 // capacity of an order buffer: the per-XCD modes pad every class to the largest one
 static int tile_order_len(int gx, int gy) { return 8 * div_up(gy, 8) * gx; }
@@ -1651,6 +1666,8 @@ struct SegArgs {
   float* st2;          // [slot][256] transmittance in FRONT of the segment (launch 3: the running product of the taus)
   int slot_cap, item_cap;
   int32_t* hist_walk;  // nullable: the camera's own walk array (the NEXT render's prediction)
+  int rebuild;         // splatB without the forward pass's states (egs_splat_bwd_seg): `walk` is given (from `contrib`), a
+                       // tile's list ENDS there, the forward launches only rebuild the segment-end states
 };
 static int g_seg_L = 256, g_seg_min = 1024;
 static void seg_config_env() {
@@ -1689,6 +1706,7 @@ static bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
   a->st1 = (float*)(a->st4 + (size_t)a->slot_cap * 256);
   a->st2 = a->st1 + (size_t)a->slot_cap * 256;
   a->hist_walk = nullptr;
+  a->rebuild = 0;
   return (char*)(a->st2 + (size_t)a->slot_cap * 256) <= (char*)ws + bytes;
 }
 
@@ -1746,6 +1764,10 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       hh[q] = backward ? a.walk[t] : (hist ? hist[t] : 0);
       bb[q] = backward ? a.seg_base[t] : -1;
     }
+    if (!backward && a.rebuild) {   // a tile's list ends at its (given) walk; every tile is planned from that length
+#pragma unroll
+      for (int q = 0; q < SP_REGS; ++q) { rr[q].y = rr[q].x + min(max(rr[q].y - rr[q].x, 0), max(hh[q], 0)); }
+    }
     if (!backward) {
       // state slots and compose-item positions of the round's split tiles: ONE wave scan each over the threads' totals
       // (cross-lane operations go through the LDS crossbar on this part: a scan per tile was 20 us of the kernel)
@@ -1801,6 +1823,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       int cnt = valid ? 1 : 0, est = n;
       if (!backward) {
         if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls, speculate); est = L + jitter(t); }
+        else if (a.rebuild) cnt = 0;            // (an unsplit tile has no state to rebuild)
         else if (hist) est = min(max(hh[q], 0), n);
       } else if (valid) {
         const int w = min(max(hh[q], 0), n);
@@ -1966,7 +1989,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
   if (PER_TILE && kind != SEG_COMPOSE) return;
   const int L = sg.hdr[SH_L];
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
-  const int n = r1 - r0;
+  const int n = sg.rebuild ? min(r1 - r0, sg.walk[tile]) : r1 - r0;
   const int tx0 = (tile % p.gx) * EGS_TILE, ty0 = (tile / p.gx) * EGS_TILE;
   const int pxb[2] = {tx0 + (lane & 7), tx0 + (lane & 7) + 8};
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
@@ -2280,7 +2303,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
     }
     if (lane == 0) {
       if (p.work_out) p.work_out[tile] = w + 2 * wmax;
-      sg.walk[tile] = wmax;
+      if (!sg.rebuild) sg.walk[tile] = wmax;      // (rebuilding: the walk of the pass whose `contrib` was handed in stays)
       if (sg.hist_walk) sg.hist_walk[tile] = wmax;
       if (wmax > sg.hdr[SH_MAXWALK]) atomicMax(&sg.hdr[SH_MAXWALK], wmax);
     }
@@ -3313,12 +3336,15 @@ extern "C" int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* to
                                       size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
                                       float* grad_records, const int32_t* prev_tile_work, int order_ready, int flags,
-                                      void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint, void* stream) {
+                                      void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint, int32_t* gsid_plain,
+                                      void* stream) {
+  // gsid_plain (nullable, with EGS_DRAW_MASKED_LISTS: the seven-op surface): receives the list without its masks
   EGS_CHECK_ARG((rec || n == 0) && (!total_patches || patches > 0));
+  EGS_CHECK_ARG(!gsid_plain || ((((uintptr_t)gsid_plain | (uintptr_t)gsid_per_patch) & 15) == 0));
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin, ws_draw,
                          ws_draw_bytes, (const float4*)rec, image, contrib, final_tau, patch_range_per_tile,
                          gsid_per_patch, stream, total_patches, tile_order, grad_records, prev_tile_work, order_ready,
-                         flags, nullptr, seg_ws, seg_ws_bytes, seg_hint);
+                         flags, gsid_plain, seg_ws, seg_ws_bytes, seg_hint);
 }
 
 // [records | packed gradients | tile dispatch order (bounded: larger images keep the plain tile map)]
@@ -3334,7 +3360,11 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
                      float** gpack_out, void* stream, const void* rec_in, const int32_t* tile_order,
                      float* grad_records, bool keep_forward_order, bool masked_lists, void* seg_ws,
-                     size_t seg_ws_bytes) {
+                     size_t seg_ws_bytes, int rebuild, uint32_t* seg_hint) {
+  // rebuild != 0 (with seg_ws of egs_seg_rebuild_ws_bytes): no forward pass left its segment states here -- the public
+  // splatB is handed tensors only -- so they are REBUILT first: every tile's walk from `contrib`, then the forward
+  // segment launches over [0, walk) with their pixels going to scratch.  seg_hint (nullable): the page-locked words
+  // that learn the longest walk (both paths report it: a host decides the path of its NEXT call from it).
   hipStream_t s = (hipStream_t)stream;
   const float4* rec = rec_in ? (const float4*)rec_in : (const float4*)ws;
   // [N][12] packed gradient records: the caller's (already zeroed by the forward draw kernel) or a piece of ws
@@ -3356,15 +3386,49 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
   static const int red = [] { const char* e = getenv("EGS_DRAWB_RED"); return e ? atoi(e) : EGS_DRAWB_RED_DEFAULT; }();
   if (seg_ws) {   // the forward pass split its long lists (egs_splat_draw_rec_seg): one wave per segment
     SegArgs sga;
-    if (pol->footprint != 0 || !seg_carve(seg_ws, seg_ws_bytes, dp.T, &sga)) {
-      set_error(EGS_ERR_WORKSPACE, "segment workspace too small", __FILE__, __LINE__);
+    const size_t hw = (size_t)width * height;
+    const size_t scratch = rebuild ? align_up(20 * hw, 256) + 256 : 0;
+    if (pol->footprint != 0 || !(pol->alpha_skip > 0.f) || !(pol->tau_stop > 0.f) || seg_ws_bytes <= scratch ||
+        !seg_carve(seg_ws, seg_ws_bytes - scratch, dp.T, &sga)) {
+      set_error(EGS_ERR_WORKSPACE, "segment workspace too small (or a policy without a skip / stop threshold)", __FILE__, __LINE__);
       return EGS_ERR_WORKSPACE;
     }
     seg_config_env();
-    EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, (const int32_t*)nullptr, 0,
-               0, sga, 1, (uint32_t*)nullptr, 0);
     const int64_t bound = (int64_t)dp.T + patches / g_seg_L + patches / g_seg_min + 2;
     const int grid = (int)std::min<int64_t>(bound, sga.item_cap);
+    if (rebuild) {
+      sga.rebuild = 1;
+      char* sc = (char*)(((uintptr_t)seg_ws + seg_ws_bytes - scratch + 255) & ~(uintptr_t)255);
+      float* simg = (float*)sc;
+      int32_t* scont = (int32_t*)(sc + 12 * hw);
+      float* stau = (float*)(sc + 16 * hw);
+      DrawParams fp = make_draw_params(width, height, pol);
+      fp.masked = dp.masked;
+      int32_t* rg = const_cast<int32_t*>(patch_range_per_tile);   // (only DIRECT items of an empty tile write it: none here)
+      EGS_LAUNCH("k_tile_walk", k_tile_walk, dim3(dp.T), dim3(64), s, dp.W, dp.H, dp.gx, contrib, sga.walk);
+      EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile,
+                 (const int32_t*)sga.walk, g_seg_L, g_seg_min, sga, 0, seg_hint, 0);
+#define EGS_REB(FLOOR, CLAMP, ROLE, NAME, GRID)                                                                  \
+      EGS_LAUNCH(NAME, (k_draw_seg<FLOOR, CLAMP, ROLE>), dim3(GRID), dim3(64), s, fp, sga, rg, gsid_per_patch, rec, \
+                 simg, scont, stau)
+#define EGS_REB4(FLOOR, CLAMP)                                                                                   \
+      do {                                                                                                       \
+        EGS_REB(FLOOR, CLAMP, 0, "k_draw_seg", grid);                                                            \
+        EGS_REB(FLOOR, CLAMP, 3, "k_draw_seg_prefix", dp.T);                                                     \
+        EGS_REB(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid);                                                        \
+        EGS_REB(FLOOR, CLAMP, 2, "k_draw_seg_compose", dp.T);                                                    \
+      } while (0)
+      switch ((pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0)) {
+        case 0: EGS_REB4(false, false); break;
+        case 1: EGS_REB4(false, true); break;
+        case 2: EGS_REB4(true, false); break;
+        default: EGS_REB4(true, true); break;
+      }
+#undef EGS_REB4
+#undef EGS_REB
+    }
+    EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, (const int32_t*)nullptr, 0,
+               0, sga, 1, (uint32_t*)nullptr, 0);
 #define EGS_DRAWBS(FLOOR, CLAMP)                                                                            \
     EGS_LAUNCH("k_draw_bwd_seg", (k_draw_bwd<false, FLOOR, CLAMP, 7, true>), dim3(grid), dim3(64), s, dp,    \
                patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, gpack, sga)
@@ -3390,8 +3454,9 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     // length mis-ranks tiles whose pixels saturate early; simulated with the measured work of the 1 M scene:
     // makespan 1.11 x ideal by length, 1.03 x by work)
     int32_t* order = (int32_t*)((char*)ws + 2 * align_up((size_t)n * 48, 256));
-    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s,
-                                      tile_order + tile_order_len(dp.gx, dp.gy));
+    const int32_t* wk = tile_order + tile_order_len(dp.gx, dp.gy);      // [work | walk] of the forward draw
+    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s, wk,
+                                      seg_hint ? wk + dp.T : nullptr, seg_hint);
     if (rc) return rc;
   } else if (tile_order && same_mode) {
     // the forward pass left its dispatch order behind (same mode): no second k_tile_order
@@ -3404,11 +3469,14 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
     int32_t* order = (int32_t*)((char*)ws + 2 * align_up((size_t)n * 48, 256));
     const size_t len = (size_t)tile_order_len(dp.gx, dp.gy);
     int32_t* work = nullptr;
+    int32_t* walk = nullptr;
     if (by_work && tile_order_mode(1) > 0 && len + (size_t)dp.T <= BWD_ORDER_CAP) {
       work = order + len;
-      EGS_LAUNCH("k_tile_work", k_tile_work, dim3(dp.T), dim3(64), s, dp.W, dp.H, dp.gx, contrib, work);
+      if (seg_hint && len + 2 * (size_t)dp.T <= BWD_ORDER_CAP) walk = work + dp.T;
+      EGS_LAUNCH("k_tile_work", k_tile_work, dim3(dp.T), dim3(64), s, dp.W, dp.H, dp.gx, contrib, work, walk);
     }
-    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s, work);
+    const int rc = tile_order_enqueue(dp, 1, order, BWD_ORDER_CAP, patch_range_per_tile, s, work, walk,
+                                      walk ? seg_hint : nullptr);
     if (rc) return rc;
   }
   // variants of the backward kernel (bit 0: in-row merges of the wave reduction with bank-masked DPP adds instead
@@ -3530,6 +3598,42 @@ extern "C" int egs_splat_bwd_rec_lists(int n, int64_t patches, int width, int he
                             final_tau, patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream,
                             rec, tile_order, grad_records, false,
                             (flags & (EGS_DRAW_CULLED_LISTS | EGS_DRAW_MASKED_LISTS)) != 0);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,
+             dloss_dus, dloss_dcinv2ds, dloss_dalphas, dloss_dcolors);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// splatB with everything optional that a host may or may not have: the packed records (else packed here from the four
+// tensors), the [order | work | walk] buffer and the cleared gradient records of the forward draw, the forward's
+// segment workspace (rebuild == 0) or a fresh one of egs_seg_rebuild_ws_bytes (rebuild != 0: the segment states are
+// rebuilt from contrib / final_tau first), and the hint words.  seg_ws == NULL: the unsplit kernel.
+extern "C" size_t egs_seg_rebuild_ws_bytes(int64_t patch_capacity, int width, int height) {
+  return egs_seg_ws_bytes(patch_capacity, width, height) + align_up((size_t)20 * width * height, 256) + 512;
+}
+extern "C" int egs_splat_bwd_seg(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
+                                 const float* alphas, const float* colors, const void* rec, const EgsPolicy* pol,
+                                 const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                                 const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                                 const int32_t* tile_order, float* grad_records, float* dloss_dus,
+                                 float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors, int flags,
+                                 void* seg_ws, size_t seg_ws_bytes, int rebuild, uint32_t* seg_hint, void* stream) {
+  EGS_CHECK_ARG(n >= 0 && patches >= 0 && width > 0 && height > 0 && pol);
+  if (n == 0) return 0;
+  EGS_CHECK_ARG(ws && dloss_dus && dloss_dcinv2ds && dloss_dalphas && dloss_dcolors);
+  EGS_CHECK_ARG(rec || (us && cinv2ds && alphas && colors && pol->footprint != 1));
+  if (ws_bytes < egs_splat_bwd_ws_bytes(n)) {
+    set_error(EGS_ERR_WORKSPACE, "splat_bwd workspace too small", __FILE__, __LINE__);
+    return EGS_ERR_WORKSPACE;
+  }
+  float* gpack = nullptr;
+  int rc = splat_bwd_packed(n, patches, width, height, us, cinv2ds, alphas, colors, nullptr, pol, contrib, final_tau,
+                            patch_range_per_tile, gsid_per_patch, dloss_dgammas, ws, ws_bytes, &gpack, stream, rec,
+                            tile_order, grad_records, false,
+                            (flags & (EGS_DRAW_CULLED_LISTS | EGS_DRAW_MASKED_LISTS)) != 0, seg_ws, seg_ws_bytes, rebuild,
+                            seg_hint);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   EGS_LAUNCH("k_unpack_grads", k_unpack_grads, dim3(div_up(n, 256)), dim3(256), s, n, (const float4*)gpack,

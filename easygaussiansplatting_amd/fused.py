@@ -346,7 +346,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                                               ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                               _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
                                               order_ready, draw_flags, _ptr(S.seg),
-                                              S.seg.numel() if S.seg is not None else 0, seg_hint, st))
+                                              S.seg.numel() if S.seg is not None else 0, seg_hint, None, st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -467,7 +467,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                                               _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
                                               _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
                                               _ptr(S.gpack), prev_work, order_ready, draw_flags, _ptr(S.seg),
-                                              S.seg.numel() if S.seg is not None else 0, seg_hint, st))
+                                              S.seg.numel() if S.seg is not None else 0, seg_hint, None, st))
     except BaseException:
         # Whatever was enqueued before the failure (the arm, the binning chain) still stores {P, max key} into the
         # slot: it goes back on the free list only once those kernels have run -- otherwise a render on another

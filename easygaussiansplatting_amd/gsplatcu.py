@@ -302,7 +302,7 @@ MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's 
 class SplatRecords:
     """Opaque: what one ``splat`` call left for the ``splatB`` of the same tensors (see above)."""
     __slots__ = ("tensors", "sig", "width", "height", "policy", "rec", "order", "gpack", "dev_index", "stream",
-                 "lists", "pair", "pair_sig", "stamp", "n", "npatch", "visible")
+                 "lists", "pair", "pair_sig", "stamp", "n", "npatch", "visible", "seg")
 
     def matches(self, dev, st, tensors, width, height):
         if (self.dev_index != dev.index or self.stream != int(st.value or 0) or self.width != width
@@ -341,7 +341,7 @@ def _make_records(dev, st, tensors, width, height, rec, order, gpack, lists=None
     if sig is None:
         return None
     h = SplatRecords()
-    h.stamp, h.n, h.npatch, h.visible = stamp, n, npatch, None
+    h.stamp, h.n, h.npatch, h.visible, h.seg = stamp, n, npatch, None, None
     h.tensors, h.sig, h.width, h.height, h.policy = tensors, sig, width, height, _policy_name
     h.rec, h.order, h.gpack, h.dev_index, h.stream = rec, order, gpack, dev.index, int(st.value or 0)
     # the list WITH block masks the forward draw walked, valid for the (gsid_per_patch, patch_range_per_tile) pair
@@ -435,6 +435,16 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
             # the packed gradient records of a splatB that may follow: cleared on the side by the draw kernel (it is
             # VALU-bound, the memory system idles), good for ONE backward pass
             gpack = torch.empty((n, 12), dtype=torch.float32, device=dev)
+    # Long tile lists split over several waves (include/egs_hip.h egs_splat_draw_rec_seg): taken when the longest walk a
+    # recent call of this problem size reported exceeds the split threshold (page-locked hint words, read without
+    # waiting; fused._seg_decision).  The op has no camera identity, so there is no walk on record per view: every
+    # segment of a list is speculated when the scene's renders walk most of their lists, else segment 0 + one wave
+    # continuing -- the BACKWARD pass is split either way (with the handle: from these states; public splatB: rebuilt).
+    from . import fused as _fused            # (the per-device mailbox / capacity / hint state lives there)
+    ctx = _fused._ctx(dev)
+    use_seg, seg_hint = _fused._seg_decision(ctx, lib, key, _pol()) if n > 0 else (False, None)
+    seg_flags = 8 if (use_seg and getattr(_fused._tls, "seg_speculate", False)) else 0     # EGS_DRAW_SEG_SPECULATE
+    seg_ws = [None]
     lists = [None]     # the list the draw kernels walked (with masks), kept for the backward draw
     # content stamps of us / cinv2ds / alphas (public pair: splatB validates what it is given against them)
     stamp = torch.empty(lib.egs_pair_stamp_words(n), dtype=torch.int32, device=dev) if (masks and keep == "public") else None
@@ -448,6 +458,7 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
                               lists[0], (gsid, ranges) if lists[0] is not None else None)
             if h is not None:
                 h.visible = visible
+                h.seg = seg_ws[0]       # the segment states of this draw (long lists split over waves), if any
             return h
         if keep == "public" and lists[0] is not None:   # no tensor is referenced, no record kept: values are validated
             return _make_records(dev, st, None, width, height, None, order, gpack, lists[0], None, stamp, n,
@@ -472,10 +483,14 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
         # (with masks the range kernel also writes the plain list the caller gets: no strip launch)
-        _lib.check(lib.egs_splat_draw_rec_plain(n, patches, width, height, _ptr(rec), pol, _ptr(ws_bin), _ptr(ws_draw),
-                                                ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau),
-                                                _ptr(ranges), _ptr(walked), _ptr(gsid) if masks else None, _ptr(order),
-                                                _ptr(gpack), flags, st))
+        seg_ws[0] = torch.empty(lib.egs_seg_ws_bytes(max(patches, 1), width, height), dtype=torch.uint8,
+                                device=dev) if use_seg else None
+        _lib.check(lib.egs_splat_draw_rec_seg(n, patches, None, width, height, _ptr(rec), pol, _ptr(ws_bin),
+                                              _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau),
+                                              _ptr(ranges), _ptr(walked), _ptr(order), _ptr(gpack), None, 0,
+                                              flags | seg_flags, _ptr(seg_ws[0]),
+                                              seg_ws[0].numel() if use_seg else 0, seg_hint,
+                                              _ptr(gsid) if masks else None, st))
         if masks:
             lists[0] = walked
         return gsid
@@ -489,8 +504,6 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
     # host has seen P: buffers sized by the largest count met so far (+6 %), the count taken from device memory,
     # {P, max depth key} delivered into a page-locked mailbox slot by the binning kernels.  `gsid_per_patch` must
     # come back with exactly P rows, so the host still waits for P -- while the GPU draws.
-    from . import fused as _fused            # (the per-device mailbox / capacity state lives there)
-    ctx = _fused._ctx(dev)
     cap = ctx.capacity.get(key, 0) if (_fused.ENQUEUE_AHEAD and n > 0) else 0
     slot = None
     if cap > 0:
@@ -514,11 +527,14 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         walked_full = torch.empty(cap, dtype=torch.int32, device=dev) if masks else gsid_full
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, cap, width, height)
         ws_draw = torch.empty(ws_draw_bytes, dtype=torch.uint8, device=dev)
-        _lib.check(lib.egs_splat_draw_rec_dev_plain(n, cap, _ptr(total), width, height, _ptr(rec), pol, _ptr(ws_bin),
-                                                    _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
-                                                    _ptr(final_tau), _ptr(ranges), _ptr(walked_full),
-                                                    _ptr(gsid_full) if masks else None, _ptr(order), _ptr(gpack),
-                                                    flags, st))
+        seg_ws[0] = torch.empty(lib.egs_seg_ws_bytes(cap, width, height), dtype=torch.uint8, device=dev) if use_seg \
+            else None
+        _lib.check(lib.egs_splat_draw_rec_seg(n, cap, _ptr(total), width, height, _ptr(rec), pol, _ptr(ws_bin),
+                                              _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
+                                              _ptr(final_tau), _ptr(ranges), _ptr(walked_full), _ptr(order),
+                                              _ptr(gpack), None, 0, flags | seg_flags, _ptr(seg_ws[0]),
+                                              seg_ws[0].numel() if use_seg else 0, seg_hint,
+                                              _ptr(gsid_full) if masks else None, st))
     except BaseException:
         # Kernels enqueued before the failure (the arm, the binning chain) still store {P, max key} into the slot:
         # it may only go back on the free list once they have run, or a later render that picks it up could settle
@@ -580,11 +596,18 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     st = _stream()
     rec, order, gpack, walked = (None, None, None, None)
+    seg, rebuild, seg_hint = None, 0, None
     if n > 0 and pol.footprint != 1:   # (the pixel-box policy's records also depend on `areas`, which splat mutates)
+        from . import fused as _fused
+        use_seg, seg_hint = _fused._seg_decision(_fused._ctx(dev), lib, (n, width, height), pol)
         if records is not None:        # explicit handle: trusted if the signatures still match
             rec, order, gpack = _take_records(records, dev, st, (us, cinv2ds, alphas, colors), width, height)
             if rec is not None:        # ... and the list with block masks, if gsid / ranges are that splat's own pair
                 walked = _walked_lists(records, gsid, ranges)
+                # ... and the segment states of that draw, if it split its long lists (valid for that very list pair)
+                sig = _memo_sig((gsid, ranges))
+                if records.seg is not None and sig is not None and sig == records.pair_sig:
+                    seg = records.seg
         elif _memo_enabled:            # public pair: what the last splat of this stream kept, validated by CONTENT
             h = _splat_memo.get((dev.index, int(st.value or 0)))
             npatch = gsid.shape[0]
@@ -599,12 +622,21 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
                                                          _ptr(stamp_b), npatch, _ptr(h.lists), _ptr(gsid), st))
                 walked, order = h.lists, h.order
                 gpack, h.gpack = h.gpack, None
-    if rec is not None:     # the records (and the measured per-tile work) of the splat call these tensors came from
-        _lib.check(lib.egs_splat_bwd_rec_lists(n, gsid.shape[0], width, height, _ptr(rec), C.byref(pol), _ptr(contrib),
-                                               _ptr(final_tau), _ptr(ranges), _ptr(gsid if walked is None else walked),
-                                               _ptr(dl), _ptr(ws), ws_bytes, _ptr(order), _ptr(gpack), _ptr(d_us),
-                                               _ptr(d_cinv), _ptr(d_alpha), _ptr(d_color), 0 if walked is None else 2,
-                                               st))
+    if n > 0 and pol.footprint != 1:
+        # one entry point for every combination of what this call was handed (records / order / cleared gradient
+        # records or nothing; the forward's segment states, or none: with long walks on record they are REBUILT from
+        # contrib -- a forward-draw's worth of work that removes the serial tail of one wave per tile)
+        if seg is None and use_seg and gsid.shape[0] > 0:
+            seg = torch.empty(lib.egs_seg_rebuild_ws_bytes(gsid.shape[0], width, height), dtype=torch.uint8, device=dev)
+            rebuild = 1
+        _lib.check(lib.egs_splat_bwd_seg(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
+                                         _ptr(colors), _ptr(rec), C.byref(pol), _ptr(contrib), _ptr(final_tau),
+                                         _ptr(ranges), _ptr(gsid if walked is None else walked), _ptr(dl), _ptr(ws),
+                                         ws_bytes, _ptr(order), _ptr(gpack), _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha),
+                                         _ptr(d_color), 0 if walked is None else 2, _ptr(seg),
+                                         seg.numel() if seg is not None else 0, rebuild, seg_hint, st))
+    elif rec is not None:   # (unreachable: records are only taken under the tile-footprint policies)
+        raise AssertionError
     else:
         _lib.check(lib.egs_splat_bwd(n, gsid.shape[0], width, height, _ptr(us), _ptr(cinv2ds), _ptr(alphas),
                                      _ptr(colors), _ptr(areas), C.byref(pol), _ptr(contrib), _ptr(final_tau),

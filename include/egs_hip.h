@@ -336,7 +336,30 @@ int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* total_patches
                            size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                            int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
                            float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/, int order_ready,
-                           int flags, void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint /*nullable*/, void* stream);
+                           int flags, void* seg_ws /*nullable: the unsplit draw stage*/, size_t seg_ws_bytes,
+                           uint32_t* seg_hint /*nullable*/,
+                           int32_t* gsid_plain /*nullable; with EGS_DRAW_MASKED_LISTS: the list without its masks, what
+                                                 the caller of `splat` gets (as egs_splat_draw_rec_plain)*/,
+                           void* stream);
+/* splatB for a host that may or may not have kept what its forward pass left (the seven-op surface: `splatB` is handed
+ * tensors).  rec (nullable: packed here from us / cinv2ds / alphas / colors), tile_order / grad_records (nullable: the
+ * forward draw's [order | work | walk] buffer and cleared gradient records), flags as egs_splat_bwd_rec_lists.
+ * seg_ws == NULL: the unsplit kernel (egs_splat_bwd / egs_splat_bwd_rec_lists).  seg_ws + rebuild == 0: the workspace the
+ * forward's egs_splat_draw_rec_seg filled.  seg_ws of egs_seg_rebuild_ws_bytes(patches, ..) + rebuild != 0: nothing
+ * was kept -- every tile's walk is read off `contrib`, the forward segment launches run once more over [0, walk) with
+ * their pixels going to scratch (they only rebuild the segment-end states: about the cost of a forward draw), then
+ * every segment is walked backward by a wave of its own: on scene.skewed_scene after reset_alpha 3.4 ms of one-wave-
+ * per-tile backward draw become ~1.2 ms.  seg_hint (nullable): page-locked words that learn the longest walk from
+ * either path -- a host decides from them whether its next call brings a workspace. */
+size_t egs_seg_rebuild_ws_bytes(int64_t patch_capacity, int width, int height);
+int egs_splat_bwd_seg(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
+                      const float* alphas, const float* colors, const void* rec /*nullable*/, const EgsPolicy* pol,
+                      const int32_t* contrib, const float* final_tau, const int32_t* patch_range_per_tile,
+                      const int32_t* gsid_per_patch, const float* dloss_dgammas, void* ws, size_t ws_bytes,
+                      const int32_t* tile_order /*nullable*/, float* grad_records /*nullable*/, float* dloss_dus,
+                      float* dloss_dcinv2ds, float* dloss_dalphas, float* dloss_dcolors, int flags,
+                      void* seg_ws /*nullable*/, size_t seg_ws_bytes, int rebuild, uint32_t* seg_hint /*nullable*/,
+                      void* stream);
 /* As egs_splat_draw_rec, for a host that enqueues the draw stage BEFORE it has read total_patches (no GPU
  * idle time around the read-back): patch_capacity sizes gsid_per_patch and ws_draw
  * (egs_splat_draw_ws_bytes(n, patch_capacity, ..)), the real patch count is taken from total_patches[0] on

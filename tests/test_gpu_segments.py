@@ -153,3 +153,59 @@ def test_segments_skewed_scene_full_size(fx):
         d = np.abs(got["image"][:, ys, xs] - o_img[:, ys, xs]).max(0)
         flip = got["contrib"][ys, xs] != o_cont[ys, xs]
         assert flip.sum() <= 8 and d[~flip].max() < 1e-4, (t, int(flip.sum()), d.max())
+
+
+@pytest.mark.parametrize("reset", [False, True])
+@pytest.mark.parametrize("how", ["public", "handle"])
+def test_seven_op_surface_splits_long_lists(fx, reset, how):
+    """``gsplatcu.splat`` / ``splatB`` (ext.cpp:10-32) on the segment path: the public pair -- ``splatB`` is handed
+    tensors, so it REBUILDS the segment states from ``contrib`` (egs_splat_bwd_seg, rebuild) -- and the records handle
+    (the forward's states are reused).  Lists bit-exact, image / contrib / final_tau and the four gradient tensors equal
+    to the unsplit kernels', speculated forward segments included."""
+    fused, lib = fx
+    from easygaussiansplatting_amd import _lib, gsplatcu as gsc
+    W, H = 320, 240
+    sc = S.small_scene(60_000, W, H, 3, seed=5)
+    sc.scales[:] = sc.scales * 2.2
+    if reset:
+        sc.alphas[:] = np.minimum(sc.alphas, 0.01)
+    cam = sc.cam
+    pws, rots, scales, alphas, shs = map(dev, (sc.pws, sc.rots, sc.scales, sc.alphas, sc.shs))
+    Rcw, tcw, twc = dev(cam.Rcw), dev(cam.tcw), dev(cam.twc)
+    us, pcs, depths = gsc.project(pws, Rcw, tcw, cam.fx, cam.fy, cam.cx, cam.cy, False)
+    cov3 = gsc.computeCov3D(rots, scales, depths, False)[0]
+    cov2 = gsc.computeCov2D(cov3, pcs, Rcw, depths, cam.fx, cam.fy, cam.width, cam.height, False)[0]
+    col = gsc.sh2Color(shs, pws, twc, False)[0]
+    cinv, areas = gsc.inverseCov2D(cov2, depths, False)
+    dl = dev(S.normal(3, 23, (3, H, W)).astype(np.float32) / (3 * H * W))
+
+    def both():
+        d, a = depths.clone(), areas.clone()
+        if how == "handle":
+            out, h = gsc.splat_with_records(H, W, us, cinv, alphas, d, col, a)
+        else:
+            out, h = gsc.splat(H, W, us, cinv, alphas, d, col, a), None
+        g = gsc.splatB(H, W, us, cinv, alphas, d, col, out[1], out[2], out[3], out[4], dl, records=h)
+        return [host(x) for x in out], [host(x) for x in g], h
+    keep_spec = fused.SEG_SPECULATE
+    try:
+        fused.SEGMENTS = "0"
+        ref_out, ref_g, _ = both()
+        lens = ref_out[3][:, 1] - ref_out[3][:, 0]
+        assert lens.max() > 512
+        fused.SEGMENTS = "1"
+        _lib.check(lib.egs_seg_config(64, 128, None))
+        for spec in ("0", "1"):
+            fused.SEG_SPECULATE = spec
+            out, g, h = both()
+            assert how == "public" or (h is not None and h.seg is not None)
+            assert np.array_equal(out[3], ref_out[3]) and np.array_equal(out[4], ref_out[4])     # ranges, gsid_per_patch
+            flip = out[1] != ref_out[1]
+            assert flip.sum() <= 8, int(flip.sum())
+            d = np.abs(out[0] - ref_out[0]).max(0)
+            assert d[~flip].max() < 2e-5 and np.abs(out[2] - ref_out[2])[~flip].max() < 1e-5
+            for a, b, nm in zip(g, ref_g, ("dus", "dcinv", "dalpha", "dcolor")):
+                assert_grad_close(a, b, "ops_%s_%s_spec%s:%s" % (how, "reset" if reset else "opaque", spec, nm),
+                                  tol_max=1e-4, med_rel=2e-5, max_rel=2e-3, outliers=8)
+    finally:
+        fused.SEG_SPECULATE = keep_spec
