@@ -1969,7 +1969,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
 // The blend loop is k_draw's, unchanged (one stop threshold for the whole wave: a re-walk or a continuation starts
 // from the TRUE transmittance, not from 1).
 template <bool FLOOR, bool CLAMP, int ROLE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 8 : 5, 8))) void k_draw_seg(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 8 : (ROLE == 2 ? 4 : 5), 8))) void k_draw_seg(
     DrawParams p, SegArgs sg, int32_t* __restrict__ ranges, const int32_t* __restrict__ gsid,
     const float4* __restrict__ rec, float* __restrict__ image, int32_t* __restrict__ contrib,
     float* __restrict__ final_tau) {
