@@ -49,6 +49,7 @@ ACCUMULATE = 64           # include/egs_hip.h EGS_BWD_ACCUMULATE
 FACTORED_SH = 128         # include/egs_hip.h EGS_BWD_FACTORED_SH
 GSID_MASK = 0x0FFFFFFF    # csrc/egs_common.h EGS_GSID_MASK
 MAILBOX_SLOTS = 64
+HINT_SLOTS = 16           # problem sizes that keep a hint slot (longest list / longest walk of their recent renders)
 
 
 class FusedState:
@@ -232,12 +233,18 @@ def _seg_decision(ctx, lib, key, pol_):
     if SEGMENTS == "0" or pol_.footprint != 0 or not (pol_.alpha_skip > 0) or not (pol_.tau_stop > 0):
         return False, None
     with ctx.lock:
-        slot = ctx.seg_hint.get(key)
+        slot = ctx.seg_hint.pop(key, None)
         if slot is None:
-            if len(ctx.free) <= MAILBOX_SLOTS // 2:      # (never starve the renders of their read-back slots)
+            # at most HINT_SLOTS problem sizes keep a slot; the least recently used one hands its slot on (a kernel of
+            # that size still in flight may write into it once more: a stale hint, never a wrong result)
+            if len(ctx.seg_hint) >= HINT_SLOTS:
+                slot = ctx.seg_hint.pop(next(iter(ctx.seg_hint)))
+            elif len(ctx.free) > MAILBOX_SLOTS // 2:     # (never starve the renders of their read-back slots)
+                slot = ctx.free.pop()
+            else:
                 return SEGMENTS == "1", None
-            slot = ctx.seg_hint[key] = ctx.free.pop()
             _lib.check(lib.egs_mailbox_clear(ctx.mb, slot))
+        ctx.seg_hint[key] = slot                         # (re-inserted: most recently used)
     out = (C.c_uint32 * 4)()
     _lib.check(lib.egs_mailbox_peek(ctx.mb, slot, out))
     cfg = (C.c_int * 2)()
