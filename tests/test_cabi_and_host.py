@@ -118,10 +118,15 @@ def test_product_path_never_imports_the_oracle():
                     src = open(os.path.join(root, f)).read()
                     code = "\n".join(ln for ln in src.splitlines() if re.match(r"\s*(from|import)\s", ln))
                     assert "oracle" not in code, os.path.join(root, f)
-    # bench.py imports the oracle only inside cpu_baseline()
-    bench = open(os.path.join(REPO, "bench.py")).read()
-    top_level = "\n".join(ln for ln in bench.splitlines() if re.match(r"(from|import)\s", ln))
-    assert "oracle" not in top_level
+    # bench.py (and its helper module tools/benchlib.py) import the oracle only inside cpu_baseline()
+    for f in ("bench.py", os.path.join("tools", "benchlib.py")):
+        src = open(os.path.join(REPO, f)).read()
+        top_level = "\n".join(ln for ln in src.splitlines() if re.match(r"(from|import)\s", ln))
+        assert "oracle" not in top_level, f
+        inside = [ln for ln in src.splitlines() if re.match(r"\s+(from|import)\s.*oracle", ln)]
+        assert len(inside) == (1 if f.endswith("benchlib.py") else 0), (f, inside)      # ... and exactly there
+    lib = open(os.path.join(REPO, "tools", "benchlib.py")).read()
+    assert lib.index("def cpu_baseline") < lib.index("from oracle import") < lib.index("def relaunch_command")
 
 
 def test_reference_module_names_resolve_without_a_gpu():
