@@ -25,12 +25,10 @@ a = ap.parse_args()
 
 import torch
 from easygaussiansplatting_amd import scene as S
-from easygaussiansplatting_amd.function import Camera, GSFunction, render
+from easygaussiansplatting_amd.function import Camera, GSFunction, RenderOptions, render
 
 dev = torch.device("cuda", 0)
-GSFunction.mode = a.mode
-if a.public_pair:
-    GSFunction.ops_use_records = False
+opts = RenderOptions(mode=a.mode, ops_use_records=not a.public_pair)       # per call, not a process-wide switch
 sc = S.big_scene(a.gaussians, a.width, a.height, 48)
 cam = Camera.from_scene(sc.cam, dev)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
@@ -53,7 +51,6 @@ for _ in range(a.steps):
         from easygaussiansplatting_amd import dist_views as DV, fused
         if a.factored and "fx" not in globals():
             fx = DV.FactoredShGrad(1)
-        import contextlib
         opt.zero_grad(set_to_none=True)
         if a.factored:      # (Trainer._render_views: a persistent `us` leaf, the loss kernels hand over dL/dimage)
             from easygaussiansplatting_amd.loss import gau_loss_with_grad
@@ -63,9 +60,12 @@ for _ in range(a.steps):
             us.grad = None
         else:
             us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-        with fused.deferred() as d, (fx.attach() if a.factored else contextlib.nullcontext()):
+        if a.factored:
+            fx.begin_step(sc.n, dev)
+        ropts = RenderOptions(accumulate=a.factored, sh_sink=fx if a.factored else None)
+        with fused.deferred() as d:
             img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
-                                         raw["scales_raw"], raw["rots_raw"], us, cam)
+                                         raw["scales_raw"], raw["rots_raw"], us, cam, ropts)
             if a.factored:
                 stats, dimg = gau_loss_with_grad(img.detach(), gt, grad_scale=1.0)
                 img.backward(dimg)
@@ -86,7 +86,7 @@ for _ in range(a.steps):
             for p in P.values():
                 p.grad = None
             us0.grad = None
-            img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam)
+            img, _ = GSFunction.apply(P["pws"], P["shs"], P["alphas"], P["scales"], P["rots"], us0, cam, opts)
             img.backward(dl)
             assert not d.commit()
 torch.cuda.synchronize()
