@@ -1649,21 +1649,21 @@ constexpr int SEG_HDR = 16;          // header words: see SegLayout
 constexpr int SEG_SLOT_FLOATS = 256 * 6;
 constexpr uint32_t SEG_TILE_MASK = 0x7FFFFu, SEG_SEG_MASK = 0x7FFu;   // item = tile | seg << 19 | kind << 30
 constexpr int SEG_SPEC = 1, SEG_COMPOSE = 2;   // (0: a DIRECT item, the bare tile index)
-enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_ITEMSB = 5, SH_L = 6, SH_MIN = 7,
+enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_L = 6, SH_MIN = 7,
        SH_MAXWALK = 8 /* longest walk of THIS render, gathered by the draw items */,
        SH_HINT = 10 /* two words: the host's hint slot */ };
 struct SegArgs {
   int32_t* hdr;        // SEG_HDR words
   int32_t* seg_base;   // [T] first state slot of a split tile, -1: not split
-  int32_t* walk;       // [T] how far the forward pass walked the tile (largest contributor index): the backward plan
-  int32_t* items1;     // forward, launches 0 and 1: DIRECT / SPEC
+  int32_t* walk;       // [T] how far the forward pass walked the tile (largest contributor index; rebuilding: given)
+  int32_t* items1;     // DIRECT / SPEC items: forward launches 0 and 1, and the backward launch (COMPOSE appends the
+                       // segments it had to walk itself, so every walked segment of a split tile is in the list)
   int32_t* items3;     // forward, launch 2: COMPOSE(nspec), one per split tile
-  int32_t* itemsB;     // backward: DIRECT / SPEC
   int32_t* tmp;        // [T] plan scratch: (bin, rank inside the bin) of the tile's items
   int32_t* tmp2;       // [T] plan scratch: the tile's item count (-1: one DIRECT item)
   float4* st4;         // [slot][256] (C_local.rgb, tau_local) -> after COMPOSE (G.rgb, T_end)
   float* st1;          // [slot][256] last contributor (int bits) -> T_end
-  float* st2;          // [slot][256] transmittance in FRONT of the segment (launch 3: the running product of the taus)
+  float* st2;          // [slot][256] tau_local again, dense (launch 1 multiplies the taus in front of its segment)
   int slot_cap, item_cap;
   int32_t* hist_walk;  // nullable: the camera's own walk array (the NEXT render's prediction)
   int rebuild;         // splatB without the forward pass's states (egs_splat_bwd_seg): `walk` is given (from `contrib`), a
@@ -1683,11 +1683,11 @@ static void seg_config_env() {
 }
 static size_t seg_fixed_words(int T) { return (size_t)SEG_HDR + 48 + 5 * (size_t)align_up((size_t)T, 64); }
 static size_t seg_ws_bytes_for(int64_t slots, int T) {
-  return 4 * (seg_fixed_words(T) + 2 * ((size_t)T + (size_t)slots + 64)) + (size_t)slots * SEG_SLOT_FLOATS * 4 + 1024;
+  return 4 * (seg_fixed_words(T) + ((size_t)T + (size_t)slots + 64)) + (size_t)slots * SEG_SLOT_FLOATS * 4 + 1024;
 }
 static bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
   if (!ws || bytes < seg_ws_bytes_for(16, T)) return false;
-  const size_t per_slot = SEG_SLOT_FLOATS * 4 + 8;
+  const size_t per_slot = SEG_SLOT_FLOATS * 4 + 4;
   const int64_t slots = (int64_t)((bytes - seg_ws_bytes_for(0, T)) / per_slot);
   if (slots < 16) return false;
   const size_t Tp = align_up((size_t)T, 64);
@@ -1701,7 +1701,6 @@ static bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
   a->item_cap = (int)std::min<int64_t>((int64_t)T + slots, (int64_t)1 << 20);
   a->slot_cap = (int)std::min<int64_t>(slots, (int64_t)a->item_cap - T);
   a->items1 = w; w += (size_t)T + (size_t)slots + 64;
-  a->itemsB = w; w += (size_t)T + (size_t)slots + 64;
   a->st4 = (float4*)(((uintptr_t)w + 255) & ~(uintptr_t)255);
   a->st1 = (float*)(a->st4 + (size_t)a->slot_cap * 256);
   a->st2 = a->st1 + (size_t)a->slot_cap * 256;
@@ -1710,10 +1709,11 @@ static bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
   return (char*)(a->st2 + (size_t)a->slot_cap * 256) <= (char*)ws + bytes;
 }
 
-// One workgroup plans a launch: which tiles are split (forward only: state slots are handed out here), the work items,
-// longest first (counting sort on the estimated walk, as k_tile_order), and the list statistics the host steers by.
-//   backward == 0:  ranges (+ hist: the walks this camera's previous render measured) -> seg_base, items1, items3, hdr
-//   backward == 1:  seg_base + walk (this render's) -> itemsB
+// One workgroup plans a render: which tiles are split (state slots are handed out here), the work items, longest first
+// (counting sort on the estimated walk, as k_tile_order), and the list statistics the host steers by:
+//   ranges (+ hist: the walks this camera's previous render measured) -> seg_base, items1, items3, hdr
+// The BACKWARD launch runs over the same items1 (a second plan from this render's walks cost 31 us on its one CU for
+// a marginally better order): a segment the pixels never reached returns after its first loads.
 // Segment 0 of a split tile is ALWAYS a SPEC item: it starts from tau = 1 like the unsplit walk, so it is exact and
 // never wasted; further SPEC items follow the prediction (walk + a quarter), the COMPOSE item walks on where they end.
 constexpr int SP_REGS = 8;     // tiles per thread and round whose inputs are requested together (the kernel is a chain
@@ -1730,22 +1730,21 @@ __device__ __forceinline__ int seg_nspec(const int32_t* __restrict__ hist, int h
 }
 __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restrict__ ranges,
                                                    const int32_t* __restrict__ hist, int L, int split_min, SegArgs a,
-                                                   int backward, uint32_t* __restrict__ hint_host, int speculate) {
+                                                   uint32_t* __restrict__ hint_host, int speculate) {
   constexpr int NB = 4096;
   __shared__ uint32_t bins[NB];
   __shared__ uint32_t wsum[16];
   __shared__ int s_slots, s_n3, s_max, s_mw;
   const int tid = threadIdx.x, lane = tid & 63;
 #ifdef EGS_PLAN_STAMPS
-#define PLAN_STAMP(k) do { if (tid == 0) a.hdr[16 + 2 * backward * 8 + (k)] = (int)wall_clock64(); } while (0)
+#define PLAN_STAMP(k) do { if (tid == 0) a.hdr[16 + (k)] = (int)wall_clock64(); } while (0)
 #else
 #define PLAN_STAMP(k) do { } while (0)
 #endif
   PLAN_STAMP(0);
-  int mw = 0;     // longest walk seen by this thread (forward: the previous render's; backward: this render's)
+  int mw = 0;     // longest walk of the camera's previous render seen by this thread
   for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
   if (tid == 0) { s_slots = 0; s_n3 = 0; s_max = 0; s_mw = 0; }
-  if (backward) { L = a.hdr[SH_L]; split_min = a.hdr[SH_MIN]; }
   const int Ls = 31 - __clz(L);
   __syncthreads();
   auto bin_of = [&](int est) { return NB - 1 - min(max(est, 0) >> 3, NB - 1); };
@@ -1761,14 +1760,14 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
     for (int q = 0; q < SP_REGS; ++q) {
       const int t = min(t0 + q * 1024 + tid, T - 1);
       rr[q] = reinterpret_cast<const int2*>(ranges)[t];
-      hh[q] = backward ? a.walk[t] : (hist ? hist[t] : 0);
-      bb[q] = backward ? a.seg_base[t] : -1;
+      hh[q] = hist ? hist[t] : 0;
+      bb[q] = -1;
     }
-    if (!backward && a.rebuild) {   // a tile's list ends at its (given) walk; every tile is planned from that length
+    if (a.rebuild) {   // a tile's list ends at its (given) walk; every tile is planned from that length
 #pragma unroll
       for (int q = 0; q < SP_REGS; ++q) { rr[q].y = rr[q].x + min(max(rr[q].y - rr[q].x, 0), max(hh[q], 0)); }
     }
-    if (!backward) {
+    {
       // state slots and compose-item positions of the round's split tiles: ONE wave scan each over the threads' totals
       // (cross-lane operations go through the LDS crossbar on this part: a scan per tile was 20 us of the kernel)
       uint32_t want = 0u, nsp = 0u;
@@ -1821,16 +1820,8 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       const bool valid = t < T;
       const int n = max(rr[q].y - rr[q].x, 0);
       int cnt = valid ? 1 : 0, est = n;
-      if (!backward) {
-        if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls, speculate); est = L + jitter(t); }
-        else if (a.rebuild) cnt = 0;            // (an unsplit tile has no state to rebuild)
-        else if (hist) est = min(max(hh[q], 0), n);
-      } else if (valid) {
-        const int w = min(max(hh[q], 0), n);
-        mw = max(mw, w);
-        est = w;
-        if (bb[q] >= 0) { cnt = (w + L - 1) >> Ls; est = min(w, L) + jitter(t); }
-      }
+      if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls, speculate); est = L + jitter(t); }
+      else if (hist) est = min(max(hh[q], 0), n);
       uint32_t packed = 0xFFFFFFFFu;
       if (cnt > 0) {
         const int b = bin_of(est);
@@ -1861,7 +1852,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
   }
   __syncthreads();
   const int total = (int)wsum[0];
-  int32_t* __restrict__ items = backward ? a.itemsB : a.items1;
+  int32_t* __restrict__ items = a.items1;
   // pass 2: a tile's items go to [start of its bin + its rank, + count).  Only the HEAD of a run is written here (a
   // lane filling its own tile's run is one store instruction per item and wave; the whole wave filling one run after
   // the other is 40 instructions per split tile on the one CU this kernel runs on: 12 us per 1000 split tiles); pass 3
@@ -1886,10 +1877,8 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
       if (t >= T || pp[q] == 0xFFFFFFFFu) continue;
       const int slot = (int)(bins[pp[q] >> 20] + (pp[q] & 0xFFFFFu));
       if (slot >= ntot) continue;
-      // DIRECT: the bare tile index; split: segment 0 first (forward) / the deepest segment first (backward: it starts
-      // from the pixels' own final state)
-      items[slot] = cc[q] < 0 ? t : (int32_t)((uint32_t)t | ((uint32_t)(backward ? cc[q] - 1 : 0) << 19) |
-                                               ((uint32_t)SEG_SPEC << 30));
+      // DIRECT: the bare tile index; split: segment 0 first
+      items[slot] = cc[q] < 0 ? t : (int32_t)((uint32_t)t | ((uint32_t)SEG_SPEC << 30));
     }
   }
   __syncthreads();
@@ -1929,7 +1918,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
         const int i = i0 + k;
         if (i < ntot) {
           if (v[k] != -1) { head = v[k]; hpos = i; }
-          else if (hpos >= 0) items[i] = backward ? head - ((i - hpos) << 19) : head + ((i - hpos) << 19);
+          else if (hpos >= 0) items[i] = head + ((i - hpos) << 19);
         }
       }
       __syncthreads();
@@ -1938,28 +1927,22 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
   }
   PLAN_STAMP(5);
   if (tid == 0) {
-    if (!backward) {
-      a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
-      a.hdr[SH_MAXLEN] = s_max; a.hdr[SH_SPLIT] = s_n3; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
-      a.hdr[SH_ITEMSB] = 0; a.hdr[SH_MAXWALK] = 0;
-      // page-locked words the host peeks at before a LATER render: the longest list, and the longest walk of the
-      // camera's previous render (the backward plan overwrites it with this render's)
-      if (hint_host) { hint_host[0] = (uint32_t)s_max; if (hist) hint_host[1] = (uint32_t)s_mw; }
-      *reinterpret_cast<uint32_t**>(a.hdr + SH_HINT) = hint_host;
-    } else {
-      a.hdr[SH_ITEMSB] = min(total, a.item_cap);
-      uint32_t* hh_ = *reinterpret_cast<uint32_t**>(a.hdr + SH_HINT);
-      if (hh_) hh_[1] = (uint32_t)s_mw;
-    }
+    a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
+    a.hdr[SH_MAXLEN] = s_max; a.hdr[SH_SPLIT] = s_n3; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
+    a.hdr[SH_MAXWALK] = 0;
+    // page-locked words the host peeks at before a LATER render: the longest list, and the longest walk of the
+    // camera's previous render (k_seg_report overwrites it with this render's)
+    if (hint_host) { hint_host[0] = (uint32_t)s_max; if (hist) hint_host[1] = (uint32_t)s_mw; }
+    *reinterpret_cast<uint32_t**>(a.hdr + SH_HINT) = hint_host;
   }
 }
 
 // The forward kernels over work items (see above), tile-footprint policies with a skip threshold only (the pixel-box
-// policy of forward_cpu.py has no early stop to speak of and is not a training path).  Four launches, ROLE:
+// policy of forward_cpu.py has no early stop to speak of and is not a training path).  Three launches, ROLE:
 //   0  items1: DIRECT tiles (== k_draw) and SPEC segments, blended from tau = 1 into their state slot
-//   3  items3, one wave per split tile: the transmittance in FRONT of every SPEC segment, T_0 = 1, T_(s+1) = T_s tau_s
-//      (a chain of loads, requested eight segments ahead)
-//   1  items1 again, SPEC items with s > 0 only: the pixels that FINISH inside this segment (T_s >= tau_stop > T_s tau_s:
+//   1  items1 again, SPEC items with s > 0 only: the wave forms the transmittance in FRONT of its segment, T_s = tau_0
+//      ... tau_(s-1) (dense copies of the taus in st2, s KB per item: a per-tile prefix launch in between cost 19 us
+//      of dependent loads); the pixels that FINISH inside this segment (T_s >= tau_stop > T_s tau_s:
 //      the wave of launch 0 could not know) are blended again from tau = T_s, which stops them exactly where the
 //      unsplit kernel does, and their state is replaced (last contributor stored NEGATIVE: "finished here").  Every
 //      pixel finishes once, and only the 8x8 blocks that hold such a pixel are live: a fraction of one more segment
@@ -1969,7 +1952,7 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
 // The blend loop is k_draw's, unchanged (one stop threshold for the whole wave: a re-walk or a continuation starts
 // from the TRUE transmittance, not from 1).
 template <bool FLOOR, bool CLAMP, int ROLE>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 8 : (ROLE == 2 ? 4 : 5), 8))) void k_draw_seg(
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 8 : (ROLE == 2 ? 2 : 5), 8))) void k_draw_seg(
     DrawParams p, SegArgs sg, int32_t* __restrict__ ranges, const int32_t* __restrict__ gsid,
     const float4* __restrict__ rec, float* __restrict__ image, int32_t* __restrict__ contrib,
     float* __restrict__ final_tau) {
@@ -1980,12 +1963,14 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
     float4* __restrict__ zb = p.zero_buf;
     for (uint32_t i = z0 + lane; i < z1; i += 64) zb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
-  constexpr bool PER_TILE = ROLE == 2 || ROLE == 3;
+  constexpr bool PER_TILE = ROLE == 2;
   if ((int)blockIdx.x >= sg.hdr[PER_TILE ? SH_ITEMS3 : SH_ITEMS1]) return;
   const uint32_t item = (uint32_t)(PER_TILE ? sg.items3 : sg.items1)[blockIdx.x];
   const int tile = (int)(item & SEG_TILE_MASK), iseg = (int)((item >> 19) & SEG_SEG_MASK), kind = (int)(item >> 30);
   if (tile >= p.T) return;
   if (ROLE == 1 && (kind != SEG_SPEC || iseg == 0)) return;   // (segment 0 starts from T = 1: launch 0 was exact)
+  if (ROLE == 0 && sg.rebuild && kind != SEG_SPEC) return;    // (an unsplit tile has no state to rebuild; its item is
+                                                              // the backward launch's)
   if (PER_TILE && kind != SEG_COMPOSE) return;
   const int L = sg.hdr[SH_L];
   const int r0 = ranges[2 * (size_t)tile], r1 = ranges[2 * (size_t)tile + 1];
@@ -2012,31 +1997,6 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
   }
   const int slot0 = sg.seg_base[tile];
   const float stop = p.tau_stop, lthr = p.lskip;
-  if constexpr (ROLE == 3) {   // T_s for the SPEC segments of this tile
-    const int nspec = iseg;
-    float T[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) T[k] = inside_px(k) ? 1.f : -1.f;
-    constexpr int AHEAD = 8;
-    for (int s0 = 0; s0 < nspec; s0 += AHEAD) {
-      float tl[AHEAD][4];
-#pragma unroll
-      for (int u = 0; u < AHEAD; ++u) {
-        const size_t so = ((size_t)(slot0 + min(s0 + u, nspec - 1))) * 256 + lane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tl[u][k] = sg.st4[so + 64 * k].w;
-      }
-#pragma unroll
-      for (int u = 0; u < AHEAD; ++u) {
-        if (s0 + u < nspec) {
-          const size_t so = ((size_t)(slot0 + s0 + u)) * 256 + lane;
-#pragma unroll
-          for (int k = 0; k < 4; ++k) { sg.st2[so + 64 * k] = T[k]; T[k] *= tl[u][k]; }
-        }
-      }
-    }
-    return;
-  }
   const float X[2] = {(float)(lane & 7) - 7.5f, (float)(lane & 7) + 0.5f};
   const float Y[2] = {(float)(lane >> 3) - 7.5f, (float)(lane >> 3) + 0.5f};
   const float XX[2] = {X[0] * X[0], X[1] * X[1]}, YY[2] = {Y[0] * Y[0], Y[1] * Y[1]};
@@ -2050,13 +2010,37 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
   float Tf[4];
   int nseg = 1, nspec = 0, sdone = 0;
   if (ROLE == 1) {
+    // the transmittance in FRONT of this segment, T_s = tau_0 tau_1 ... tau_(s-1) in that order (as COMPOSE forms it),
+    // from the dense copies launch 0 left in st2: s x 1 KB per item, requested eight segments at a time
+    float T[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) T[k] = inside_px(k) ? 1.f : -1.f;
+    constexpr int AHEAD = 8;
+    for (int s0 = 0; s0 < iseg; s0 += AHEAD) {
+      float tl[AHEAD][4];
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u) {
+        const size_t sj = ((size_t)(slot0 + min(s0 + u, iseg - 1))) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) tl[u][k] = sg.st2[sj + 64 * k];
+      }
+      bool alive = false;
+#pragma unroll
+      for (int u = 0; u < AHEAD; ++u)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (s0 + u < iseg) T[k] *= tl[u][k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) alive = alive || (T[k] >= stop);
+      if (!__any(alive)) return;       // every pixel finished in front of this segment
+    }
     const size_t so = ((size_t)(slot0 + iseg)) * 256 + lane;
     bool ev = false;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-      const float T = sg.st2[so + 64 * k], tl = sg.st4[so + 64 * k].w;
-      const bool e = (T >= stop) && (T * tl < stop);
-      Tf[k] = e ? T : -1.f;
+      const float tl = sg.st2[so + 64 * k];
+      const bool e = (T[k] >= stop) && (T[k] * tl < stop);
+      Tf[k] = e ? T[k] : -1.f;
       ev = ev || e;
     }
     if (!__any(ev)) return;
@@ -2068,40 +2052,40 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
     int cc[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) { Tf[k] = inside_px(k) ? 1.f : -1.f; ca[k][0] = 0.f; ca[k][1] = 0.f; ca[k][2] = 0.f; cc[k] = 0; }
-    float4 vn[4];
-    int cn[4];
-    {
-      const size_t so = ((size_t)slot0) * 256 + lane;
+    // (a chain of dependent round trips to the slots: four segments are requested together)
+    constexpr int CA = 4;
+    bool done = false;
+    for (int s0 = 0; s0 < nspec && !done; s0 += CA) {
+      float4 v[CA][4];
+      int c[CA][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[so + 64 * k]; cn[k] = __float_as_int(sg.st1[so + 64 * k]); }
-    }
-    for (int s = 0; s < nspec; ++s) {
-      float4 v[4];
-      int c[4];
+      for (int u = 0; u < CA; ++u) {
+        const size_t so = ((size_t)(slot0 + min(s0 + u, nspec - 1))) * 256 + lane;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { v[k] = vn[k]; c[k] = cn[k]; }
-      {
-        const size_t so = ((size_t)(slot0 + min(s + 1, nspec - 1))) * 256 + lane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[so + 64 * k]; cn[k] = __float_as_int(sg.st1[so + 64 * k]); }
+        for (int k = 0; k < 4; ++k) { v[u][k] = sg.st4[so + 64 * k]; c[u][k] = __float_as_int(sg.st1[so + 64 * k]); }
       }
-      bool alive = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) alive = alive || (Tf[k] >= stop);
-      if (!__any(alive)) break;
-      sdone = s + 1;
-      const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
+      for (int u = 0; u < CA; ++u) {
+        if (done || s0 + u >= nspec) continue;
+        bool alive = false;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        if (!(Tf[k] >= stop)) continue;
-        ca[k][0] = fmaf(Tf[k], v[k].x, ca[k][0]); ca[k][1] = fmaf(Tf[k], v[k].y, ca[k][1]); ca[k][2] = fmaf(Tf[k], v[k].z, ca[k][2]);
-        float tn = Tf[k] * v[k].w;
-        // (a negative contributor: launch 1 blended this pixel to its end inside the segment -- not decided again here
-        // from a product that may round the other way)
-        if (c[k] < 0 || tn < stop) tn = -fmaxf(tn, 1.0e-30f);
-        if (c[k] != 0) cc[k] = abs(c[k]);
-        Tf[k] = tn;
-        sg.st1[so + 64 * k] = fabsf(tn);     // transmittance at the END of segment s
+        for (int k = 0; k < 4; ++k) alive = alive || (Tf[k] >= stop);
+        if (!__any(alive)) { done = true; continue; }
+        sdone = s0 + u + 1;
+        const size_t so = ((size_t)(slot0 + s0 + u)) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          if (!(Tf[k] >= stop)) continue;
+          ca[k][0] = fmaf(Tf[k], v[u][k].x, ca[k][0]); ca[k][1] = fmaf(Tf[k], v[u][k].y, ca[k][1]);
+          ca[k][2] = fmaf(Tf[k], v[u][k].z, ca[k][2]);
+          float tn = Tf[k] * v[u][k].w;
+          // (a negative contributor: launch 1 blended this pixel to its end inside the segment -- not decided again here
+          // from a product that may round the other way)
+          if (c[u][k] < 0 || tn < stop) tn = -fmaxf(tn, 1.0e-30f);
+          if (c[u][k] != 0) cc[k] = abs(c[u][k]);
+          Tf[k] = tn;
+          sg.st1[so + 64 * k] = fabsf(tn);     // transmittance at the END of segment s
+        }
       }
     }
 #pragma unroll
@@ -2207,6 +2191,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
       for (int k = 0; k < 4; ++k) {
         sg.st4[so + 64 * k] = make_float4(cr[k], cg[k], cb[k], tau[k]);
         sg.st1[so + 64 * k] = __int_as_float(cont[k]);
+        // (dense copy: launch 1 multiplies the taus in front of a segment; st2 follows st1)
+        sg.st1[so + 64 * k + (size_t)sg.slot_cap * 256] = tau[k];
       }
       return;
     }
@@ -2223,6 +2209,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
       return;
     }
     if (ROLE == 2) {     // a continuation segment, walked right here from Tf: absolute colour, exact stop
+      if (lane == 0) {   // the backward launch walks it with a wave of its own: one more SPEC item
+        const int at = atomicAdd(&sg.hdr[SH_ITEMS1], 1);
+        if (at < sg.item_cap) sg.items1[at] = (int32_t)((uint32_t)tile | ((uint32_t)s << 19) | ((uint32_t)SEG_SPEC << 30));
+      }
       const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -2263,30 +2253,28 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
       sstar[k] = (Tf[k] < stop) ? (max(cfin[k] - 1, 0) >> (31 - __clz(L))) : sdone - 1;
       G[k][0] = 0.f; G[k][1] = 0.f; G[k][2] = 0.f;
     }
-    float4 vn[4];
-    float tn[4];
-    if (sdone > 0) {
-      const size_t so = ((size_t)(slot0 + sdone - 1)) * 256 + lane;
+    constexpr int GA = 4;       // (again four slots per round trip; a slot is read before this loop overwrites it)
+    for (int s1 = sdone - 1; s1 >= 0; s1 -= GA) {
+      float4 vv[GA][4];
+      float te[GA][4];
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[so + 64 * k]; tn[k] = sg.st1[so + 64 * k]; }
-    }
-    for (int s = sdone - 1; s >= 0; --s) {
-      float4 vv[4];
-      float te[4];
+      for (int u = 0; u < GA; ++u) {
+        const size_t sp = ((size_t)(slot0 + max(s1 - u, 0))) * 256 + lane;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) { vv[k] = vn[k]; te[k] = tn[k]; }
-      {
-        const size_t sp = ((size_t)(slot0 + max(s - 1, 0))) * 256 + lane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) { vn[k] = sg.st4[sp + 64 * k]; tn[k] = sg.st1[sp + 64 * k]; }
+        for (int k = 0; k < 4; ++k) { vv[u][k] = sg.st4[sp + 64 * k]; te[u][k] = sg.st1[sp + 64 * k]; }
       }
-      const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
 #pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        sg.st4[so + 64 * k] = make_float4(G[k][0], G[k][1], G[k][2], te[k]);
-        if (s <= sstar[k]) {
-          G[k][0] = fmaf(vv[k].w, G[k][0], vv[k].x); G[k][1] = fmaf(vv[k].w, G[k][1], vv[k].y);
-          G[k][2] = fmaf(vv[k].w, G[k][2], vv[k].z);
+      for (int u = 0; u < GA; ++u) {
+        const int s = s1 - u;
+        if (s < 0) continue;
+        const size_t so = ((size_t)(slot0 + s)) * 256 + lane;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          sg.st4[so + 64 * k] = make_float4(G[k][0], G[k][1], G[k][2], te[u][k]);
+          if (s <= sstar[k]) {
+            G[k][0] = fmaf(vv[u][k].w, G[k][0], vv[u][k].x); G[k][1] = fmaf(vv[u][k].w, G[k][1], vv[u][k].y);
+            G[k][2] = fmaf(vv[u][k].w, G[k][2], vv[u][k].z);
+          }
         }
       }
     }
@@ -2310,8 +2298,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
   }
 }
 
-// the longest walk of the render that just drew -> the host's hint slot (a forward-only caller has no backward plan to
-// report it; without it a scene of short walks would stay on the segment path for ever)
+// the longest walk of the render that just drew -> the host's hint slot (without it a scene of short walks would stay
+// on the segment path for ever)
 __global__ void k_seg_report(const int32_t* __restrict__ hdr, uint32_t* __restrict__ hint_host) {
   if (threadIdx.x == 0 && hint_host) hint_host[1] = (uint32_t)hdr[SH_MAXWALK];
 }
@@ -2423,7 +2411,7 @@ __device__ __forceinline__ float rows_to_lanes9_bank(const float (&q)[9], int c1
 //   du = -cinv (M1x, M1y), dcinv = -(M2xx/2, M2xy, M2yy/2), applied once per entry)
 // The 9 partials are reduced across the wave 4 entries at a time (transposing reduction below) and nine
 // lanes per entry issue the 9 atomics as one instruction: one atomic set per (tile, Gaussian).
-// SEG: the launch runs over the work items of k_seg_plan (backward == 1) instead of tiles: DIRECT(tile) is the kernel
+// SEG: the launch runs over the forward pass's work items (items1) instead of tiles: DIRECT(tile) is the kernel
 // as it always was; SPEC(tile, s) walks entries [s L, (s + 1) L) of a split tile only, and a pixel whose last
 // contributor lies BEHIND the segment starts from the state the forward pass's COMPOSE item left for the segment's end
 // -- the transmittance there and G, the colour of everything behind it (lq = dL/dgamma . G) -- where the unsplit kernel
@@ -2445,8 +2433,8 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(5, 8))) void
   size_t seg_state = 0;
   bool seg_item = false;
   if constexpr (SEG) {
-    if ((int)blockIdx.x >= sg.hdr[SH_ITEMSB]) return;
-    const uint32_t item = (uint32_t)sg.itemsB[blockIdx.x];
+    if ((int)blockIdx.x >= min(sg.hdr[SH_ITEMS1], sg.item_cap)) return;
+    const uint32_t item = (uint32_t)sg.items1[blockIdx.x];
     tile = (int)(item & SEG_TILE_MASK);
     if (tile >= p.T) return;
     if ((item >> 30) == (uint32_t)SEG_SPEC) {
@@ -3168,7 +3156,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     sga.hist_walk = tile_order ? tile_order + olen + dp.T : nullptr;
     const int speculate = (!hist && (flags & EGS_DRAW_SEG_SPECULATE)) ? 1 : 0;
     EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, hist, g_seg_L, g_seg_min,
-               sga, 0, seg_hint, speculate);
+               sga, seg_hint, speculate);
     if (tile_order) dp.work_out = tile_order + olen;
     // items <= tiles + segments <= T + P / L + P / split_min: the launch covers the bound, surplus workgroups exit
     const int64_t bound = (int64_t)dp.T + patches / g_seg_L + patches / g_seg_min + 2;
@@ -3185,7 +3173,6 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     do {                                                                                                          \
       EGS_DRAWS(FLOOR, CLAMP, 0, "k_draw_seg", grid1);                                                            \
       if (hist || speculate) {   /* (else segment 0 is the only SPEC item of a tile, and it is exact) */            \
-        EGS_DRAWS(FLOOR, CLAMP, 3, "k_draw_seg_prefix", dp.T);                                                    \
         EGS_DRAWS(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid1);                                                      \
       }                                                                                                           \
       EGS_DRAWS(FLOOR, CLAMP, 2, "k_draw_seg_compose", dp.T);                                                     \
@@ -3407,14 +3394,13 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
       int32_t* rg = const_cast<int32_t*>(patch_range_per_tile);   // (only DIRECT items of an empty tile write it: none here)
       EGS_LAUNCH("k_tile_walk", k_tile_walk, dim3(dp.T), dim3(64), s, dp.W, dp.H, dp.gx, contrib, sga.walk);
       EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile,
-                 (const int32_t*)sga.walk, g_seg_L, g_seg_min, sga, 0, seg_hint, 0);
+                 (const int32_t*)sga.walk, g_seg_L, g_seg_min, sga, seg_hint, 0);
 #define EGS_REB(FLOOR, CLAMP, ROLE, NAME, GRID)                                                                  \
       EGS_LAUNCH(NAME, (k_draw_seg<FLOOR, CLAMP, ROLE>), dim3(GRID), dim3(64), s, fp, sga, rg, gsid_per_patch, rec, \
                  simg, scont, stau)
 #define EGS_REB4(FLOOR, CLAMP)                                                                                   \
       do {                                                                                                       \
         EGS_REB(FLOOR, CLAMP, 0, "k_draw_seg", grid);                                                            \
-        EGS_REB(FLOOR, CLAMP, 3, "k_draw_seg_prefix", dp.T);                                                     \
         EGS_REB(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid);                                                        \
         EGS_REB(FLOOR, CLAMP, 2, "k_draw_seg_compose", dp.T);                                                    \
       } while (0)
@@ -3427,8 +3413,6 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
 #undef EGS_REB4
 #undef EGS_REB
     }
-    EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, patch_range_per_tile, (const int32_t*)nullptr, 0,
-               0, sga, 1, (uint32_t*)nullptr, 0);
 #define EGS_DRAWBS(FLOOR, CLAMP)                                                                            \
     EGS_LAUNCH("k_draw_bwd_seg", (k_draw_bwd<false, FLOOR, CLAMP, 7, true>), dim3(grid), dim3(64), s, dp,    \
                patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, dloss_dgammas, gpack, sga)

@@ -190,10 +190,10 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
                "walked_pairs": int(walked.sum().item()), "max_walked": int(walked.max().item()),
                "ms_per_step": round(ms, 4), "Mpix/s": round(W * H / (ms * 1e-3) / 1e6, 2), "kernels_avg_us": kern}
     # the draw stage of either path: the unsplit kernel, or the segment kernels + the planning launch in front of them
-    # (k_seg_plan runs once per pass: its average counts for both)
-    plan = kern.get("k_seg_plan", 0.0)
-    fwd = sum(v for k, v in kern.items() if k.startswith("k_draw") and "bwd" not in k) + plan
-    bwd = sum(v for k, v in kern.items() if k.startswith("k_draw_bwd")) + plan
+    # and the one-word report behind them (the backward launch runs over the forward pass's work items: no plan of its own)
+    fwd = sum(v for k, v in kern.items() if k.startswith("k_draw") and "bwd" not in k) + \
+        kern.get("k_seg_plan", 0.0) + kern.get("k_seg_report", 0.0)
+    bwd = sum(v for k, v in kern.items() if k.startswith("k_draw_bwd"))
     out["draw_fwd_us"], out["draw_bwd_us"] = round(fwd, 1), round(bwd, 1)
     out["segment_path"] = "k_draw_seg" in kern
     # the seven-op drop-in surface on the same scene: with this package's records handle, and the plain public
