@@ -1650,8 +1650,7 @@ constexpr int SEG_SLOT_FLOATS = 256 * 6;
 constexpr uint32_t SEG_TILE_MASK = 0x7FFFFu, SEG_SEG_MASK = 0x7FFu;   // item = tile | seg << 19 | kind << 30
 constexpr int SEG_SPEC = 1, SEG_COMPOSE = 2;   // (0: a DIRECT item, the bare tile index)
 enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_L = 6, SH_MIN = 7,
-       SH_MAXWALK = 8 /* longest walk of THIS render, gathered by the draw items */,
-       SH_HINT = 10 /* two words: the host's hint slot */ };
+       SH_MAXWALK = 8 /* longest walk of THIS render, gathered by the draw items */ };
 struct SegArgs {
   int32_t* hdr;        // SEG_HDR words
   int32_t* seg_base;   // [T] first state slot of a split tile, -1: not split
@@ -1933,7 +1932,6 @@ __global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restr
     // page-locked words the host peeks at before a LATER render: the longest list, and the longest walk of the
     // camera's previous render (k_seg_report overwrites it with this render's)
     if (hint_host) { hint_host[0] = (uint32_t)s_max; if (hist) hint_host[1] = (uint32_t)s_mw; }
-    *reinterpret_cast<uint32_t**>(a.hdr + SH_HINT) = hint_host;
   }
 }
 
@@ -1964,8 +1962,13 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
     for (uint32_t i = z0 + lane; i < z1; i += 64) zb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
   }
   constexpr bool PER_TILE = ROLE == 2;
-  if ((int)blockIdx.x >= sg.hdr[PER_TILE ? SH_ITEMS3 : SH_ITEMS1]) return;
-  const uint32_t item = (uint32_t)(PER_TILE ? sg.items3 : sg.items1)[blockIdx.x];
+  // launch 1 runs FOUR waves per item, one per 8x8 block of the tile: what it costs is the latency of ONE lone wave
+  // walking one segment (it executes 3 % of launch 0's instructions), and a wave that blends one block instead of up
+  // to four walks an entry in a fraction of the time
+  const uint32_t bix = ROLE == 1 ? blockIdx.x >> 2 : blockIdx.x;
+  const int quad = ROLE == 1 ? (int)(blockIdx.x & 3u) : -1;
+  if ((int)bix >= sg.hdr[PER_TILE ? SH_ITEMS3 : SH_ITEMS1]) return;
+  const uint32_t item = (uint32_t)(PER_TILE ? sg.items3 : sg.items1)[bix];
   const int tile = (int)(item & SEG_TILE_MASK), iseg = (int)((item >> 19) & SEG_SEG_MASK), kind = (int)(item >> 30);
   if (tile >= p.T) return;
   if (ROLE == 1 && (kind != SEG_SPEC || iseg == 0)) return;   // (segment 0 starts from T = 1: launch 0 was exact)
@@ -2012,37 +2015,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
   if (ROLE == 1) {
     // the transmittance in FRONT of this segment, T_s = tau_0 tau_1 ... tau_(s-1) in that order (as COMPOSE forms it),
     // from the dense copies launch 0 left in st2: s x 1 KB per item, requested eight segments at a time
-    float T[4];
-#pragma unroll
-    for (int k = 0; k < 4; ++k) T[k] = inside_px(k) ? 1.f : -1.f;
+    const int qo = 64 * quad;            // this wave's block of the tile
+    const bool qin = (pxb[quad & 1] < p.W) && (pyb[quad >> 1] < p.H);
+    float T = qin ? 1.f : -1.f;
     constexpr int AHEAD = 8;
     for (int s0 = 0; s0 < iseg; s0 += AHEAD) {
-      float tl[AHEAD][4];
+      float tl[AHEAD];
 #pragma unroll
-      for (int u = 0; u < AHEAD; ++u) {
-        const size_t sj = ((size_t)(slot0 + min(s0 + u, iseg - 1))) * 256 + lane;
-#pragma unroll
-        for (int k = 0; k < 4; ++k) tl[u][k] = sg.st2[sj + 64 * k];
-      }
-      bool alive = false;
+      for (int u = 0; u < AHEAD; ++u) tl[u] = sg.st2[((size_t)(slot0 + min(s0 + u, iseg - 1))) * 256 + lane + qo];
 #pragma unroll
       for (int u = 0; u < AHEAD; ++u)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          if (s0 + u < iseg) T[k] *= tl[u][k];
-#pragma unroll
-      for (int k = 0; k < 4; ++k) alive = alive || (T[k] >= stop);
-      if (!__any(alive)) return;       // every pixel finished in front of this segment
+        if (s0 + u < iseg) T *= tl[u];
+      if (!__any(T >= stop)) return;       // every pixel of the block finished in front of this segment
     }
-    const size_t so = ((size_t)(slot0 + iseg)) * 256 + lane;
-    bool ev = false;
+    const float tls = sg.st2[((size_t)(slot0 + iseg)) * 256 + lane + qo];
+    const bool ev = (T >= stop) && (T * tls < stop);
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const float tl = sg.st2[so + 64 * k];
-      const bool e = (T[k] >= stop) && (T[k] * tl < stop);
-      Tf[k] = e ? T[k] : -1.f;
-      ev = ev || e;
-    }
+    for (int k = 0; k < 4; ++k) Tf[k] = (k == quad && ev) ? T : -1.f;
     if (!__any(ev)) return;
   }
   if (ROLE == 2) {
@@ -3173,7 +3162,7 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     do {                                                                                                          \
       EGS_DRAWS(FLOOR, CLAMP, 0, "k_draw_seg", grid1);                                                            \
       if (hist || speculate) {   /* (else segment 0 is the only SPEC item of a tile, and it is exact) */            \
-        EGS_DRAWS(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid1);                                                      \
+        EGS_DRAWS(FLOOR, CLAMP, 1, "k_draw_seg_fix", 4 * grid1);                                                  \
       }                                                                                                           \
       EGS_DRAWS(FLOOR, CLAMP, 2, "k_draw_seg_compose", dp.T);                                                     \
     } while (0)
@@ -3401,7 +3390,7 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
 #define EGS_REB4(FLOOR, CLAMP)                                                                                   \
       do {                                                                                                       \
         EGS_REB(FLOOR, CLAMP, 0, "k_draw_seg", grid);                                                            \
-        EGS_REB(FLOOR, CLAMP, 1, "k_draw_seg_fix", grid);                                                        \
+        EGS_REB(FLOOR, CLAMP, 1, "k_draw_seg_fix", 4 * grid);                                                    \
         EGS_REB(FLOOR, CLAMP, 2, "k_draw_seg_compose", dp.T);                                                    \
       } while (0)
       switch ((pol->maha_floor ? 2 : 0) | (pol->alpha_clamp ? 1 : 0)) {

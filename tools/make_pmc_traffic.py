@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """profiles/pmc_traffic.json from tools/pmc_summary.py JSONs:
-   python tools/make_pmc_traffic.py <fetch_write.json> <sq_counters.json or -> <ubench_counters.json or -> <out.json> [<valu_mix.json>]
+   python tools/make_pmc_traffic.py <fetch_write.json> <sq_counters.json or -> <ubench_counters.json or -> <out.json> [<valu_mix.json> [<scene>]]
 
 * HBM bytes per launch from the rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate passes);
 * VALU issue utilisation per kernel from the SQ passes, CALIBRATED on single-instruction kernels
@@ -25,15 +25,29 @@ src, sq, ub, dst = sys.argv[1:5]
 mix = json.load(open(sys.argv[5])) if len(sys.argv) > 5 else {}
 MIX_OF = {"k_draw_bwd": "k_draw_bwdILb0ELb1ELb1ELi7ELb0", "k_draw": "k_drawILb0ELb1ELb1ELb1",
           "k_draw_bwd_seg": "k_draw_bwdILb0ELb1ELb1ELi7ELb1", "k_draw_seg": "k_draw_segILb1ELb1ELi0"}
+
+
+def kname(k):
+    """kernel name of the bench tables: the template instances of the segment path are kernels of their own"""
+    base = k.replace("egs::", "").split("<")[0]
+    args = [x.strip() for x in k[k.find("<") + 1:k.rfind(">")].split(",")] if "<" in k else []
+    if base == "k_draw_seg" and args:
+        return {"0": "k_draw_seg", "1": "k_draw_seg_fix", "2": "k_draw_seg_compose"}.get(args[-1], base)
+    if base == "k_draw_bwd" and len(args) >= 5 and args[4] == "true":
+        return "k_draw_bwd_seg"
+    return base
+
+
 d = json.load(open(src))
-out = {"gaussians": 1000000, "width": 1920, "height": 1080, "source_hash": kernel_source_hash(),
+scene = sys.argv[6] if len(sys.argv) > 6 else "iid"
+out = {"scene": scene, "gaussians": 1000000 if scene == "iid" else 1500000, "width": 1920, "height": 1080, "source_hash": kernel_source_hash(),
        "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) and SQ passes, "
                  "tools/profile_step.py, MI355X; tools/collect_profiles.sh",
        "correction": "FETCH_SIZE x2 (gfx950 tallies 128-B requests at 64 B for 16 B/lane loads, MI355X_MICROARCH.md "
                      "section HBM; calibrated on k_preprocess_fwd), WRITE_SIZE x1; counters are in KB",
        "kernels": {}}
 for k, v in d.items():
-    name = k.replace("egs::", "").split("<")[0]
+    name = kname(k)
     if "FETCH_SIZE" not in v or "WRITE_SIZE" not in v:
         continue
     e = out["kernels"].setdefault(name, {"FETCH_SIZE_KB": 0.0, "WRITE_SIZE_KB": 0.0, "variants": 0})
@@ -48,7 +62,7 @@ for name, e in out["kernels"].items():
     e["hbm_bytes_per_launch"] = int((2 * e["FETCH_SIZE_KB"] + e["WRITE_SIZE_KB"]) * 1024)
 if sq != "-":
     for k, c in json.load(open(sq)).items():
-        name = k.replace("egs::", "").split("<")[0]
+        name = kname(k)
         if name not in out["kernels"] or "SQ_ACTIVE_INST_VALU" not in c or "GRBM_GUI_ACTIVE" not in c:
             continue
         insts, active = c["SQ_INSTS_VALU"], c["SQ_ACTIVE_INST_VALU"]

@@ -16,6 +16,8 @@ ap.add_argument("--gaussians", type=int, default=1_000_000)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
 ap.add_argument("--fwd-only", action="store_true")
+ap.add_argument("--scene", default="iid", choices=["iid", "skewed", "skewed_reset"],
+                help="iid = the bench scene; skewed / skewed_reset = scene.skewed_scene (1.5 M, heavy-tailed; after reset_alpha)")
 ap.add_argument("--mode", default="fused", choices=["fused", "ops"], help="GSFunction evaluation (ops = the seven-op surface)")
 ap.add_argument("--train", action="store_true", help="whole optimizer step: GSRawFunction + HIP loss + FusedAdam")
 ap.add_argument("--factored", action="store_true", help="--train: SH gradient factored, consumed by FusedAdam")
@@ -29,7 +31,8 @@ from easygaussiansplatting_amd.function import Camera, GSFunction, RenderOptions
 
 dev = torch.device("cuda", 0)
 opts = RenderOptions(mode=a.mode, ops_use_records=not a.public_pair)       # per call, not a process-wide switch
-sc = S.big_scene(a.gaussians, a.width, a.height, 48)
+sc = S.big_scene(a.gaussians, a.width, a.height, 48) if a.scene == "iid" else \
+    S.skewed_scene(width=a.width, height=a.height, sh_dim=48, reset_alpha=(a.scene == "skewed_reset"))
 cam = Camera.from_scene(sc.cam, dev)
 t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
 P = dict(pws=t(sc.pws), shs=t(sc.shs), alphas=t(sc.alphas).reshape(-1, 1).clone(), scales=t(sc.scales), rots=t(sc.rots))
