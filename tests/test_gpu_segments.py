@@ -249,3 +249,94 @@ def test_trainer_on_the_segment_path_follows_the_unsplit_trainer(fx):
         # Adam normalises every gradient to ~lr: a gradient that is rounding-level noise around zero may step the other
         # way, so single entries differ by a few lr; the bulk does not
         assert np.median(d) <= 1e-6 + 1e-5 * np.abs(p0[k]).max() and (d > 5e-3 * max(1.0, np.abs(p0[k]).max())).mean() < 1e-3, k
+
+
+def _segment_states(seg_bytes, T):
+    """what k_seg_plan / k_draw_seg left in a segment workspace (mirrors seg_carve, csrc/egs_raster.hip: header,
+    seg_base[T], walk[T], items3, two scratch arrays, items1, then per slot [256] x (float4, float, float)) ->
+    hdr, seg_base, st4[slot, 256, 4]; a slot's 256 entries are (lane + 64 k): pixel (8 (k & 1) + (lane & 7),
+    8 (k >> 1) + (lane >> 3)) of the tile"""
+    w = seg_bytes.view(np.int32)
+    nbytes = seg_bytes.size
+    Tp = (T + 63) // 64 * 64
+    fixed = 16 + 48 + 5 * Tp
+    slots = (nbytes - (4 * (fixed + T + 64) + 1024)) // (256 * 6 * 4 + 4)
+    item_cap = min(T + slots, 1 << 20)
+    slot_cap = min(slots, item_cap - T)
+    hdr = w[:16]
+    seg_base = w[64:64 + T]
+    off = 4 * (fixed + T + slots + 64)
+    off = (off + 255) // 256 * 256
+    st4 = seg_bytes[off:off + slot_cap * 256 * 16].view(np.float32).reshape(slot_cap, 256, 4)
+    return hdr, seg_base, st4
+
+
+def _slot_to_tile(a):
+    """[256, ...] in slot order -> [16, 16, ...] (y, x) of the tile"""
+    out = np.zeros((16, 16) + a.shape[1:], a.dtype)
+    for k in range(4):
+        blk = a[64 * k:64 * k + 64].reshape((8, 8) + a.shape[1:])          # [lane >> 3, lane & 7]
+        out[8 * (k >> 1):8 * (k >> 1) + 8, 8 * (k & 1):8 * (k & 1) + 8] = blk
+    return out
+
+
+@pytest.mark.parametrize("reset,spec", [(False, "1"), (True, "1"), (True, "0")])
+def test_segment_end_states_equal_the_oracles(fx, reset, spec):
+    """The states the forward launches leave for the backward pass -- per segment and pixel the transmittance at the
+    segment's end and G, the colour of everything behind it -- against oracle/segment_oracle.py (float64, the stages
+    evaluated in the device's float32; tests/test_segment_oracle.py shows that decomposition to be the reference's
+    loop).  ``spec`` "1": every segment speculated, then fixed and composed; "0": first sight, the composing wave walks
+    everything behind segment 0 itself."""
+    fused, lib = fx
+    from easygaussiansplatting_amd import _lib
+    from easygaussiansplatting_amd.function import Camera
+    from oracle import segment_oracle as SO
+    from tests.test_gpu_parity import _oracle_2d
+    W, H, L = 160, 128, 64
+    sc = S.small_scene(16_000, W, H, 12, seed=9)
+    sc.scales[:] = sc.scales * 2.2
+    if reset:
+        sc.alphas[:] = np.minimum(sc.alphas, 0.01)
+    fused.SEGMENTS = "1"
+    _lib.check(lib.egs_seg_config(L, L, None))
+    keep = fused.SEG_SPECULATE
+    fused.SEG_SPECULATE = spec
+    try:
+        with torch.no_grad():
+            _, _, st = fused.forward(dev(sc.pws), dev(sc.shs), dev(sc.alphas).reshape(-1, 1), dev(sc.scales),
+                                     dev(sc.rots), Camera.from_scene(sc.cam), need_grad=True)
+            torch.cuda.synchronize()
+    finally:
+        fused.SEG_SPECULATE = keep
+    assert st.seg is not None
+    T = ((W + 15) // 16) * ((H + 15) // 16)
+    hdr, seg_base, st4 = _segment_states(host(st.seg), T)
+    ranges, ids = host(st.ranges), host(st.gaussian_ids())
+    lens = ranges[:, 1] - ranges[:, 0]
+    split = np.nonzero(seg_base >= 0)[0]
+    assert len(split) > 10 and np.array_equal(np.sort(split), np.nonzero(lens > L)[0]) and hdr[6] == L
+    tiles = [int(np.argmax(lens))] + [int(t) for t in split[:: max(1, len(split) // 5)][:5]]
+    o_us, o_ci, o_col, _, _ = _oracle_2d(sc, sc.cam, dtype=np.float32)
+    _, cont, _, states = SO.draw_segments(W, H, ranges, ids, o_us, o_ci, sc.alphas.astype(np.float64), o_col, L,
+                                          tiles=tiles)
+    assert np.array_equal(cont[cont > 0] > 0, np.ones((cont > 0).sum(), bool))
+    n_cmp, n_bad = 0, 0
+    worst = 0.0
+    for t in tiles:
+        G, T_end = states[t]
+        y0, x0 = (t // ((W + 15) // 16)) * 16, (t % ((W + 15) // 16)) * 16
+        hh, ww = min(16, H - y0), min(16, W - x0)
+        for s in range(G.shape[0]):
+            alive = T_end[s] > 0                      # the pixel was alive in segment s: the device wrote both states
+            if not alive.any():
+                break
+            d = _slot_to_tile(st4[seg_base[t] + s])[:hh, :ww]
+            e_t = np.abs(d[..., 3] - T_end[s])[alive]
+            e_g = np.abs(d[..., :3] - np.moveaxis(G[s], 0, -1))[alive]
+            n_cmp += e_t.size + e_g.size
+            n_bad += int((e_t > 2e-5).sum() + (e_g > 1e-4).sum())
+            worst = max(worst, float(e_t.max()), float(e_g.max()))
+    assert n_cmp > 20_000
+    # (a pixel whose alpha' sits at the skip threshold, or whose tau crosses the stop one entry apart, differs in a
+    # whole state: counted, as everywhere in the suite)
+    assert n_bad <= 2e-3 * n_cmp, (n_bad, n_cmp, worst)
