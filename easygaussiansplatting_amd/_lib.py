@@ -75,7 +75,6 @@ SIGNATURES = {
     "egs_pair_stamp_words": (_sz, [_i]),
     "egs_pack_records_validate": (_i, [_i, _i, _i, _P, _P, _P, _P, _PP, _P, _P, _P, _i64, _P, _P, _P]),
     "egs_strip_list_masks": (_i, [_i64, _P, _P, _P, _P]),
-    "egs_probe_set_hit_bits": (_i, [_P]),
     "egs_sort_pairs_ws_bytes": (_sz, [_i64]),
     "egs_sort_pairs": (_i, [_i64, _P, _P, _P, _P, _i, _i, _P, _sz, C.POINTER(C.c_int), _P]),
     "egs_scan_ws_bytes": (_sz, [_i64]),

@@ -82,7 +82,7 @@ struct Carver {
   bool ok() const { return off <= cap; }
 };
 
-// ---- binning pieces shared by egs_raster.hip (egs_splat_bin) and egs_preprocess.hip (the fused forward
+// ---- binning pieces shared by egs_bin.hip (egs_splat_bin) and egs_preprocess.hip (the fused forward
 // kernel does getRects + the depth key itself) ---------------------------------------------------------
 struct BinParams {
   int W, H, gx, gy;
@@ -141,7 +141,7 @@ bool bin_count_outputs(void* ws_bin, size_t ws_bin_bytes, int n, BinCountOut* ou
 int splat_bin_after_count(int n, int key_bits_hint, void* ws_bin, size_t ws_bin_bytes, uint32_t* total_patches,
                           void* stream, uint32_t* host_totals);
 
-// splatB's draw pass into the packed [N][12] gradient records (egs_raster.hip); *gpack
+// splatB's draw pass into the packed [N][12] gradient records (egs_splat.hip); *gpack
 // points into `ws`.  Shared by egs_splat_bwd (+unpack) and egs_fused_backward.
 int splat_bwd_packed(int n, int64_t patches, int width, int height, const float* us, const float* cinv2ds,
                      const float* alphas, const float* colors, const int32_t* areas, const EgsPolicy* pol,

@@ -431,7 +431,7 @@ __device__ __forceinline__ void load_sh_row(const float* __restrict__ row, float
   }
 }
 
-// ---- packed 2D record of the draw kernels (layout: see egs_raster.hip k_pack_records) ----
+// ---- packed 2D record of the draw kernels (layout: see egs_bin.hip k_pack_records) ----
 #define EGS_NHL2E (-0.72134752044f)  // -0.5 * log2(e)
 // saturating float -> int (v_cvt_i32_f32 semantics; NaN -> 0)
 __device__ __forceinline__ int f2i(float v) { return (int)v; }

@@ -70,7 +70,8 @@ class GSFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pws, shs, alphas, scales, rots, us, cam, opts=None):
         ctx.opts = opts            # None: the process-wide defaults, looked up where they are needed
-        ctx.n_inputs = 7 if opts is None else 8
+        # always the maximal tuple (autograd drops surplus trailing Nones): apply(..., cam, None) passes `opts` explicitly
+        ctx.n_inputs = 8
         ctx.mode = GSFunction.mode if opts is None else opts.mode
         use_records = GSFunction.ops_use_records if opts is None else opts.ops_use_records
         # the mask output never carries a gradient: do not let autograd zero-fill one per step
@@ -151,7 +152,7 @@ class GSRawFunction(torch.autograd.Function):
     @staticmethod
     def forward(ctx, pws, low_shs, high_shs, alphas_raw, scales_raw, rots_raw, us, cam, opts=None):
         ctx.opts = opts            # (``mode`` does not apply: this node IS the fused path)
-        ctx.n_inputs = 8 if opts is None else 9
+        ctx.n_inputs = 9     # (as GSFunction: the maximal tuple)
         ctx.set_materialize_grads(False)
         image, mask, state = _fused.forward(pws, low_shs, alphas_raw, scales_raw, rots_raw, cam, high_shs=high_shs,
                                             need_grad=True)

@@ -250,8 +250,11 @@ def _seg_decision(ctx, lib, key, pol_):
     cfg = (C.c_int * 2)()
     _lib.check(lib.egs_seg_config(0, 0, cfg))
     longest, walk = int(out[0]), int(out[1])
-    use = SEGMENTS == "1" or walk == 0xFFFFFFFF or walk > cfg[1]
     known = walk != 0xFFFFFFFF and longest != 0xFFFFFFFF
+    # no walk on record yet: the longest LIST bounds it (a scene whose lists all stay below the split threshold never
+    # pays for the segment workspace, ~6 KB per 256 entries of a split tile); nothing known at all: the segment path
+    unknown = walk == 0xFFFFFFFF and (longest == 0xFFFFFFFF or longest > cfg[1])
+    use = SEGMENTS == "1" or unknown or (walk != 0xFFFFFFFF and walk > cfg[1])
     _tls.seg_speculate = SEG_SPECULATE == "1" or (SEG_SPECULATE == "auto" and known and 2 * walk >= longest)
     return use, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot))
 

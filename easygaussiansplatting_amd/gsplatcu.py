@@ -26,6 +26,7 @@ supersets:
 from __future__ import annotations
 
 import ctypes as C
+import threading
 
 import torch
 
@@ -293,9 +294,21 @@ def _alphas(alphas, n):
 #     ``SplatRecords`` and ``splatB(..., records=handle)`` takes it back -- this package's GSFunction (mode "ops") does
 #     that with its own intermediates (us / cinv2ds / colors never leave the autograd node) and skips both the re-pack
 #     and the validation (21 + 10 us); the handle is checked by (data_ptr, _version, shape), policy, size and stream.
+#   * round 6, long lists only: when the public ``splat`` split its long tile lists over waves it keeps that
+#     draw's SEGMENT-END STATES (G_s, T_end per segment and pixel: ~6 KB per 256 entries of a split tile) with strong
+#     references to the four tensors it RETURNED -- contrib, final_tau, patch_range_per_tile, gsid_per_patch -- one entry
+#     per (device, stream), replaced by the next ``splat`` there.  A ``splatB`` that is handed exactly those four tensors
+#     (same memory -- they cannot have been freed --, same in-place version) and the same inputs (data_ptr, version)
+#     walks its segments from the kept states; anything else rebuilds them from ``contrib`` first (a forward draw's
+#     worth of work: 2.7 instead of 2.2 ms per step on scene.skewed_scene(reset_alpha=True)).  ``set_pair_states(False)``
+#     keeps nothing.  Scenes whose walks stay below the split threshold never create an entry.
 _memo_enabled = False
 _splat_memo = {}        # (device, stream) -> SplatRecords, in order of last use
 MEMO_MAX = 8
+_pair_states_enabled = True
+_pair_states = {}       # (device, stream) -> dict(outs, sig, in_sig, seg, lists, width, height, policy)
+_last_splatB = {"segments": False, "rebuilt": False, "kept_states": False}
+_pair_tls = threading.local()   # hands the segment workspace of a _splat call to the public splat() around it
 MASKED_LISTS = True     # A/B knob: exact block masks in the seven-op surface's list values (egs_splat_bin_pack)
 
 
@@ -320,10 +333,28 @@ def set_memo(on: bool) -> None:
         _splat_memo.clear()
 
 
+def set_pair_states(on: bool) -> bool:
+    """Keep the segment-end states of a public ``splat`` for the ``splatB`` of the tensors it returned (default: on; only
+    scenes with long tile lists ever hold any).  -> the previous setting."""
+    global _pair_states_enabled
+    prev, _pair_states_enabled = _pair_states_enabled, bool(on)
+    if not on:
+        _pair_states.clear()
+    return prev
+
+
+def last_splatB_info() -> dict:
+    """What the last ``splatB`` of this process did: ``segments`` (long lists walked by one wave per segment), ``rebuilt``
+    (the segment states were rebuilt from ``contrib``), ``kept_states`` (the forward's states were found).  For tests
+    and bench lines."""
+    return dict(_last_splatB)
+
+
 def clear_memo() -> None:
     """Drop what ``splat`` keeps for the next ``splatB`` (per device and stream: the list with masks, the dispatch-order
     buffer, the cleared gradient records and the content stamps -- ~80 MB at 1 M Gaussians until the next ``splat``)."""
     _splat_memo.clear()
+    _pair_states.clear()
 
 
 def _memo_sig(tensors):
@@ -382,6 +413,18 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
     ``depths`` and ``areas`` are updated IN PLACE for Gaussians whose tile rect is
     empty (kernel.cu:114-119).  Reference: ext.cpp:10-18, gausplat.cu:24-112."""
     out, h = _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep="public" if _memo_enabled else False)
+    if _pair_states_enabled:
+        key = (us.device.index, int(_stream().value or 0))
+        _pair_states.pop(key, None)
+        kept = getattr(_pair_tls, "seg_of_last_call", None)
+        _pair_tls.seg_of_last_call = None
+        if kept is not None:
+            sig, in_sig = _memo_sig(out[1:5]), _memo_sig((us, cinv2ds, alphas, colors))
+            if sig is not None and in_sig is not None:
+                _pair_states[key] = dict(outs=tuple(out[1:5]), sig=sig, in_sig=in_sig, seg=kept[0], lists=kept[1],
+                                         width=int(width), height=int(height), policy=_policy_name)
+                while len(_pair_states) > MEMO_MAX:
+                    _pair_states.pop(next(iter(_pair_states)))
     if _memo_enabled:
         key = (us.device.index, int(_stream().value or 0))
         _splat_memo.pop(key, None)          # (an older entry must not outlive its splat; re-inserted = most recent)
@@ -453,6 +496,8 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
     visible = torch.empty(n, dtype=torch.bool, device=dev) if (masks and keep == "handle") else None
 
     def records(gsid):    # only once the draw stage is enqueued: the order buffer is written, the gradient records cleared
+        # (the public splat may keep this draw's segment states for the splatB of the tensors it returns: see above)
+        _pair_tls.seg_of_last_call = (seg_ws[0], lists[0]) if (seg_ws[0] is not None and keep != "handle") else None
         if keep == "handle":
             h = _make_records(dev, st, (us, cinv2ds, alphas, colors), width, height, rec, order, gpack,
                               lists[0], (gsid, ranges) if lists[0] is not None else None)
@@ -622,7 +667,18 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
                                                          _ptr(stamp_b), npatch, _ptr(h.lists), _ptr(gsid), st))
                 walked, order = h.lists, h.order
                 gpack, h.gpack = h.gpack, None
+    kept_states = False
     if n > 0 and pol.footprint != 1:
+        if seg is None and records is None and _pair_states_enabled and gsid.shape[0] > 0:
+            # the public pair: the states the splat of exactly these tensors left (same four outputs by memory and
+            # version -- held alive by the entry --, same inputs by memory and version, same policy and size)
+            e = _pair_states.get((dev.index, int(st.value or 0)))
+            if (e is not None and e["width"] == width and e["height"] == height and e["policy"] == _policy_name
+                    and _memo_sig((contrib, final_tau, ranges, gsid)) == e["sig"] and _memo_sig(e["outs"]) == e["sig"]
+                    and _memo_sig((us, cinv2ds, alphas, colors)) == e["in_sig"]):
+                seg, kept_states = e["seg"], True
+                if walked is None and e["lists"] is not None and e["lists"].shape[0] >= gsid.shape[0]:
+                    walked = e["lists"]          # the same entries with their exact block masks
         # one entry point for every combination of what this call was handed (records / order / cleared gradient
         # records or nothing; the forward's segment states, or none: with long walks on record they are REBUILT from
         # contrib -- a forward-draw's worth of work that removes the serial tail of one wave per tile)
@@ -635,6 +691,7 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
                                          ws_bytes, _ptr(order), _ptr(gpack), _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha),
                                          _ptr(d_color), 0 if walked is None else 2, _ptr(seg),
                                          seg.numel() if seg is not None else 0, rebuild, seg_hint, st))
+        _last_splatB.update(segments=seg is not None, rebuilt=bool(rebuild), kept_states=kept_states)
     elif rec is not None:   # (unreachable: records are only taken under the tile-footprint policies)
         raise AssertionError
     else:

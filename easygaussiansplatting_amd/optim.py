@@ -78,7 +78,9 @@ class FusedAdam:
                 if len(lrs) != 1:
                     raise ValueError("FusedAdam.step(factored_sh=...): an SH tensor that is not in exactly one group")
                 sh.append((t, lrs[0]))
-        # 2. state and step counters, rolled back if a launch is refused after all (the C side checks alignment / counts)
+        # 2. state and step counters; a launch that is refused after all (the C side checks alignment / counts) rolls back
+        # the counters of ITS groups and of those not launched yet -- tensors an earlier launch already updated keep
+        # their new step (a retry must not apply the same step to them twice)
         bumped = []
 
         def state_of(t):
@@ -106,11 +108,15 @@ class FusedAdam:
                 _lib.check(lib.egs_adam_sh_factored(
                     n, K, rows.shape[0], pws.data_ptr(), rows.data_ptr(), rows.shape[1], float(scale), groups[0],
                     groups[1] if len(groups) > 1 else None, self.betas[0], self.betas[1], self.eps, stream))
+                del bumped[len(plain):]          # enqueued: the SH tensors' counters stand
             for i in range(0, len(recs), 8):
                 chunk = recs[i:i + 8]
                 arr = (_lib.EgsAdamGroup * len(chunk))(*chunk)
                 _lib.check(lib.egs_adam_step(len(chunk), arr, self.betas[0], self.betas[1], self.eps, stream))
+                for j in range(i, i + len(chunk)):
+                    bumped[j] = None             # enqueued
         except BaseException:
             for st in bumped:
-                st["step"] -= 1
+                if st is not None:
+                    st["step"] -= 1
             raise

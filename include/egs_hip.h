@@ -381,13 +381,6 @@ int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void* stream);
  * device memory; once the stream has run it, MHz = (out[1] - out[0]) / (out[3] - out[2]) * 100.  What a VALU-bound
  * kernel's roofline is priced against: 1024 SIMDs x this clock. */
 int egs_clock_probe(void* out8, int iters, void* stream);
-/* Measurement helper (tools/bwd_hit_stats.py): one bit per list entry of the NEXT backward draws of this process
- * (bit i = entry i of gsid_per_patch blended into some pixel of its tile; NULL switches the probe off).  Entries with
- * a 0 bit are dropped by k_draw_bwd before staging.  Prices a "the forward draw leaves a hit bit per entry" design
- * from the backward side alone; never set by the product path.  Returns 1 (and does nothing) unless the library was
- * built with -DEGS_PROBE_HIT_BITS=1: the test inside k_draw_bwd, wave-uniform as it is, cost the production kernel two
- * spilled registers. */
-int egs_probe_set_hit_bits(const void* bits);
 /* Mailbox for that read-back: `slots` page-locked landing zones, each with a HIP event.  egs_mailbox_post
  * enqueues the asynchronous 8-byte copy of total_patches[0..1] into a slot on `stream` and records the
  * slot's event behind it; egs_mailbox_fetch returns 1 and the two words once the copy has landed, 0 when it

@@ -219,3 +219,20 @@ def test_render_options_validate_and_default():
         RenderOptions(mode="cuda")
     with pytest.raises(ValueError):
         RenderOptions(sh_sink=object(), exchange=object())
+
+
+def test_variant_patches_apply():
+    """the measurement probes are patches under tools/lab/variants, not #ifdefs in the product sources:
+    they must keep applying to the current csrc/, and the sources must hold no probe knob"""
+    import glob
+    import subprocess
+    patches = sorted(glob.glob(os.path.join(REPO, "tools", "lab", "variants", "*.patch")))
+    assert len(patches) >= 3
+    for p in patches:
+        r = subprocess.run(["git", "apply", "--check", p], cwd=REPO, capture_output=True, text=True)
+        assert r.returncode == 0, "%s no longer applies:\n%s" % (os.path.basename(p), r.stderr)
+    for f in glob.glob(os.path.join(REPO, "easygaussiansplatting_amd", "csrc", "*.h*")):
+        src = open(f).read()
+        for knob in ("EGS_DRAW_PROBE_NOK", "EGS_PROBE_REDUCE", "EGS_DRAW_DUMMY_", "EGS_PLAN_STAMPS", "EGS_PROBE_HIT_BITS",
+                     "WRONG"):
+            assert knob not in src, "%s still holds %s" % (os.path.basename(f), knob)

@@ -1,4 +1,4 @@
-"""CPU check of the arithmetic k_draw uses for the exponent of alpha' (csrc/egs_raster.hip): the quadratic
+"""CPU check of the arithmetic k_draw uses for the exponent of alpha' (csrc/egs_draw.hip): the quadratic
 form evaluated as a polynomial about the TILE CENTRE with per-lane constant monomials,
     e = c0 + c1 X + c2 Y + qxx XX + qxy XY + qyy YY,   c0 = log2(alpha) + E(D), (c1, c2) = grad E(D),
 against the direct form E(u - pixel) (what the reference computes, common.cuh:85-88) -- both emulated in fp32

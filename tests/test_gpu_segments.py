@@ -252,7 +252,7 @@ def test_trainer_on_the_segment_path_follows_the_unsplit_trainer(fx):
 
 
 def _segment_states(seg_bytes, T):
-    """what k_seg_plan / k_draw_seg left in a segment workspace (mirrors seg_carve, csrc/egs_raster.hip: header,
+    """what k_seg_plan / k_draw_seg left in a segment workspace (mirrors seg_carve, csrc/egs_segments.hip: header,
     seg_base[T], walk[T], items3, two scratch arrays, items1, then per slot [256] x (float4, float, float)) ->
     hdr, seg_base, st4[slot, 256, 4]; a slot's 256 entries are (lane + 64 k): pixel (8 (k & 1) + (lane & 7),
     8 (k >> 1) + (lane >> 3)) of the tile"""

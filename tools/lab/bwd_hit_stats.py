@@ -84,8 +84,13 @@ if "--time" in sys.argv:
     us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
     dl = t(S.normal(1, 77, (3, H, W))) / (3 * H * W)
 
+    # the probe is not in the product sources: git apply tools/lab/variants/draw_bwd_probes.patch, then
+    # make FLAGS+=-DEGS_PROBE_HIT_BITS=1 (tools/lab/lab_r4d.sh); the symbol is bound here, not in _lib.SIGNATURES
+    if not hasattr(lib, "egs_probe_set_hit_bits"):
+        sys.exit("this libegs_hip.so was built without tools/lab/variants/draw_bwd_probes.patch")
+    lib.egs_probe_set_hit_bits.restype = C.c_int; lib.egs_probe_set_hit_bits.argtypes = [C.c_void_p]
     if lib.egs_probe_set_hit_bits(None) != 0:
-        sys.exit("this libegs_hip.so was built without the probe: make FLAGS+=-DEGS_PROBE_HIT_BITS=1 (tools/lab/lab_r4d.sh)")
+        sys.exit("this libegs_hip.so was built without -DEGS_PROBE_HIT_BITS=1 (tools/lab/lab_r4d.sh)")
 
     def run(probe, reps=40):
         lib.egs_probe_set_hit_bits(C.c_void_p(bits.data_ptr()) if probe else None)

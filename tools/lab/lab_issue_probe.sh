@@ -2,7 +2,7 @@
 # Which issue port limits k_draw?  Library variants with N dummy scalar / vector instructions per (tile, entry)
 # (-DEGS_DRAW_DUMMY_SALU=N / -DEGS_DRAW_DUMMY_VALU=N) or with two LDS broadcast reads per entry instead of three
 # (-DEGS_DRAW_PROBE_NOK: wrong colours, timing only), built into tools/variants/libegs_<name>.so, are swapped in
-# on the box:   hipcc <Makefile FLAGS> -D... -c csrc/egs_raster.hip -o /tmp/r.o; hipcc -shared -o tools/variants/libegs_X.so /tmp/r.o <other .o>
+# on the box:   hipcc <Makefile FLAGS> -D... -c csrc/egs_draw.hip (after git apply tools/lab/variants/draw_issue_probes.patch) -o /tmp/r.o; hipcc -shared -o tools/variants/libegs_X.so /tmp/r.o <other .o>
 # Measured (1 M / 1080p, k_draw 171 us): +4 SALU 178, +8 SALU 193; +4 VALU 173, +8 VALU 185; one LDS read less 162.
 cd $GRAFT_REPO_ROOT; O=gpurun_out/probe; mkdir -p $O; export PYTHONDONTWRITEBYTECODE=1
 cp easygaussiansplatting_amd/libegs_hip.so /tmp/libegs_base.so
