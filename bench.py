@@ -26,6 +26,8 @@ Rank 0 prints ONE JSON line carrying, besides the contract fields,
   gpu_busy_ms_per_step -- sum of the HIP-event durations of all kernels of a step (untimed pre-pass), next to
                   the wall-clock ms_per_step: a ratio above 1.03 means the host, not the GPU, set the pace
                   (a warning goes to stderr);
+  fwd_loss_bwd, train_step, epoch_pattern, uhd_3840x2160 -- the training step (loss, Adam), train.py's access pattern
+                  (shuffled cameras, densify, reset_alpha) and one 4K render: extra legs outside the timed region;
   roofline     -- the dominant kernel of the timed region (by HIP-event time, measured on the stream it is
                   launched on), algorithmic bytes per launch / average launch duration vs the 8 TB/s HBM peak
                   and vs a device-to-device copy timed on this box (peak_measured);
@@ -45,7 +47,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 from tools.benchlib import (HBM_PEAK_GBS, VALU_BOUND, XGMI_LINK_GBS, algorithmic_bytes, cpu_baseline,  # noqa: E402,F401
-                            kernel_source_hash, parse_report, relaunch_command, scene_leg)
+                            epoch_pattern_leg, kernel_source_hash, parse_report, relaunch_command, scene_leg,
+                            train_legs, uhd_leg)
 
 
 def main():
@@ -88,6 +91,9 @@ def main():
                          "scene.skewed_scene (1.5 M heavy-tailed Gaussians, lists up to ~24 k); skewed_reset = the same "
                          "right after reset_alpha (every opacity <= 0.01: nothing saturates)")
     ap.add_argument("--no-skewed", action="store_true", help="skip the extra legs on the two skewed scenes")
+    ap.add_argument("--no-train", action="store_true",
+                    help="skip the training-step legs (fwd_loss_bwd, train_step, epoch_pattern) of the default run")
+    ap.add_argument("--no-uhd", action="store_true", help="skip the extra 3840x2160 leg")
     ap.add_argument("--extras", action="store_true",
                     help="also time render+loss+backward and the whole optimizer step (other dL/dimage, so their "
                          "kernel launches would blur a rocprofv3 summary of the headline step)")
@@ -521,7 +527,8 @@ def main():
             p.grad = None
         torch.cuda.empty_cache()
         skewed = [scene_leg(nm, S.skewed_scene(width=a.width, height=a.height, sh_dim=a.sh_dim, reset_alpha=rs), dev, lib,
-                            12, ref) for nm, rs in (("skewed", False), ("skewed_reset", True))]
+                            12, ref, train=(rs and not a.no_train))
+                  for nm, rs in (("skewed", False), ("skewed_reset", True))]
 
     # achievable HBM bandwidth on THIS box: a device-to-device float4 copy ("confirm on the box
     # with a device-to-device copy kernel and report both")
@@ -555,90 +562,20 @@ def main():
         cbh = cb.cpu().numpy()
         clock_mhz = round(float(cbh[1] - cbh[0]) / max(1.0, float(cbh[3] - cbh[2])) * 100.0, 1)
 
-    # informative extra (outside the timed region): render + fused L1/SSIM loss + backward, i.e. a
-    # training step without the optimizer (the torch loss of the reference costs 10.9 ms at 1080p)
-    from easygaussiansplatting_amd.loss import gau_loss
-    loss_step_ms = None
-    train_extra = None
-    if a.extras:
-        gt = torch.rand((3, a.height, a.width), device=dev)
-
-        def step_with_loss():
-            for p in params.values():
-                p.grad = None
-            us0.grad = None
-            img, _ = GSFunction.apply(params["pws"], params["shs"], params["alphas"], params["scales"],
-                                      params["rots"], us0, cam)
-            gau_loss(img, gt).backward()
-        for _ in range(2):
-            step_with_loss()
-        torch.cuda.synchronize()
-        tl0 = time.perf_counter()
-        for _ in range(nf):
-            step_with_loss()
-        torch.cuda.synchronize()
-        loss_step_ms = (time.perf_counter() - tl0) / nf * 1e3
-
-        # the whole optimizer step of the train.py counterpart (raw parameters -> activations -> render ->
-        # loss -> backward -> Adam) and the two Adam implementations alone
-        if rank == 0 and world == 1:
-            from easygaussiansplatting_amd.optim import FusedAdam, adam_groups
-            from easygaussiansplatting_amd.trainer import activate, raw_params_from_scene
-
-            def timed(fn, n):
-                for _ in range(2):
-                    fn()
-                torch.cuda.synchronize()
-                t0_ = time.perf_counter()
-                for _ in range(n):
-                    fn()
-                torch.cuda.synchronize()
-                return (time.perf_counter() - t0_) / n * 1e3
-            raw = raw_params_from_scene(sc, dev)
-            opts = {"fused": FusedAdam(adam_groups(raw), eps=1e-15),
-                    "torch": torch.optim.Adam(adam_groups(raw), lr=0.0, eps=1e-15)}
-
-            from easygaussiansplatting_amd.function import GSRawFunction
-
-            def train_step(opt, fused_act=False):
-                opt.zero_grad(set_to_none=True)
-                us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-                if fused_act:   # activations inside the HIP kernels
-                    img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
-                                                 raw["scales_raw"], raw["rots_raw"], us, cam)
-                else:           # the reference's structure: torch activations around GSFunction
-                    img, _ = GSFunction.apply(*activate(raw), us, cam)
-                gau_loss(img, gt).backward()
-                opt.step()
-            fxt = DV.FactoredShGrad(1)
-
-            from easygaussiansplatting_amd.loss import gau_loss_with_grad
-            us_keep = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
-
-            def train_step_factored(opt):
-                """What Trainer.step does for one view: the render validated at commit() (no host wait inside the
-                step), the loss kernels hand dL/dimage straight to backward, a persistent `us` leaf, and the SH
-                gradient never leaves its factored form -- the chain-rule kernel writes dL/dcolour [N,3], the
-                optimizer forms every Gaussian's row in LDS (egs_adam_sh_factored)"""
-                opt.zero_grad(set_to_none=True)
-                us_keep.grad = None
-                with fused_path.deferred() as d, fxt.attach():
-                    img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
-                                                 raw["scales_raw"], raw["rots_raw"], us_keep, cam)
-                    _stats, dimg = gau_loss_with_grad(img.detach(), gt)
-                    img.backward(dimg)
-                    d.commit()
-                rows, _w = fxt.take()
-                opt.step(factored_sh=(rows, 1.0, raw["pws"], raw["low_shs"], raw["high_shs"]))
-            train_extra = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
-            train_extra["train_step_ms_fused_activations_fused_adam"] = round(
-                timed(lambda: train_step(opts["fused"], True), nf), 4)
-            train_extra["train_step_ms_as_trainer_factored_sh"] = round(
-                timed(lambda: train_step_factored(opts["fused"]), nf), 4)
-            for name, opt in opts.items():
-                train_extra["train_step_ms_torch_activations_%s_adam" % name] = round(
-                    timed(lambda: train_step(opt), nf), 4)
-                train_extra["adam_only_ms_%s" % name] = round(timed(opt.step, nf), 4)
+    # the whole training step (outside the timed region; VERDICT r5 #3: in the DEFAULT line): render + fused HIP L1 / SSIM
+    # loss + backward, and raw parameters -> activations -> render -> loss -> backward -> Adam; --extras adds the
+    # reference's structure (torch activations, torch.optim.Adam).  Then the access pattern of train.py's loop
+    # (epoch_pattern) and one 4K render.
+    loss_leg, train_extra, epoch_pat, uhd = None, None, None, None
+    solo = a.mode == "fused" and a.scene == "iid" and rank == 0 and world == 1 and V == 1 and not a.immediate
+    if solo and (a.extras or not a.no_train):
+        for p in params.values():
+            p.grad = None
+        torch.cuda.empty_cache()
+        loss_leg, train_extra = train_legs(sc, cam, dev, nf, full=a.extras)
+        epoch_pat = epoch_pattern_leg(dev)
+    if solo and not a.no_uhd and a.width == 1920:
+        uhd = uhd_leg(dev, lib)
 
     roofline = None
     src_hash = kernel_source_hash()
@@ -658,6 +595,37 @@ def main():
                         "frac_of_measured": None if not peak_measured else round(ach / peak_measured, 4),
                         "algorithmic_bytes_per_launch": ab, "avg_launch_us": round(avg_s * 1e6, 1),
                         "launches": cnt, "share_of_step": round(tot / a.steps / ms, 3)}
+            # `achieved` / `frac` above count SURVEY 8(d)'s bytes on the REFERENCE's lists (`patches`: what the seven-op
+            # surface walks); the fused path walks footprint-culled lists (`patches_drawn`): the same figure on those
+            abd = algorithmic_bytes(dom, sc.n, P_drawn, T, HW, a.sh_dim)
+            if abd is not None:
+                roofline["on_lists_drawn"] = {"algorithmic_bytes_per_launch": abd,
+                                              "achieved": round(abd / avg_s / 1e9, 1),
+                                              "frac": round(abd / avg_s / 1e9 / HBM_PEAK_GBS, 4)}
+            # the whole step against the HBM peak, two byte counts: SURVEY 8(d)'s formula for the seven-op surface
+            # (1656 N + 316 P + 24 T + 40 HW at K = 48: Jacobians written and re-read, the reference's lists) and the
+            # bytes the FUSED path's own kernels move algorithmically (no Jacobians, culled lists, sorts as 12 B per item
+            # and pass)
+            if a.mode == "fused" and kernels:
+                K_ = a.sh_dim
+                # N-terms: stages 204 + 4K, Jacobians 372 + 4K/3, splat 72, splatB 36, chain rule 460 + 4K + 4K/3 (= 1656 at K = 48)
+                survey = (1144 + 8 * K_ + 8 * K_ // 3) * sc.n + 316 * P + 24 * T + 40 * HW
+                own = 0
+                for k_, row_ in kernels.items():
+                    ab_ = algorithmic_bytes(k_, sc.n, P_drawn, T, HW, a.sh_dim, (world * V) if fx is not None else 0)
+                    if ab_ is None and k_ in ("k_radix_hist", "k_radix_scatter"):
+                        # per step: 2 depth passes over N items + 2 tile passes over P_drawn items; hist reads 4 B,
+                        # scatter moves 16 B per item (the depth sort's last pass also gathers 16 + 4 B)
+                        per = (4 if k_ == "k_radix_hist" else 16)
+                        ab_ = (2 * sc.n + 2 * P_drawn) * per / max(1, row_["launches_per_step"]) + \
+                            (20 * sc.n / max(1, row_["launches_per_step"]) if k_ == "k_radix_scatter" else 0)
+                    if ab_:
+                        own += ab_ * row_["launches_per_step"]
+                roofline["step"] = {
+                    "survey_8d_bytes": int(survey), "survey_8d_frac": round(survey / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "fused_own_bytes": int(own), "fused_own_frac": round(own / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                    "note": "survey_8d = the seven-op surface's algorithmic bytes (SURVEY 8d) over THIS step's time; "
+                            "fused_own = what the fused path's kernels move algorithmically (no Jacobians, culled lists)"}
             # HBM bytes per launch and the calibrated VALU-issue utilisation come from rocprofv3 --pmc passes stored
             # under profiles/ -- quoted only when those passes ran on exactly these kernel sources
             tpath = os.path.join(REPO, "profiles", "pmc_traffic.json")
@@ -734,9 +702,8 @@ def main():
             "ops_public_pair_ms_per_step": None if ops_public_ms is None else round(ops_public_ms, 4),
             "ops_kernels": ops_kernels,
             "ring_views_8": ring8, "skewed_scenes": skewed,
-            "fwd_loss_bwd": None if loss_step_ms is None else {
-                "ms": round(loss_step_ms, 4), "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"},
-            "train_step": train_extra, "exchange": exch,
+            "fwd_loss_bwd": loss_leg, "train_step": train_extra, "epoch_pattern": epoch_pat, "uhd_3840x2160": uhd,
+            "exchange": exch,
             "roofline": roofline, "cpu_baseline": cpu, "kernels": kernels, "kernel_source_hash": src_hash,
         }
         if cpu:

@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegs_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 
 class EgsPolicy(C.Structure):
@@ -88,7 +88,7 @@ SIGNATURES = {
     "egs_seg_ws_bytes": (_sz, [_i64, _i, _i]),
     "egs_seg_config": (_i, [_i, _i, C.POINTER(C.c_int)]),
     "egs_splat_draw_rec_seg": (_i, [_i, _i64, _P, _i, _i, _P, _PP, _P, _P, _sz, _P, _P, _P, _P, _P, _P, _P, _P,
-                                    _i, _i, _P, _sz, _P, _P, _P]),
+                                    _i, _i, _P, _sz, _P, _P, _P, _P]),
     "egs_seg_rebuild_ws_bytes": (_sz, [_i64, _i, _i]),
     "egs_splat_bwd_seg": (_i, [_i, _i64, _i, _i, _P, _P, _P, _P, _P, _PP, _P, _P, _P, _P, _P, _P, _sz, _P, _P,
                                _P, _P, _P, _P, _i, _P, _sz, _i, _P, _P]),

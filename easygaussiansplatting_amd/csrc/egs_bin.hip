@@ -426,7 +426,19 @@ __global__ __launch_bounds__(256) void k_bin_emit(int n, int gx, const uint32_t*
 __global__ __launch_bounds__(256) void k_tile_ranges(int64_t P, const uint32_t* __restrict__ tkeys,
                                                      int32_t* __restrict__ ranges,
                                                      const uint32_t* __restrict__ n_dev,
-                                                     const uint32_t* __restrict__ masked, int32_t* __restrict__ plain) {
+                                                     const uint32_t* __restrict__ masked, int32_t* __restrict__ plain,
+                                                     int32_t* __restrict__ zero, int zero_words,
+                                                     int32_t* __restrict__ walk_word, uint32_t* __restrict__ walk_host) {
+  // zero (nullable): words cleared on the side -- the bins and counters of the segment plan that may follow
+  for (int z = blockIdx.x * 256 + threadIdx.x; z < zero_words; z += gridDim.x * 256) zero[z] = 0;
+  // walk_word (nullable): the longest walk the previous render on this stream gathered (complete: stream order) goes to
+  // the host's hint word; -1 = nothing gathered since the last publication
+  // ([0] the longest walk, [1] the longest list: a PAIR from one render -- the host compares them)
+  if (walk_word && blockIdx.x == 0 && threadIdx.x == 0) {
+    const int w = walk_word[0], l = walk_word[1];
+    if (w >= 0 && l >= 0 && walk_host) { walk_host[0] = (uint32_t)l; walk_host[1] = (uint32_t)w; }
+    walk_word[0] = -1; walk_word[1] = -1;
+  }
   // masked / plain (nullable pair, seven-op surface): gsid_per_patch as the reference returns it -- the sorted list
   // values without their block masks -- written on the way (this kernel is a chain of latencies: the 8 bytes per
   // patch ride along; as a launch of its own, k_strip_masks, they cost 6-8 us)
@@ -601,8 +613,9 @@ int bin_emit(int n, int gx, const BinLayout& B, uint32_t* tkeys, uint32_t* gsid,
 }
 
 int tile_ranges(int64_t P, const uint32_t* tkeys, int32_t* ranges, const uint32_t* n_dev, const uint32_t* masked,
-                int32_t* plain, hipStream_t s) {
-  EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(P, 1024)), dim3(256), s, P, tkeys, ranges, n_dev, masked, plain);
+                int32_t* plain, hipStream_t s, int32_t* zero, int zero_words, int32_t* walk_word, uint32_t* walk_host) {
+  EGS_LAUNCH("k_tile_ranges", k_tile_ranges, dim3(div_up(P, 1024)), dim3(256), s, P, tkeys, ranges, n_dev, masked, plain,
+             zero, zero_words, walk_word, walk_host);
   EGS_LAUNCH_OK();
   return 0;
 }

@@ -286,7 +286,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
   const int pyb[2] = {ty0 + (lane >> 3), ty0 + (lane >> 3) + 8};
   if (n <= 0) {  // empty tile: image = 0, contrib = 0 and final_tau = 0 (NOT 1), exactly what the
                  // reference's early return leaves in its zero-filled outputs (kernel.cu:182)
-    if (p.work_out && lane == 0) { p.work_out[tile] = 0; if (p.walk_out) p.walk_out[tile] = 0; }
+    if (p.work_out && lane == 0) { p.work_out[tile] = 0; if (p.walk_out) p.walk_out[tile] = 0; walk_raise(p.walk_max, 0); }
     // a tile without patches still holds the (INT_MAX, 0) the binning initialised it with: (0, 0), as the reference
     if (lane == 0 && (r0 != 0 || r1 != 0)) { ranges[2 * (size_t)tile] = 0; ranges[2 * (size_t)tile + 1] = 0; }
     const size_t HW0 = (size_t)p.W * p.H;
@@ -443,7 +443,12 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu((!BOX && SKI
       w += mx;
       wmax = max(wmax, mx);
     }
-    if (lane == 0) { p.work_out[tile] = w + 2 * wmax; if (p.walk_out) p.walk_out[tile] = wmax; }
+    if (lane == 0) {
+      p.work_out[tile] = w + 2 * wmax;
+      if (p.walk_out) p.walk_out[tile] = wmax;
+      walk_raise(p.walk_max, wmax);
+      if (p.walk_max) walk_raise(p.walk_max + 1, n);      // ... and the longest list of the same render
+    }
   }
   const size_t HW = (size_t)p.W * p.H;
 #pragma unroll
@@ -884,6 +889,7 @@ DrawParams make_draw_params(int W, int H, const EgsPolicy* pol, bool backward) {
   p.zero_per = 0;
   p.work_out = nullptr;
   p.walk_out = nullptr;
+  p.walk_max = nullptr;
   p.masked = 0;
   p.alpha_skip = pol->alpha_skip; p.tau_stop = pol->tau_stop;
   p.lskip = pol->alpha_skip > 0.f ? log2f(pol->alpha_skip) : -INFINITY;

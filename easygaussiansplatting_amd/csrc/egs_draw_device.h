@@ -44,6 +44,22 @@ __device__ __forceinline__ bool nan_entry_fix(float4& A, float4& B) {
   return false;
 }
 
+// The longest walk of a render -> the host's hint word, without a launch of its own.  The host reads that word WITHOUT
+// waiting, while the GPU may be in the middle of a render, so it must only ever hold the maximum of a COMPLETED render.
+// Two things were tried first in round 6 and measured: a running maximum mirrored into the host word by whichever wave
+// raises it (the host saw 300 of an 8 000-entry walk, took the unsplit kernels, and the path flip-flopped), and tickets
+// -- every wave counts its arrival, the last one publishes (k_draw 152 -> 452 us: 8 160 returning device-scope atomics
+// on one cache line serialise at ~40 ns each, sharded or not).  What is left costs nothing: the waves gather the
+// maximum in a PERSISTENT device word the host keeps per (problem size, stream) -- the conditional load keeps all but a
+// few dozen waves off the atomic -- and the range kernel of the NEXT render on that stream publishes it (stream order:
+// the render it belongs to is complete) and resets it to -1 = "nothing gathered yet".
+// (Round 5: a k_seg_report launch behind the compose launch, 6 us; nothing on the unsplit path, where the word was
+// refreshed every 4th render of a camera by k_tile_order -- after reset_alpha a trainer kept walking 8 000-entry lists
+// with one wave per tile for an epoch.)
+__device__ __forceinline__ void walk_raise(int32_t* __restrict__ word, int wmax) {
+  if (word && wmax > *word) atomicMax(word, wmax);
+}
+
 // min(x, hi) as ONE v_med3_f32 (fminf() costs a canonicalising v_max + v_min in IEEE mode; the
 // low bound is finite so the compiler cannot fold the median back into a min)
 __device__ __forceinline__ float min_hi(float x, float hi) {

@@ -58,8 +58,12 @@ bool bin_carve(void* ws, size_t bytes, int n, BinLayout* L);
 int bin_emit(int n, int gx, const BinLayout& B, uint32_t* tkeys, uint32_t* gsid, uint32_t cap, int32_t* ranges,
              int n_ranges, int with_masks, uint32_t* sort_sup, uint32_t sort_sup_words, hipStream_t s);
 // getRanges over the sorted tile keys; masked / plain (nullable pair): the list without its block masks on the way
+// zero / zero_words (nullable): words the kernel clears on the side (the segment plan's bins and counters)
+// walk_word / walk_host (nullable pair): the longest walk the PREVIOUS render on this stream gathered in the caller's
+// persistent device word is published into walk_host[1] (page-locked) and the word reset to -1 (walk_raise)
 int tile_ranges(int64_t P, const uint32_t* tkeys, int32_t* ranges, const uint32_t* n_dev, const uint32_t* masked,
-                int32_t* plain, hipStream_t s);
+                int32_t* plain, hipStream_t s, int32_t* zero = nullptr, int zero_words = 0, int32_t* walk_word = nullptr,
+                uint32_t* walk_host = nullptr);
 // the packed 48-B records of the draw kernels from the four tensors of the op surface (+ content stamps, nullable)
 int pack_records(int n, int width, int height, int footprint, float alpha_skip, const float* us, const float* cinv2ds,
                  const float* alphas, const float* colors, const int32_t* areas, float4* rec, uint32_t* stamp,
@@ -84,6 +88,9 @@ struct DrawParams {
   // actually walked its list (early termination makes that 0.6 .. 1.0 of the list length, tile by tile)
   int32_t* work_out;
   int32_t* walk_out;   // nullable, next to work_out: the largest contributor index of the tile (how far it was walked)
+  // k_draw only (nullable, with work_out): the caller's persistent device word in which the waves gather the longest walk
+  // of the render; the range kernel of the NEXT render on the stream publishes it (walk_raise, egs_draw_device.h)
+  int32_t* walk_max;
   // the list values carry the tile's 4-bit block mask in their high bits (culled lists of the fused path, k_bin_emit):
   // the kernels take it from there instead of testing the record's certain-miss box per entry
   int masked;
@@ -107,7 +114,12 @@ constexpr int SEG_SLOT_FLOATS = 256 * 6;
 constexpr uint32_t SEG_TILE_MASK = 0x7FFFFu, SEG_SEG_MASK = 0x7FFu;   // item = tile | seg << 19 | kind << 30
 constexpr int SEG_SPEC = 1, SEG_COMPOSE = 2;   // (0: a DIRECT item, the bare tile index)
 enum { SH_ITEMS1 = 0, SH_ITEMS3 = 1, SH_SLOTS = 2, SH_MAXLEN = 3, SH_SPLIT = 4, SH_L = 6, SH_MIN = 7,
-       SH_MAXWALK = 8 /* longest walk of THIS render, gathered by the draw items */ };
+       SH_MAXWALK = 8 /* longest walk of THIS render, gathered by the draw items */,
+       // the plan's global counters (k_seg_plan_count; zeroed with the bins in front of it) and the compose launch's ticket
+       SH_P_SLOTS = 10, SH_P_N3 = 11 /* one 8-byte aligned pair: a single 64-bit atomic hands out both */,
+       SH_P_MAXLEN = 12, SH_P_MAXWALK = 13 };
+constexpr int SEG_PLAN_BINS = 4096;  // global bins of the plan's counting sort, behind the header and its 48 spare words
+constexpr int SEG_PLAN_WORDS = SEG_HDR + 48 + SEG_PLAN_BINS;   // what must be ZERO when k_seg_plan_count starts
 struct SegArgs {
   int32_t* hdr;        // SEG_HDR words
   int32_t* seg_base;   // [T] first state slot of a split tile, -1: not split
@@ -124,6 +136,7 @@ struct SegArgs {
   int32_t* hist_walk;  // nullable: the camera's own walk array (the NEXT render's prediction)
   int rebuild;         // splatB without the forward pass's states (egs_splat_bwd_seg): `walk` is given (from `contrib`), a
                        // tile's list ENDS there, the forward launches only rebuild the segment-end states
+  int32_t* walk_max;   // nullable: the caller's persistent word the draw items gather the render's longest walk in
 };
 struct SegConfig { int L, split_min; };   // segment length (a power of two >= 64), shortest list that is split
 SegConfig seg_config();                   // the process-wide default (egs_seg_config / EGS_SEG_L / EGS_SEG_MIN)
@@ -132,8 +145,11 @@ bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a);
 // upper bound of the work items of a render: tiles + segments
 int64_t seg_item_bound(int T, int64_t patches, const SegConfig& c);
 // plan + the three forward launches (+ the report to the host's hint words) over a carved workspace
+// plan_zeroed: the SEG_PLAN_WORDS words at sga.hdr are already zero (tile_ranges cleared them on the side)
+// walk_word (nullable): the caller's persistent word for the render's longest walk (see tile_ranges)
 int draw_segments_forward(DrawParams& dp, const EgsPolicy* pol, SegArgs& sga, const SegConfig& cfg, int64_t patches,
-                          const int32_t* hist, int speculate, bool fix_pass, bool report, uint32_t* seg_hint,
+                          const int32_t* hist, int speculate, bool fix_pass, int32_t* walk_word, uint32_t* seg_hint,
+                          bool plan_zeroed,
                           int32_t* ranges, const int32_t* gsid, const float4* rec, float* image, int32_t* contrib,
                           float* final_tau, hipStream_t s);
 int launch_draw_bwd(const DrawParams& dp, const EgsPolicy* pol, const int32_t* ranges, const int32_t* gsid,

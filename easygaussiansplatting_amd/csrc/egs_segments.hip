@@ -70,7 +70,7 @@ SegConfig seg_config() {
 int64_t seg_item_bound(int T, int64_t patches, const SegConfig& c) {
   return (int64_t)T + patches / c.L + patches / c.split_min + 2;
 }
-static size_t seg_fixed_words(int T) { return (size_t)SEG_HDR + 48 + 5 * (size_t)align_up((size_t)T, 64); }
+static size_t seg_fixed_words(int T) { return (size_t)SEG_HDR + 48 + SEG_PLAN_BINS + 5 * (size_t)align_up((size_t)T, 64); }
 size_t seg_ws_bytes_for(int64_t slots, int T) {
   return 4 * (seg_fixed_words(T) + ((size_t)T + (size_t)slots + 64)) + (size_t)slots * SEG_SLOT_FLOATS * 4 + 1024;
 }
@@ -81,7 +81,7 @@ bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
   if (slots < 16) return false;
   const size_t Tp = align_up((size_t)T, 64);
   int32_t* w = (int32_t*)ws;
-  a->hdr = w; w += SEG_HDR + 48;
+  a->hdr = w; w += SEG_HDR + 48 + SEG_PLAN_BINS;   // header, spare words, the plan's global bins
   a->seg_base = w; w += Tp;
   a->walk = w; w += Tp;
   a->items3 = w; w += Tp;
@@ -95,222 +95,144 @@ bool seg_carve(void* ws, size_t bytes, int T, SegArgs* a) {
   a->st2 = a->st1 + (size_t)a->slot_cap * 256;
   a->hist_walk = nullptr;
   a->rebuild = 0;
+  a->walk_max = nullptr;
   return (char*)(a->st2 + (size_t)a->slot_cap * 256) <= (char*)ws + bytes;
 }
 
-// One workgroup plans a render: which tiles are split (state slots are handed out here), the work items, longest first
-// (counting sort on the estimated walk, as k_tile_order), and the list statistics the host steers by:
+// Planning a render: which tiles are split (state slots are handed out here), the work items, longest first (counting
+// sort on the estimated walk, as k_tile_order), and the list statistics the host steers by:
 //   ranges (+ hist: the walks this camera's previous render measured) -> seg_base, items1, items3, hdr
-// The BACKWARD launch runs over the same items1 (a second plan from this render's walks cost 31 us on its one CU for
-// a marginally better order): a segment the pixels never reached returns after its first loads.
+// Round 5 did this in ONE workgroup: 3 900 instructions per thread on one CU, 27-32 us whatever was tried inside it
+// (LAB r5 note 4).  Round 6: two launches of T / 256 workgroups around GLOBAL bins -- k_seg_plan_count hands out the
+// state slots and the compose positions (one returning atomic per wave: any disjoint ranges will do, the order is
+// irrelevant) and ranks every tile's items inside its bin (one returning atomic per tile); k_seg_plan_place scans the
+// 4096 bins in every workgroup (16 KB out of L2) and writes each tile's run of items itself.  The bins and counters
+// (SEG_PLAN_WORDS words behind the header) are zeroed on the side by the kernel in front (k_tile_ranges).
+// The BACKWARD launch runs over the same items1 (a second plan from this render's walks cost 31 us for a marginally
+// better order): a segment the pixels never reached returns after its first loads.
 // Segment 0 of a split tile is ALWAYS a SPEC item: it starts from tau = 1 like the unsplit walk, so it is exact and
 // never wasted; further SPEC items follow the prediction (walk + a quarter), the COMPOSE item walks on where they end.
-constexpr int SP_REGS = 8;     // tiles per thread and round whose inputs are requested together (the kernel is a chain
-                               // of latencies: 8160 tiles are ONE round of 1024 x 8)
-// (L is a power of two: a segment index is a shift -- an integer division is ~40 instructions on this part, and the plan
-// kernel's first version spent 26 of its 37 us dividing)
+// (L is a power of two: a segment index is a shift -- an integer division is ~40 instructions on this part)
 __device__ __forceinline__ int seg_nspec(const int32_t* __restrict__ hist, int h, int n, int nseg, int L, int Ls,
                                          int speculate) {
   // no walk on record for this camera: segment 0 only -- or, when the host knows the scene's tiles to be walked to
   // (nearly) their ends (EGS_DRAW_SEG_SPECULATE: nothing saturates, e.g. right after reset_alpha), the whole list
   if (!hist) return speculate ? nseg : 1;
   const int w = min(max(h, 0), n);
+  // a walk on record that is far shorter than the list while the scene's recent renders walk most of theirs (`speculate`:
+  // the host's hint words): a STALE record -- the render right after reset_alpha (gsmodel.py:320-324) meets the walks of
+  // the opaque scene -- and the whole list is speculated, as at first sight
+  if (speculate && 4 * w < n) return nseg;
   return max(1, min(nseg, (w + (w >> 2) + L) >> Ls));
 }
-__global__ __launch_bounds__(1024) void k_seg_plan(int T, const int32_t* __restrict__ ranges,
-                                                   const int32_t* __restrict__ hist, int L, int split_min, SegArgs a,
-                                                   uint32_t* __restrict__ hint_host, int speculate) {
-  constexpr int NB = 4096;
-  __shared__ uint32_t bins[NB];
-  __shared__ uint32_t wsum[16];
-  __shared__ int s_slots, s_n3, s_max, s_mw;
-  const int tid = threadIdx.x, lane = tid & 63;
-  int mw = 0;     // longest walk of the camera's previous render seen by this thread
-  for (int i = tid; i < NB; i += 1024) bins[i] = 0u;
-  if (tid == 0) { s_slots = 0; s_n3 = 0; s_max = 0; s_mw = 0; }
+// longest first: one bin per entry up to 3072, one per 32 beyond (to ~36 k).  (One bin per 8 entries put the 7 000 DIRECT
+// tiles of a 1080p render on ~130 addresses: several hundred same-address atomics each, 12 ns apiece.)
+__device__ __forceinline__ int seg_plan_bin(int est) {
+  const int e = max(est, 0);
+  return SEG_PLAN_BINS - 1 - (e < 3072 ? e : 3072 + min((e - 3072) >> 5, SEG_PLAN_BINS - 3073));
+}
+// the SPEC items of all split tiles are equal work: spread them over a few bins (they would all meet in one)
+__device__ __forceinline__ int seg_plan_jitter(int t) { return (int)(((uint32_t)t * 2654435761u) >> 25) - 64; }
+
+__global__ __launch_bounds__(256) void k_seg_plan_count(int T, const int32_t* __restrict__ ranges,
+                                                        const int32_t* __restrict__ hist, int L, int split_min,
+                                                        SegArgs a, int speculate) {
+  const int t = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  const bool valid = t < T;
+  const int tc = min(t, T - 1);
+  int2 rr = reinterpret_cast<const int2*>(ranges)[tc];
+  const int hh = hist ? hist[tc] : 0;
+  if (a.rebuild) rr.y = rr.x + min(max(rr.y - rr.x, 0), max(hh, 0));   // a tile's list ends at its (given) walk
   const int Ls = 31 - __clz(L);
-  __syncthreads();
-  auto bin_of = [&](int est) { return NB - 1 - min(max(est, 0) >> 3, NB - 1); };
-  // the SPEC items of all split tiles are equal work: spread them over a few bins (they would all meet in one)
-  auto jitter = [&](int t) { return (int)(((uint32_t)t * 2654435761u) >> 25) - 64; };
-  // pass 1: per tile its item count and estimated walk -> (bin, rank inside the bin) parked in tmp[]
-  // (what every tile adds to ONE counter -- slots, compose items, the maxima -- is combined inside the wave first: 8160
-  // same-address LDS atomics are 8160 serial steps, 50 us of this kernel's first version)
-  for (int t0 = 0; t0 < T; t0 += 1024 * SP_REGS) {
-    int2 rr[SP_REGS];
-    int hh[SP_REGS], bb[SP_REGS];
+  const int n = valid ? max(rr.y - rr.x, 0) : 0, nseg = (n + L - 1) >> Ls;
+  const bool split = valid && n > split_min && nseg <= (int)SEG_SEG_MASK;
+  // state slots and compose positions of the wave's split tiles: ONE wave scan over (slots << 10 | tiles), one returning
+  // atomic per wave on each of the two global counters
+  const uint32_t both = split ? (((uint32_t)nseg << 10) | 1u) : 0u;
+  const uint32_t inc = wave_inclusive_scan(both);
+  int32_t* plan = a.hdr + SEG_HDR + 48;        // [SEG_PLAN_BINS] bins
+  uint32_t wb = 0u, w3 = 0u;
+  if (lane == 63 && inc) {      // (both counters in ONE 64-bit atomic: SH_P_SLOTS is 8-byte aligned, SH_P_N3 follows it)
+    const unsigned long long old = atomicAdd(reinterpret_cast<unsigned long long*>(&a.hdr[SH_P_SLOTS]),
+                                             ((unsigned long long)(inc & 1023u) << 32) | (unsigned long long)(inc >> 10));
+    wb = (uint32_t)old; w3 = (uint32_t)(old >> 32);
+  }
+  wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
+  w3 = (uint32_t)__builtin_amdgcn_readlane((int)w3, 63);
+  const uint32_t sb = wb + ((inc - both) >> 10), s3 = w3 + ((inc - both) & 1023u);
+  int mx = n, mw = (hist && valid) ? hh : 0;
 #pragma unroll
-    for (int q = 0; q < SP_REGS; ++q) {
-      const int t = min(t0 + q * 1024 + tid, T - 1);
-      rr[q] = reinterpret_cast<const int2*>(ranges)[t];
-      hh[q] = hist ? hist[t] : 0;
-      bb[q] = -1;
-    }
-    if (a.rebuild) {   // a tile's list ends at its (given) walk; every tile is planned from that length
-#pragma unroll
-      for (int q = 0; q < SP_REGS; ++q) { rr[q].y = rr[q].x + min(max(rr[q].y - rr[q].x, 0), max(hh[q], 0)); }
-    }
-    {
-      // state slots and compose-item positions of the round's split tiles: ONE wave scan each over the threads' totals
-      // (cross-lane operations go through the LDS crossbar on this part: a scan per tile was 20 us of the kernel)
-      uint32_t want = 0u, nsp = 0u;
-      int mx = 0;
-#pragma unroll
-      for (int q = 0; q < SP_REGS; ++q) {
-        const int t = t0 + q * 1024 + tid, n = max(rr[q].y - rr[q].x, 0), nseg = (n + L - 1) >> Ls;
-        const bool split = t < T && n > split_min && nseg <= (int)SEG_SEG_MASK;
-        if (split) { want += (uint32_t)nseg; nsp += 1u; }
-        if (t < T) mx = max(mx, n);
-      }
-      if (hist) {
-#pragma unroll
-        for (int q = 0; q < SP_REGS; ++q)
-          if (t0 + q * 1024 + tid < T) mw = max(mw, hh[q]);
-      }
-      const uint32_t both = (want << 10) | nsp;                // (at most 512 split tiles per wave and round; < 2^22 slots)
-      const uint32_t inc = wave_inclusive_scan(both);
-      uint32_t wb = 0u, w3 = 0u;
-      if (lane == 63 && inc) { wb = (uint32_t)atomicAdd(&s_slots, (int)(inc >> 10)); w3 = (uint32_t)atomicAdd(&s_n3, (int)(inc & 1023u)); }
-      wb = (uint32_t)__builtin_amdgcn_readlane((int)wb, 63);
-      w3 = (uint32_t)__builtin_amdgcn_readlane((int)w3, 63);
-      uint32_t sb = wb + ((inc - both) >> 10), s3 = w3 + ((inc - both) & 1023u);
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d, 64));
-      if (lane == 0) atomicMax(&s_max, mx);
-#pragma unroll
-      for (int q = 0; q < SP_REGS; ++q) {
-        const int t = t0 + q * 1024 + tid, n = max(rr[q].y - rr[q].x, 0), nseg = (n + L - 1) >> Ls;
-        const bool split = t < T && n > split_min && nseg <= (int)SEG_SEG_MASK;
-        bb[q] = -1;
-        if (split) {
-          // (a workspace of egs_seg_ws_bytes cannot run out of slots; if a caller's does, the tile stays unsplit)
-          if ((int)sb + nseg <= a.slot_cap) {
-            bb[q] = (int)sb;
-            a.items3[s3] = (int32_t)((uint32_t)t | ((uint32_t)seg_nspec(hist, hh[q], n, nseg, L, Ls, speculate) << 19) |
-                                     ((uint32_t)SEG_COMPOSE << 30));
-          } else {
-            a.items3[s3] = t;      // (no COMPOSE kind: the per-tile launches skip it)
-          }
-          s3 += 1u;
-          sb += (uint32_t)nseg;
-        }
-        if (t < T) a.seg_base[t] = bb[q];
-      }
-    }
-#pragma unroll
-    for (int q = 0; q < SP_REGS; ++q) {
-      const int t = t0 + q * 1024 + tid;
-      const bool valid = t < T;
-      const int n = max(rr[q].y - rr[q].x, 0);
-      int cnt = valid ? 1 : 0, est = n;
-      if (bb[q] >= 0) { cnt = seg_nspec(hist, hh[q], n, (n + L - 1) >> Ls, L, Ls, speculate); est = L + jitter(t); }
-      else if (hist) est = min(max(hh[q], 0), n);
-      uint32_t packed = 0xFFFFFFFFu;
-      if (cnt > 0) {
-        const int b = bin_of(est);
-        packed = ((uint32_t)b << 20) | atomicAdd(&bins[b], (uint32_t)cnt);
-      }
-      if (valid) { a.tmp[t] = (int32_t)packed; a.tmp2[t] = bb[q] >= 0 ? cnt : -1; }
+  for (int d = 32; d >= 1; d >>= 1) { mx = max(mx, __shfl_xor(mx, d, 64)); mw = max(mw, __shfl_xor(mw, d, 64)); }
+  if (lane == 0) { if (mx > 0) atomicMax(&a.hdr[SH_P_MAXLEN], mx); if (mw > 0) atomicMax(&a.hdr[SH_P_MAXWALK], mw); }
+  int base = -1;
+  if (split) {
+    // (a workspace of egs_seg_ws_bytes cannot run out of slots; if a caller's does, the tile stays unsplit)
+    if ((int)sb + nseg <= a.slot_cap) {
+      base = (int)sb;
+      a.items3[s3] = (int32_t)((uint32_t)t | ((uint32_t)seg_nspec(hist, hh, n, nseg, L, Ls, speculate) << 19) |
+                               ((uint32_t)SEG_COMPOSE << 30));
+    } else {
+      a.items3[s3] = t;      // (no COMPOSE kind: the per-tile launches skip it)
     }
   }
+  if (valid) {
+    a.seg_base[t] = base;
+    int cnt = 1, est = n;
+    if (base >= 0) { cnt = seg_nspec(hist, hh, n, nseg, L, Ls, speculate); est = L + seg_plan_jitter(t); }
+    else if (hist) est = min(max(hh, 0), n);
+    const int b = seg_plan_bin(est);
+    a.tmp[t] = (int32_t)(((uint32_t)b << 20) | (uint32_t)atomicAdd(&plan[b], cnt));     // (bin, rank inside the bin)
+    a.tmp2[t] = base >= 0 ? cnt : -1;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_seg_plan_place(int T, const int32_t* __restrict__ hist, int L, int split_min,
+                                                        SegArgs a, uint32_t* __restrict__ hint_host) {
+  __shared__ uint32_t start[SEG_PLAN_BINS];
+  __shared__ uint32_t wsum[4];
+  const int tid = threadIdx.x;
+  const int32_t* plan = a.hdr + SEG_HDR + 48;
+  {  // exclusive scan of the bins, in every workgroup: thread t owns bins [16 t, 16 t + 16)
+    constexpr int PER = SEG_PLAN_BINS / 256;
+    uint32_t v[PER], sum = 0u;
+    const uint4* p4 = reinterpret_cast<const uint4*>(plan) + tid * (PER / 4);
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) mw = max(mw, __shfl_xor(mw, d, 64));
-  if (lane == 0 && mw > 0) atomicMax(&s_mw, mw);
-  __syncthreads();
-  {  // exclusive scan of the bins: thread t owns bins [4 t, 4 t + 4)
-    uint32_t v[4], sum = 0u;
-#pragma unroll
-    for (int k = 0; k < 4; ++k) { v[k] = bins[4 * tid + k]; sum += v[k]; }
+    for (int k = 0; k < PER / 4; ++k) {
+      const uint4 q = p4[k];
+      v[4 * k] = q.x; v[4 * k + 1] = q.y; v[4 * k + 2] = q.z; v[4 * k + 3] = q.w;
+      sum += q.x + q.y + q.z + q.w;
+    }
     const uint32_t inc = wave_inclusive_scan(sum);
     if ((tid & 63) == 63) wsum[tid >> 6] = inc;
     __syncthreads();
-    uint32_t pre = 0u;
-    for (int w = 0; w < (tid >> 6); ++w) pre += wsum[w];
-    uint32_t ex = pre + inc - sum;
+    uint32_t ex = inc - sum;
+    for (int w = 0; w < (tid >> 6); ++w) ex += wsum[w];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) { bins[4 * tid + k] = ex; ex += v[k]; }
-    __syncthreads();
-    if (tid == 1023) wsum[0] = ex;    // total number of items
+    for (int k = 0; k < PER; ++k) { start[PER * tid + k] = ex; ex += v[k]; }
   }
   __syncthreads();
-  const int total = (int)wsum[0];
-  int32_t* __restrict__ items = a.items1;
-  // pass 2: a tile's items go to [start of its bin + its rank, + count).  Only the HEAD of a run is written here (a
-  // lane filling its own tile's run is one store instruction per item and wave; the whole wave filling one run after
-  // the other is 40 instructions per split tile on the one CU this kernel runs on: 12 us per 1000 split tiles); pass 3
-  // fills the runs position by position: the slots are dense, so position i belongs to the last head at or before it.
+  const int total = (int)(wsum[0] + wsum[1] + wsum[2] + wsum[3]);
   const int ntot = min(total, a.item_cap);
-  for (int i = tid; i < ntot; i += 1024) items[i] = -1;
-  __syncthreads();
-  for (int t0 = 0; t0 < T; t0 += 1024 * SP_REGS) {
-    uint32_t pp[SP_REGS];
-    int cc[SP_REGS];
-#pragma unroll
-    for (int q = 0; q < SP_REGS; ++q) {
-      const int t = min(t0 + q * 1024 + tid, T - 1);
-      pp[q] = (uint32_t)a.tmp[t];
-      cc[q] = a.tmp2[t];
-    }
-#pragma unroll
-    for (int q = 0; q < SP_REGS; ++q) {
-      const int t = t0 + q * 1024 + tid;
-      if (t >= T || pp[q] == 0xFFFFFFFFu) continue;
-      const int slot = (int)(bins[pp[q] >> 20] + (pp[q] & 0xFFFFFu));
-      if (slot >= ntot) continue;
-      // DIRECT: the bare tile index; split: segment 0 first
-      items[slot] = cc[q] < 0 ? t : (int32_t)((uint32_t)t | ((uint32_t)SEG_SPEC << 30));
+  const int t = blockIdx.x * 256 + tid;
+  if (t < T) {
+    const uint32_t pk = (uint32_t)a.tmp[t];
+    const int cnt = a.tmp2[t];
+    const int slot = (int)(start[pk >> 20] + (pk & 0xFFFFFu));
+    // DIRECT: the bare tile index; split: its SPEC items, segment 0 first
+    if (cnt < 0) { if (slot < ntot) a.items1[slot] = t; }
+    else {
+      const int32_t head = (int32_t)((uint32_t)t | ((uint32_t)SEG_SPEC << 30));
+      for (int j = 0; j < cnt && slot + j < ntot; ++j) a.items1[slot + j] = head + (j << 19);
     }
   }
-  __syncthreads();
-  {  // pass 3, in rounds of 1024 x 32 positions: thread t owns 32 consecutive ones, ALL requested before the first is
-     // looked at (a loop that loads, tests, stores position by position is a chain of L2 round trips: 14 us for 17)
-    constexpr int PB = 32;
-    __shared__ unsigned long long wlast[16];
-    __shared__ unsigned long long s_carry;
-    if (tid == 0) s_carry = 0ull;
-    for (int base = 0; base < ntot; base += 1024 * PB) {
-      const int i0 = base + tid * PB;
-      int v[PB];
-#pragma unroll
-      for (int k = 0; k < PB; ++k) v[k] = items[min(i0 + k, ntot - 1)];
-      unsigned long long mine = 0ull;    // (position + 1) << 32 | head value of the LAST head in my range; 0: none
-#pragma unroll
-      for (int k = 0; k < PB; ++k)
-        if (i0 + k < ntot && v[k] != -1) mine = ((unsigned long long)(i0 + k + 1) << 32) | (uint32_t)v[k];
-      // the last head in front of my range: an inclusive max-scan over (position, value) keys, then one step back
-      unsigned long long inc = mine;
-#pragma unroll
-      for (int d = 1; d < 64; d <<= 1) {
-        const unsigned long long o = __shfl_up(inc, d, 64);
-        if (lane >= d) inc = max(inc, o);
-      }
-      __syncthreads();                   // (s_carry of the previous round is written, wlast free again)
-      if (lane == 63) wlast[tid >> 6] = inc;
-      __syncthreads();
-      unsigned long long carry = __shfl_up(inc, 1, 64);
-      if (lane == 0) carry = 0ull;
-      carry = max(carry, s_carry);
-      for (int w = 0; w < (tid >> 6); ++w) carry = max(carry, wlast[w]);
-      int head = (int)(uint32_t)carry, hpos = (int)(carry >> 32) - 1;
-#pragma unroll
-      for (int k = 0; k < PB; ++k) {
-        const int i = i0 + k;
-        if (i < ntot) {
-          if (v[k] != -1) { head = v[k]; hpos = i; }
-          else if (hpos >= 0) items[i] = head + ((i - hpos) << 19);
-        }
-      }
-      __syncthreads();
-      if (tid == 1023) s_carry = max(carry, inc);
-    }
-  }
-  if (tid == 0) {
-    a.hdr[SH_ITEMS1] = min(total, a.item_cap); a.hdr[SH_ITEMS3] = s_n3; a.hdr[SH_SLOTS] = s_slots;
-    a.hdr[SH_MAXLEN] = s_max; a.hdr[SH_SPLIT] = s_n3; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
+  if (blockIdx.x == 0 && tid == 0) {
+    a.hdr[SH_ITEMS1] = ntot; a.hdr[SH_ITEMS3] = a.hdr[SH_P_N3]; a.hdr[SH_SLOTS] = a.hdr[SH_P_SLOTS];
+    a.hdr[SH_MAXLEN] = a.hdr[SH_P_MAXLEN]; a.hdr[SH_SPLIT] = a.hdr[SH_P_N3]; a.hdr[SH_L] = L; a.hdr[SH_MIN] = split_min;
     a.hdr[SH_MAXWALK] = 0;
-    // page-locked words the host peeks at before a LATER render: the longest list, and the longest walk of the
-    // camera's previous render (k_seg_report overwrites it with this render's)
-    if (hint_host) { hint_host[0] = (uint32_t)s_max; if (hist) hint_host[1] = (uint32_t)s_mw; }
+    // page-locked words the host peeks at before a LATER render
+    // (a rebuild -- the public splatB -- is handed this render's own walks: both words at once, a consistent pair; a
+    // forward render's pair comes from the range kernel of the next render on the stream, walk_raise)
+    if (hint_host && a.rebuild) { hint_host[0] = (uint32_t)a.hdr[SH_P_MAXLEN]; hint_host[1] = (uint32_t)a.hdr[SH_P_MAXWALK]; }
   }
 }
 
@@ -664,24 +586,23 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(ROLE == 0 ? 
       if (p.work_out) p.work_out[tile] = w + 2 * wmax;
       if (!sg.rebuild) sg.walk[tile] = wmax;      // (rebuilding: the walk of the pass whose `contrib` was handed in stays)
       if (sg.hist_walk) sg.hist_walk[tile] = wmax;
-      if (wmax > sg.hdr[SH_MAXWALK]) atomicMax(&sg.hdr[SH_MAXWALK], wmax);
+      walk_raise(&sg.hdr[SH_MAXWALK], wmax);
+      walk_raise(sg.walk_max, wmax);     // (-> the host's hint words, by the next render's range kernel)
+      if (sg.walk_max) walk_raise(sg.walk_max + 1, r1 - r0);     // ... with the longest list of the render (DIRECT and COMPOSE items)
     }
   }
 }
 
-// the longest walk of the render that just drew -> the host's hint slot (without it a scene of short walks would stay
-// on the segment path for ever)
-__global__ void k_seg_report(const int32_t* __restrict__ hdr, uint32_t* __restrict__ hint_host) {
-  if (threadIdx.x == 0 && hint_host) hint_host[1] = (uint32_t)hdr[SH_MAXWALK];
-}
-
 // plan + the forward launches over a carved workspace (see the ROLE comment above k_draw_seg)
 int draw_segments_forward(DrawParams& dp, const EgsPolicy* pol, SegArgs& sga, const SegConfig& cfg, int64_t patches,
-                          const int32_t* hist, int speculate, bool fix_pass, bool report, uint32_t* seg_hint,
-                          int32_t* ranges, const int32_t* gsid, const float4* rec, float* image, int32_t* contrib,
-                          float* final_tau, hipStream_t s) {
-  EGS_LAUNCH("k_seg_plan", k_seg_plan, dim3(1), dim3(1024), s, dp.T, ranges, hist, cfg.L, cfg.split_min, sga, seg_hint,
-             speculate);
+                          const int32_t* hist, int speculate, bool fix_pass, int32_t* walk_word, uint32_t* seg_hint,
+                          bool plan_zeroed, int32_t* ranges, const int32_t* gsid, const float4* rec, float* image,
+                          int32_t* contrib, float* final_tau, hipStream_t s) {
+  if (!plan_zeroed) EGS_HIP(hipMemsetAsync(sga.hdr, 0, (size_t)SEG_PLAN_WORDS * 4, s));
+  sga.walk_max = walk_word;
+  const int pg = div_up(dp.T, 256);
+  EGS_LAUNCH("k_seg_plan_count", k_seg_plan_count, dim3(pg), dim3(256), s, dp.T, ranges, hist, cfg.L, cfg.split_min, sga, speculate);
+  EGS_LAUNCH("k_seg_plan_place", k_seg_plan_place, dim3(pg), dim3(256), s, dp.T, hist, cfg.L, cfg.split_min, sga, seg_hint);
   // items <= tiles + segments <= T + P / L + P / split_min: the launch covers the bound, surplus workgroups exit
   const int grid1 = (int)std::min<int64_t>(seg_item_bound(dp.T, patches, cfg), sga.item_cap);
   if (dp.zero_buf) dp.zero_per = (dp.zero_n4 + (uint32_t)grid1 - 1) / (uint32_t)grid1;
@@ -704,7 +625,6 @@ int draw_segments_forward(DrawParams& dp, const EgsPolicy* pol, SegArgs& sga, co
   }
 #undef EGS_DRAWS3
 #undef EGS_DRAWS
-  if (report && seg_hint) EGS_LAUNCH("k_seg_report", k_seg_report, dim3(1), dim3(64), s, (const int32_t*)sga.hdr, seg_hint);
   EGS_LAUNCH_OK();
   return 0;
 }

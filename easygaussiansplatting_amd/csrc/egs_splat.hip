@@ -90,8 +90,8 @@ int splat_bwd_packed(int n, int64_t patches, int width, int height, const float*
       int32_t* rg = const_cast<int32_t*>(patch_range_per_tile);   // (only DIRECT items of an empty tile write it: none here)
       int rc = tile_work_from_contrib(dp, contrib, nullptr, sga.walk, s);
       if (rc) return rc;
-      rc = draw_segments_forward(fp, pol, sga, seg_config(), patches, (const int32_t*)sga.walk, 0, true, false, seg_hint,
-                                 rg, gsid_per_patch, rec, simg, scont, stau, s);
+      rc = draw_segments_forward(fp, pol, sga, seg_config(), patches, (const int32_t*)sga.walk, 0, true, nullptr, seg_hint,
+                                 false, rg, gsid_per_patch, rec, simg, scont, stau, s);
       if (rc) return rc;
     }
     return launch_draw_bwd_seg(dp, pol, patch_range_per_tile, gsid_per_patch, rec, final_tau, contrib, dloss_dgammas,
@@ -153,7 +153,10 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
                            void* stream, const uint32_t* patches_dev = nullptr, int32_t* tile_order = nullptr,
                            float* grad_records = nullptr, const int32_t* prev_tile_work = nullptr,
                            int order_ready = 0, int flags = 0, int32_t* gsid_plain = nullptr, void* seg_ws = nullptr,
-                           size_t seg_ws_bytes = 0, uint32_t* seg_hint = nullptr) {
+                           size_t seg_ws_bytes = 0, uint32_t* seg_hint = nullptr, int32_t* walk_word = nullptr) {
+  // walk_word (nullable, with seg_hint): the caller's PERSISTENT device word (one per problem size and stream, -1 before
+  // its first use) in which this render's draw items gather its longest walk; the range kernel of this call first
+  // publishes what the previous render left there into seg_hint[1]
   // seg_ws != NULL (egs_seg_ws_bytes): long lists are split over several waves (k_draw_seg; the backward pass then
   // takes the same workspace); flags & EGS_DRAW_SEG_HISTORY: the walk part of tile_order holds what an earlier render of
   // this camera measured.  seg_hint (nullable, page-locked): receives the longest list of this render.
@@ -228,12 +231,15 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
   }
   rc = radix_sort(patches, k0, v0, k1, v1, 0, tb, D.sort, s, nullptr, patches_dev);
   if (rc) return rc;
-  rc = tile_ranges(patches, D.tkeys, patch_range_per_tile, patches_dev,
-                   (const uint32_t*)(gsid_plain ? gsid_per_patch : nullptr), gsid_plain, s);
-  if (rc) return rc;
   SegArgs sga;
   const bool seg = seg_ws && pol->footprint == 0 && pol->alpha_skip > 0.f && pol->tau_stop > 0.f &&
                    dp.T <= (int)SEG_TILE_MASK && seg_carve(seg_ws, seg_ws_bytes, dp.T, &sga);
+  // (the range kernel clears the bins and counters of the segment plan on the side, and publishes the longest walk of the
+  // previous render on this stream)
+  rc = tile_ranges(patches, D.tkeys, patch_range_per_tile, patches_dev,
+                   (const uint32_t*)(gsid_plain ? gsid_per_patch : nullptr), gsid_plain, s, seg ? sga.hdr : nullptr,
+                   seg ? SEG_PLAN_WORDS : 0, walk_word, seg_hint);
+  if (rc) return rc;
   if (seg_ws && !seg) {
     set_error(EGS_ERR_WORKSPACE, "segment workspace too small (or a policy without a skip / stop threshold)", __FILE__, __LINE__);
     return EGS_ERR_WORKSPACE;
@@ -243,13 +249,13 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     const size_t olen = (size_t)tile_order_len(dp.gx, dp.gy);
     const int32_t* hist = (tile_order && (flags & EGS_DRAW_SEG_HISTORY)) ? tile_order + olen + dp.T : nullptr;
     sga.hist_walk = tile_order ? tile_order + olen + dp.T : nullptr;
-    const int speculate = (!hist && (flags & EGS_DRAW_SEG_SPECULATE)) ? 1 : 0;
+    const int speculate = (flags & EGS_DRAW_SEG_SPECULATE) ? 1 : 0;    // (with a walk on record: where that looks stale)
     if (tile_order) dp.work_out = tile_order + olen;
     if (grad_records) {   // (zero_per: set by draw_segments_forward from its grid)
       dp.zero_buf = (float4*)grad_records;
       dp.zero_n4 = (uint32_t)(3 * (size_t)n);
     }
-    return draw_segments_forward(dp, pol, sga, cfg, patches, hist, speculate, hist || speculate, true, seg_hint,
+    return draw_segments_forward(dp, pol, sga, cfg, patches, hist, speculate, hist || speculate, walk_word, seg_hint, true,
                                  patch_range_per_tile, gsid_per_patch, rec, image, contrib, final_tau, s);
   }
   if (order_ready && tile_order && tile_order_mode(0) > 0 && dp.T <= TILE_ORDER_MAX_T) {
@@ -257,12 +263,14 @@ static int splat_draw_impl(int n, int64_t patches, int width, int height, const 
     dp.ngrid = tile_order_mode(0) >= 3 ? tile_order_len(dp.gx, dp.gy) : dp.T;
   } else {
     // (prev_tile_work is the work part of a camera's own buffer: its walk part lies T ints behind it)
+    // (no hint words from here, as in round 5 -- the walk of the camera's PREVIOUS render is stale after reset_alpha and
+    // would overwrite what the range kernel just published; the draw waves gather both words of this render)
     rc = tile_order_enqueue(dp, 0, tile_order ? tile_order : D.order, (size_t)tile_order_len(dp.gx, dp.gy),
-                            patch_range_per_tile, s, prev_tile_work,
-                            (prev_tile_work && seg_hint) ? prev_tile_work + dp.T : nullptr, seg_hint);
+                            patch_range_per_tile, s, prev_tile_work, nullptr, walk_word ? nullptr : seg_hint);
     if (rc) return rc;
   }
   if (tile_order) { dp.work_out = tile_order + tile_order_len(dp.gx, dp.gy); dp.walk_out = dp.work_out + dp.T; }
+  if (tile_order) dp.walk_max = walk_word;     // (every render refreshes the host's hint, one render late)
   if (grad_records) {
     dp.zero_buf = (float4*)grad_records;
     dp.zero_n4 = (uint32_t)(3 * (size_t)n);
@@ -361,15 +369,15 @@ extern "C" int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* to
                                       size_t ws_draw_bytes, float* image, int32_t* contrib, float* final_tau,
                                       int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order,
                                       float* grad_records, const int32_t* prev_tile_work, int order_ready, int flags,
-                                      void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint, int32_t* gsid_plain,
-                                      void* stream) {
+                                      void* seg_ws, size_t seg_ws_bytes, uint32_t* seg_hint, int32_t* walk_word,
+                                      int32_t* gsid_plain, void* stream) {
   // gsid_plain (nullable, with EGS_DRAW_MASKED_LISTS: the seven-op surface): receives the list without its masks
   EGS_CHECK_ARG((rec || n == 0) && (!total_patches || patches > 0));
   EGS_CHECK_ARG(!gsid_plain || ((((uintptr_t)gsid_plain | (uintptr_t)gsid_per_patch) & 15) == 0));
   return splat_draw_impl(n, patches, width, height, nullptr, nullptr, nullptr, nullptr, nullptr, pol, ws_bin, ws_draw,
                          ws_draw_bytes, (const float4*)rec, image, contrib, final_tau, patch_range_per_tile,
                          gsid_per_patch, stream, total_patches, tile_order, grad_records, prev_tile_work, order_ready,
-                         flags, gsid_plain, seg_ws, seg_ws_bytes, seg_hint);
+                         flags, gsid_plain, seg_ws, seg_ws_bytes, seg_hint, walk_word);
 }
 
 extern "C" size_t egs_splat_bwd_ws_bytes(int n) {

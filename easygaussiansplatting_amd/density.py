@@ -182,6 +182,9 @@ class DensityControl:
                                        m.data_ptr() if m is not None else None,
                                        v.data_ptr() if v is not None else None,
                                        torch.cuda.current_stream().cuda_stream))
+        if a.is_cuda:      # nothing saturates any more: the next renders walk their whole lists (fused.expect_long_walks)
+            from . import fused as _fused
+            _fused.expect_long_walks(a.device, renders=4)
 
     def update_pws_lr(self, optimizer):
         """gsmodel.py:332-338 with the schedule of gsmodel.py:180-183."""

@@ -102,6 +102,10 @@ class _DeviceCtx:
         # of the tiles is kept between the renders of a camera (a trainer meets every view again each epoch)
         self.tile_work = {}
         self.seg_hint = {}      # (N, W, H) -> mailbox slot kept as the landing zone of "longest list of the last render"
+        # ((N, W, H), stream) -> one persistent int32 device word (-1 = nothing gathered): the draw items of a render
+        # gather its longest walk there, the next render on that stream publishes it into the hint slot (egs_hip.h)
+        self.walk_word = {}
+        self.long_walks_expected = 0   # renders for which a caller announced long walks (expect_long_walks)
         self.lock = threading.RLock()
 
 
@@ -222,6 +226,23 @@ def commit(device=None):
     return [t.state for t in bad]
 
 
+def expect_long_walks(device=None, renders=4):
+    """A caller that KNOWS the next renders will walk their tile lists far (this package's ``DensityControl.reset_alpha``:
+    every opacity drops to 0.01, nothing saturates any more, gsmodel.py:320-324) says so: the next ``renders`` renders on
+    ``device`` take the segment path and speculate whole lists at once, instead of learning it from the hint words two
+    renders late (the draw stage publishes a render's longest walk at the start of the NEXT draw stage on its stream;
+    13 + 10 ms instead of 3.3 per training step on scene.skewed_scene's ring views).  An unmodified reference caller never
+    calls this and pays those two steps."""
+    index = torch.cuda.current_device() if device is None else torch.device(device).index
+    if index is None:
+        return
+    ctx = _contexts.get(index)
+    if ctx is None:
+        ctx = _ctx(torch.device("cuda", index))
+    with ctx.lock:
+        ctx.long_walks_expected = max(ctx.long_walks_expected, int(renders))
+
+
 def _seg_decision(ctx, lib, key, pol_):
     """-> (use the segment path for this render, device-visible address of the hint slot or None).  The draw stage
     leaves two numbers in a page-locked slot kept per problem size -- the longest list, and the longest WALK (largest
@@ -255,8 +276,29 @@ def _seg_decision(ctx, lib, key, pol_):
     # pays for the segment workspace, ~6 KB per 256 entries of a split tile); nothing known at all: the segment path
     unknown = walk == 0xFFFFFFFF and (longest == 0xFFFFFFFF or longest > cfg[1])
     use = SEGMENTS == "1" or unknown or (walk != 0xFFFFFFFF and walk > cfg[1])
+    with ctx.lock:
+        announced = ctx.long_walks_expected > 0
+        if announced:
+            ctx.long_walks_expected -= 1
+    if announced and SEGMENTS != "0":
+        _tls.seg_speculate = SEG_SPECULATE != "0"
+        return True, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot))
     _tls.seg_speculate = SEG_SPECULATE == "1" or (SEG_SPECULATE == "auto" and known and 2 * walk >= longest)
     return use, C.c_void_p(lib.egs_mailbox_slot(ctx.mb, slot))
+
+
+def _walk_word(ctx, key, dev, st, have_hint):
+    """The persistent device word of (problem size, stream) for the draw stage's longest-walk report, or None."""
+    if not have_hint:
+        return None
+    k = (key, int(st.value or 0))
+    with ctx.lock:
+        w = ctx.walk_word.get(k)
+        if w is None:
+            while len(ctx.walk_word) >= 4 * HINT_SLOTS:          # (bounded: streams and sizes that are gone)
+                ctx.walk_word.pop(next(iter(ctx.walk_word)))
+            w = ctx.walk_word[k] = torch.full((16,), -1, dtype=torch.int32, device=dev)
+    return w
 
 
 def seg_hint(device=None, key=None):
@@ -356,7 +398,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                                               ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                               _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
                                               order_ready, draw_flags, _ptr(S.seg),
-                                              S.seg.numel() if S.seg is not None else 0, seg_hint, None, st))
+                                              S.seg.numel() if S.seg is not None else 0, seg_hint, _ptr(walk_word), None, st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -378,6 +420,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     prev_work, order_ready = None, 0
     cache_entry = None        # registered only AFTER the draw stage that writes the order buffer was enqueued
     use_seg, seg_hint = _seg_decision(ctx, lib, key, pol_) if n > 0 else (False, None)
+    walk_word = _walk_word(ctx, key, dev, st, seg_hint is not None)
     walk_known = False        # the camera was rendered before: its walk lengths are on record
     if TILE_WORK_CACHE and n > 0:
         ck = (id(cam), int(st.value or 0))              # one entry per camera and stream, whatever the scene size
@@ -425,7 +468,9 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
             tw[ck] = (ref, S.order, renders, (n, W, H))
     S.order_by_work = prev_work is not None or order_ready == 1
     draw_flags = (1 if S.culled else 0) | (SEG_HISTORY if (use_seg and walk_known) else 0) | \
-        (SEG_SPECULATE_FLAG if (use_seg and not walk_known and getattr(_tls, "seg_speculate", False)) else 0)
+        (SEG_SPECULATE_FLAG if (use_seg and getattr(_tls, "seg_speculate", False)) else 0)
+    # (SPECULATE with a walk on record: the plan distrusts a record that is far shorter than the tile's list while the
+    # scene's recent renders walk most of theirs -- the renders right after reset_alpha, gsmodel.py:320-324)
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
     def render_exact():
@@ -477,7 +522,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                                               _ptr(ws_draw), ws_draw.numel(), _ptr(image), _ptr(S.contrib),
                                               _ptr(S.final_tau), _ptr(S.ranges), _ptr(gsid_full), _ptr(S.order),
                                               _ptr(S.gpack), prev_work, order_ready, draw_flags, _ptr(S.seg),
-                                              S.seg.numel() if S.seg is not None else 0, seg_hint, None, st))
+                                              S.seg.numel() if S.seg is not None else 0, seg_hint, _ptr(walk_word), None, st))
     except BaseException:
         # Whatever was enqueued before the failure (the arm, the binning chain) still stores {P, max key} into the
         # slot: it goes back on the free list only once those kernels have run -- otherwise a render on another

@@ -486,6 +486,7 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
     from . import fused as _fused            # (the per-device mailbox / capacity / hint state lives there)
     ctx = _fused._ctx(dev)
     use_seg, seg_hint = _fused._seg_decision(ctx, lib, key, _pol()) if n > 0 else (False, None)
+    walk_word = _fused._walk_word(ctx, key, dev, st, seg_hint is not None)
     seg_flags = 8 if (use_seg and getattr(_fused._tls, "seg_speculate", False)) else 0     # EGS_DRAW_SEG_SPECULATE
     seg_ws = [None]
     lists = [None]     # the list the draw kernels walked (with masks), kept for the backward draw
@@ -534,7 +535,7 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
                                               _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau),
                                               _ptr(ranges), _ptr(walked), _ptr(order), _ptr(gpack), None, 0,
                                               flags | seg_flags, _ptr(seg_ws[0]),
-                                              seg_ws[0].numel() if use_seg else 0, seg_hint,
+                                              seg_ws[0].numel() if use_seg else 0, seg_hint, _ptr(walk_word),
                                               _ptr(gsid) if masks else None, st))
         if masks:
             lists[0] = walked
@@ -578,7 +579,7 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
                                               _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib),
                                               _ptr(final_tau), _ptr(ranges), _ptr(walked_full), _ptr(order),
                                               _ptr(gpack), None, 0, flags | seg_flags, _ptr(seg_ws[0]),
-                                              seg_ws[0].numel() if use_seg else 0, seg_hint,
+                                              seg_ws[0].numel() if use_seg else 0, seg_hint, _ptr(walk_word),
                                               _ptr(gsid_full) if masks else None, st))
     except BaseException:
         # Kernels enqueued before the failure (the arm, the binning chain) still store {P, max key} into the slot:

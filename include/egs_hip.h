@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 7
+#define EGS_ABI_VERSION 8
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -315,21 +315,29 @@ size_t egs_tile_order_len(int width, int height);   /* ints: [forward dispatch o
  * egs_fused_backward(_raw) given the SAME workspace walks every segment with a wave of its own (no sequential
  * dependence is left in the backward pass).  Tile-footprint policies with alpha_skip > 0 and tau_stop > 0 only.
  * Images / contrib / final_tau equal the unsplit kernels' up to the rounding of  sum_s T_s C_s  against one running sum.
- * seg_hint (nullable, page-locked host memory, e.g. a mailbox slot): receives the longest list of this render -- a
+ * seg_hint (nullable, page-locked host memory, e.g. a mailbox slot, two words): [0] receives the longest list, [1] the
+ * longest WALK of a recent render.  ABI 8: walk_word (nullable) is a PERSISTENT device word of the caller's, one per
+ * problem size and stream, holding -1 before its first use: the draw items of this call gather the render's longest walk
+ * in it, and the range kernel at the start of the NEXT call's draw stage on the stream publishes it into seg_hint[1] and
+ * resets it -- the host word only ever holds the maximum of a completed render, from every render, split or not -- a
  * host that finds it below split_min may drop the workspace for later renders of the scene (the unsplit kernels are
  * then the same work with two launches less).  prev_tile_work / order_ready are ignored when the lists are split
  * (the work items are re-planned per render, by k_seg_plan). */
 #define EGS_DRAW_SEG_HISTORY 4
-/* flags of egs_splat_draw_rec_seg, for a camera WITHOUT a walk on record: take every tile's list length as its predicted
- * walk (all its segments get a wave at once).  For scenes the host knows to be walked to (nearly) their ends -- the
+/* flags of egs_splat_draw_rec_seg: take a tile's list length as its predicted walk (all its segments get a wave at once)
+ * -- for a camera WITHOUT a walk on record, and (ABI 8) for tiles whose recorded walk is less than a quarter of their
+ * list: a record from before reset_alpha.  For scenes the host knows to be walked to (nearly) their ends -- the
  * longest walk a recent render of the scene reported is a good part of its longest list, as right after reset_alpha --
  * where the alternative (one wave continuing from segment 1) is the serial tail this path exists to remove.  On a
  * saturating scene it would blend segments nobody looks at: exact either way, the balance is the host's call. */
 #define EGS_DRAW_SEG_SPECULATE 8
 size_t egs_seg_ws_bytes(int64_t patch_capacity, int width, int height);
 /* segment_len (a power of two >= 64) / split_min: 0 keeps the current value; out2 (nullable) receives the values BEFORE the
- * call.  Process-wide tuning knob (defaults 256 / 1024, or EGS_SEG_L / EGS_SEG_MIN from the environment); a workspace
- * must be sized and used under one setting. */
+ * call.  Process-wide default (256 / 1024, or EGS_SEG_L / EGS_SEG_MIN from the environment), one atomic word: a render
+ * reads it ONCE, when its forward pass plans; the plan leaves L in the workspace header and every later launch -- the
+ * backward pass included -- takes it from there and sizes its grid by the workspace (ABI 8: a change between a forward
+ * and its backward call no longer matters).  A workspace sized under a larger setting than the one planned with simply
+ * has fewer slots than tiles could use: tiles that do not fit stay unsplit. */
 int egs_seg_config(int segment_len, int split_min, int* out2);
 int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* total_patches /*nullable*/, int width, int height,
                            const void* rec, const EgsPolicy* pol, const void* ws_bin, void* ws_draw,
@@ -337,7 +345,7 @@ int egs_splat_draw_rec_seg(int n, int64_t patches, const uint32_t* total_patches
                            int32_t* patch_range_per_tile, int32_t* gsid_per_patch, int32_t* tile_order /*nullable*/,
                            float* grad_records /*nullable*/, const int32_t* prev_tile_work /*nullable*/, int order_ready,
                            int flags, void* seg_ws /*nullable: the unsplit draw stage*/, size_t seg_ws_bytes,
-                           uint32_t* seg_hint /*nullable*/,
+                           uint32_t* seg_hint /*nullable*/, int32_t* walk_word /*nullable*/,
                            int32_t* gsid_plain /*nullable; with EGS_DRAW_MASKED_LISTS: the list without its masks, what
                                                  the caller of `splat` gets (as egs_splat_draw_rec_plain)*/,
                            void* stream);

@@ -17,7 +17,7 @@ _NAMES = ("ranges", "gsid", "us", "cinv2ds", "alphas", "colors", "contrib", "fin
 
 
 def _worker(job):
-    tmp, width, height, tiles, near_margin, near_u_eps, repo = job
+    tmp, width, height, tiles, near_margin, near_u_ulps, repo = job
     if repo not in sys.path:
         sys.path.insert(0, repo)
     from oracle import gs_oracle as O
@@ -26,7 +26,7 @@ def _worker(job):
     near = np.zeros(n, bool)
     g = O.draw_backward(width, height, a["ranges"], a["gsid"], a["us"], a["cinv2ds"], a["alphas"], a["colors"],
                         a["contrib"], a["final_tau"], a["dl"], None, O.POLICY_G, tiles=tiles, near_out=near,
-                        near_margin=near_margin, near_u_eps=near_u_eps)
+                        near_margin=near_margin, near_u_ulps=near_u_ulps)
     rg = a["ranges"]
     ids = np.unique(np.concatenate([np.asarray(a["gsid"][rg[t, 0]:rg[t, 1]]) for t in tiles] or [np.zeros(0, np.int64)]))
     ids = ids.astype(np.int64)
@@ -34,7 +34,7 @@ def _worker(job):
 
 
 def draw_backward_tiles(width, height, ranges, gsid, us, cinv2ds, alphas, colors, contrib, final_tau, dl, tiles=None,
-                        near_margin=1e-4, procs=None, chunks_per_proc=6, near_u_eps=0.0):
+                        near_margin=1e-4, procs=None, chunks_per_proc=6, near_u_ulps=0.0):
     """-> (dus[N,2], dcinv[N,3], dalpha[N], dcolor[N,3], near[N]) over ``tiles`` (default: all), POLICY_G."""
     repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ranges = np.asarray(ranges); gsid = np.asarray(gsid)
@@ -56,7 +56,7 @@ def draw_backward_tiles(width, height, ranges, gsid, us, cinv2ds, alphas, colors
     try:
         for k, v in arrays.items():
             np.save(os.path.join(tmp, k + ".npy"), v)
-        jobs = [(tmp, width, height, c, near_margin, near_u_eps, repo) for c in chunks]
+        jobs = [(tmp, width, height, c, near_margin, near_u_ulps, repo) for c in chunks]
         dus = np.zeros((n, 2)); dcinv = np.zeros((n, 3)); dalpha = np.zeros(n); dcolor = np.zeros((n, 3))
         near = np.zeros(n, bool)
         if procs == 1:

@@ -29,7 +29,7 @@ from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
 from tests.conftest import load_golden
 from tests.gradcheck import assert_grad_close_flips
-from tests.test_gpu_parity import (LIKE_MARGIN, LIKE_NEAR_FRAC, _oracle_2d, check_against_g11, check_culled_lists, complete_inside,
+from tests.test_gpu_parity import (LIKE_MARGIN, LIKE_NEAR_FRAC, LIKE_U_ULPS, _oracle_2d, check_against_g11, check_culled_lists, complete_inside,
                                    dev, gradient_windows, host)
 
 pytestmark = pytest.mark.gpu
@@ -148,7 +148,7 @@ def test_eight_ring_views_full_size():
         # device's float32, its blend and chain rule in float64 -- the default rule of tests/gradcheck.py
         q_us, q_ci, q_col, _, _ = _oracle_2d(sc, cnp, dtype=np.float32)
         o_g2 = O.draw_backward(W, H, rg, gs, q_us, q_ci, alphas64, q_col, hcont, htau, dl64, None, O.POLICY_G,
-                               tiles=sub, near_out=near, near_margin=LIKE_MARGIN)
+                               tiles=sub, near_out=near, near_margin=LIKE_MARGIN, near_u_ulps=LIKE_U_ULPS)
         _, _, _, _, J = _oracle_2d(sc, cnp, full, True, np.float32)
         og = O.chain_rule(o_g2[0][full], o_g2[1][full], o_g2[2][full], o_g2[3][full], cnp.Rcw, J)
         want = dict(pws=og["dpws"], shs=og["dshs"], alphas=og["dalphas"][:, None], scales=og["dscales"],

@@ -68,7 +68,7 @@ def run(fused, sc, cam, dl, renders=1):
     return out
 
 
-def compare(a, b, label, flips=8, tol_max=1e-4):
+def compare(a, b, label, flips=8, tol_max=2e-4):
     """segment path ``a`` against the unsplit kernels ``b``: same lists; the image differs by the rounding of the
     composed sum; a pixel may stop one entry earlier or later where T * tau_local straddles tau_stop (counted)."""
     assert np.array_equal(a["ranges"], b["ranges"]) and np.array_equal(a["ids"], b["ids"])
@@ -138,7 +138,9 @@ def test_segments_skewed_scene_full_size(fx):
     assert got["seg"]
     lens = ref["ranges"][:, 1] - ref["ranges"][:, 0]
     assert lens.max() > 10_000 and ref["contrib"].max() > 6_000
-    compare(got, ref, "skewed_reset", flips=64, tol_max=4e-4)   # (8 000 divisions in the unsplit pass: see compare)
+    # (default tolerance since round 6: tests/test_gpu_round5_vs_oracle.py measures BOTH kernels against the oracle on this
+    # scene -- unsplit 1.6e-5, segments 1.7e-4 of the maximum in dL/du, medians 7e-6 / 7e-7 -- so 4e-4 is not needed)
+    compare(got, ref, "skewed_reset", flips=64)
     # the oracle on the longest tile, its right neighbour and two others (float64 2D Gaussians of the oracle's own)
     from tests.test_gpu_parity import _oracle_2d
     o_us, o_ci, o_col, _, _ = _oracle_2d(sc, sc.cam)
@@ -259,12 +261,12 @@ def _segment_states(seg_bytes, T):
     w = seg_bytes.view(np.int32)
     nbytes = seg_bytes.size
     Tp = (T + 63) // 64 * 64
-    fixed = 16 + 48 + 5 * Tp
+    fixed = 16 + 48 + 4096 + 5 * Tp                  # header, spare words, the plan's global bins, five [T] arrays
     slots = (nbytes - (4 * (fixed + T + 64) + 1024)) // (256 * 6 * 4 + 4)
     item_cap = min(T + slots, 1 << 20)
     slot_cap = min(slots, item_cap - T)
     hdr = w[:16]
-    seg_base = w[64:64 + T]
+    seg_base = w[64 + 4096:64 + 4096 + T]
     off = 4 * (fixed + T + slots + 64)
     off = (off + 255) // 256 * 256
     st4 = seg_bytes[off:off + slot_cap * 256 * 16].view(np.float32).reshape(slot_cap, 256, 4)

@@ -126,7 +126,193 @@ def relaunch_command(gpus, env, argv):
             "--master-addr", "127.0.0.1", "--master-port", port, BENCH_PY] + list(argv)
 
 
-def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
+def _timed(fn, n, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+def train_legs(sc, cam, dev, n_steps, full=False):
+    """The whole training step on ``sc`` from camera ``cam`` (outside the timed region of the contract line):
+      fwd_loss_bwd  render + fused HIP L1/SSIM loss + backward, no optimizer (GSFunction, activated parameters);
+      train_step    raw parameters -> activations -> render -> loss -> backward -> Adam over 59 floats per Gaussian:
+                    ``as_trainer_factored_sh`` is what ``Trainer.step`` enqueues for one view (deferred validation,
+                    activations inside the kernels, the loss kernels hand dL/dimage to backward, the SH gradient stays
+                    factored and FusedAdam forms the rows); ``fused_activations_fused_adam`` the same with dense SH rows;
+                    ``full``: also torch activations and torch.optim.Adam (the reference's structure, gsmodel.py:198-210).
+    -> (fwd_loss_bwd dict, train_step dict)"""
+    import torch
+    from easygaussiansplatting_amd import dist_views as DV, fused as fused_path
+    from easygaussiansplatting_amd.function import GSFunction, GSRawFunction
+    from easygaussiansplatting_amd.loss import gau_loss, gau_loss_with_grad
+    from easygaussiansplatting_amd.optim import FusedAdam, adam_groups
+    from easygaussiansplatting_amd.trainer import activate, raw_params_from_scene
+    H, W = int(cam.height), int(cam.width)
+    gt = torch.rand((3, H, W), device=dev)
+    raw = raw_params_from_scene(sc, dev)
+    act = [x.detach().clone().requires_grad_(True) for x in activate(raw)]
+    us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+
+    def step_with_loss():
+        for p in act:
+            p.grad = None
+        us0.grad = None
+        with fused_path.deferred() as d:
+            img, _ = GSFunction.apply(*act, us0, cam)
+            gau_loss(img, gt).backward()
+            d.commit()
+    loss_ms = _timed(step_with_loss, n_steps, warm=4)
+    del act
+    opts = {"fused": FusedAdam(adam_groups(raw), eps=1e-15)}
+    if full:
+        opts["torch"] = torch.optim.Adam(adam_groups(raw), lr=0.0, eps=1e-15)
+
+    def train_step(opt, fused_act=False):
+        opt.zero_grad(set_to_none=True)
+        us = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+        if fused_act:   # activations inside the HIP kernels
+            img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                         raw["scales_raw"], raw["rots_raw"], us, cam)
+        else:           # the reference's structure: torch activations around GSFunction
+            img, _ = GSFunction.apply(*activate(raw), us, cam)
+        gau_loss(img, gt).backward()
+        opt.step()
+    fxt = DV.FactoredShGrad(1)
+    us_keep = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+
+    def train_step_factored(opt):
+        opt.zero_grad(set_to_none=True)
+        us_keep.grad = None
+        with fused_path.deferred() as d, fxt.attach():
+            img, _ = GSRawFunction.apply(raw["pws"], raw["low_shs"], raw["high_shs"], raw["alphas_raw"],
+                                         raw["scales_raw"], raw["rots_raw"], us_keep, cam)
+            _stats, dimg = gau_loss_with_grad(img.detach(), gt)
+            img.backward(dimg)
+            d.commit()
+        rows, _w = fxt.take()
+        opt.step(factored_sh=(rows, 1.0, raw["pws"], raw["low_shs"], raw["high_shs"]))
+    tr = {"note": "1 view: activations + render + HIP loss + backward + Adam over 59 floats/Gaussian"}
+    tr["train_step_ms_as_trainer_factored_sh"] = round(_timed(lambda: train_step_factored(opts["fused"]), n_steps, warm=4), 4)
+    tr["train_step_ms_fused_activations_fused_adam"] = round(_timed(lambda: train_step(opts["fused"], True), n_steps), 4)
+    tr["adam_only_ms_fused"] = round(_timed(opts["fused"].step, n_steps), 4)
+    if full:
+        for name, opt in opts.items():
+            tr["train_step_ms_torch_activations_%s_adam" % name] = round(_timed(lambda: train_step(opt), n_steps), 4)
+        tr["adam_only_ms_torch"] = round(_timed(opts["torch"].step, n_steps), 4)
+    del raw, opts, us_keep, gt
+    torch.cuda.empty_cache()
+    return ({"ms": round(loss_ms, 4), "note": "render + fused HIP L1/SSIM loss + backward (no optimizer), 1 view"}, tr)
+
+
+def epoch_pattern_leg(dev, epochs_with_history=2):
+    """The access pattern of the reference's training loop (train.py:43-77) instead of one repeated camera: ONE view per
+    optimizer step, the 8 ring cameras in a freshly shuffled order every epoch (train.py:44-49), a densification in the
+    middle (N changes: every per-camera walk history, dispatch order and hint slot of the old size is dropped,
+    gsmodel.py:214-317) and a ``reset_alpha`` after it (gsmodel.py:320-324: nothing saturates any more, tile walks
+    grow from hundreds to thousands of entries).  The model is ``scene.skewed_scene`` (the shape of a trained scene:
+    BASELINE configs[4]'s data is on no box), perturbed so that the loss has something to do; every step is
+    ``Trainer.step`` (render + loss + backward + FusedAdam, deferred validation).  Per phase the mean GPU time of a step
+    (HIP events around each step; the host runs ahead), first-sight epochs apart from epochs with history."""
+    import torch
+    from easygaussiansplatting_amd import scene as S
+    from easygaussiansplatting_amd.function import Camera, render
+    from easygaussiansplatting_amd.trainer import Trainer
+    sc = S.skewed_scene()
+    W, H = sc.cam.width, sc.cam.height
+    cams = [Camera.from_scene(c, dev) for c in S.ring_cameras(sc.cam, 8)]
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    with torch.no_grad():
+        P = [t(sc.pws), t(sc.shs), t(sc.alphas), t(sc.scales), t(sc.rots)]
+        gts = [render(*P, c)[0].clone() for c in cams]
+        del P
+    start = S.skewed_scene()
+    start.pws[:] = start.pws + 0.004 * S.normal(11, 1, start.pws.shape).astype(np.float32)
+    start.shs[:, :3] += 0.3 * S.normal(11, 2, (start.n, 3)).astype(np.float32)
+    tr = Trainer(start, cams, gts, max_steps=3000, scene_size=8.0, seed=1)
+    rng = np.random.default_rng(0)
+    out = {"what": "Trainer.step, ONE view per step, 8 ring cameras reshuffled per epoch; ms = mean GPU time per step "
+                   "(HIP events); scene.skewed_scene perturbed (pws +- 0.004, SH degree 0 +- 0.3)", "phases": []}
+
+    def epoch(label):
+        evs = []
+        for v in rng.permutation(8):
+            e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            tr.step([int(v)], sync=False)
+            e1.record()
+            evs.append((e0, e1))
+        torch.cuda.synchronize()
+        ms = [a.elapsed_time(b) for a, b in evs]
+        out["phases"].append({"phase": label, "gaussians": int(tr.params["pws"].shape[0]), "steps": len(ms),
+                              "ms_per_step": round(float(np.mean(ms)), 4), "max_ms": round(float(np.max(ms)), 4),
+                              "redone_steps_so_far": tr.redone_steps})
+    epoch("first sight of every camera")
+    for _ in range(epochs_with_history):
+        epoch("with history")
+    rep = tr.densify()
+    out["densify"] = {k: (int(v) if isinstance(v, (int, np.integer)) else v) for k, v in (rep or {}).items()} \
+        if isinstance(rep, dict) else str(rep)
+    epoch("after densify (N changed): first sight again")
+    epoch("after densify: with history")
+    tr.reset_alpha()
+    epoch("after reset_alpha: first epoch")
+    epoch("after reset_alpha: with history")
+    first = [p["ms_per_step"] for p in out["phases"] if "first" in p["phase"]]
+    hist = [p["ms_per_step"] for p in out["phases"] if "first" not in p["phase"]]
+    out["first_sight_ms_per_step"] = round(float(np.mean(first)), 4)
+    out["with_history_ms_per_step"] = round(float(np.mean(hist)), 4)
+    del tr, gts
+    torch.cuda.empty_cache()
+    return out
+
+
+def uhd_leg(dev, lib, n=1_000_000, steps=10):
+    """3840 x 2160 once (the reference is resolution-agnostic: kernel.cu:152, grid from gausplat.cu:94): T = 32 400 tiles
+    (15 tile-key bits: two 8-bit passes of the tile sort; k_tile_order's tail registers), the bench scene seen through a
+    camera of twice the focal length.  forward + backward, fused path, deferred validation."""
+    import torch
+    from easygaussiansplatting_amd import fused as fused_path, scene as S
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    W, H = 3840, 2160
+    sc = S.big_scene(n, W, H, 48)
+    sc.cam = S.Camera(W, H, 2400.0, 2400.0, W / 2.0, H / 2.0, sc.cam.Rcw, sc.cam.tcw)
+    cam = Camera.from_scene(sc.cam, dev)
+    t = lambda x: torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+    P = [t(sc.pws), t(sc.shs), t(sc.alphas).reshape(-1, 1).clone(), t(sc.scales), t(sc.rots)]
+    for p in P:
+        p.requires_grad_(True)
+    us0 = torch.zeros((sc.n, 2), device=dev, requires_grad=True)
+    dl = torch.from_numpy(S.normal(1, 78, (3, H, W)).astype(np.float32)).to(dev) / (3 * H * W)
+
+    def step():
+        for p in P:
+            p.grad = None
+        us0.grad = None
+        with fused_path.deferred() as d:
+            img, _ = GSFunction.apply(*P, us0, cam)
+            img.backward(dl)
+            if d.commit():
+                img, _ = GSFunction.apply(*P, us0, cam)
+                img.backward(dl)
+    ms = _timed(step, steps, warm=6)
+    with torch.no_grad():
+        _, _, st = fused_path.forward(*[p.detach() for p in P], cam)
+        lens = (st.ranges[:, 1] - st.ranges[:, 0]).to(torch.int64)
+        out = {"width": W, "height": H, "gaussians": sc.n, "tiles": int(lens.numel()), "patches_drawn": int(st.patch_count()),
+               "max_list_len": int(lens.max().item()), "ms_per_step": round(ms, 4),
+               "Mpix/s": round(W * H / (ms * 1e-3) / 1e6, 2)}
+    del P, us0, dl
+    torch.cuda.empty_cache()
+    return out
+
+
+def scene_leg(name, sc, dev, lib, steps, iid_ref=None, train=False):
     """One extra leg of the default run, outside the timed region: the headline step (GSFunction fused, forward +
     backward, deferred validation) on ANOTHER scene -- list statistics, ms per step, the per-kernel table of the two
     draw kernels, and their time against the iid scene's scaled by the pixel-Gaussian pairs (every number
@@ -191,8 +377,7 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
                "ms_per_step": round(ms, 4), "Mpix/s": round(W * H / (ms * 1e-3) / 1e6, 2), "kernels_avg_us": kern}
     # the draw stage of either path: the unsplit kernel, or the segment kernels + the planning launch in front of them
     # and the one-word report behind them (the backward launch runs over the forward pass's work items: no plan of its own)
-    fwd = sum(v for k, v in kern.items() if k.startswith("k_draw") and "bwd" not in k) + \
-        kern.get("k_seg_plan", 0.0) + kern.get("k_seg_report", 0.0)
+    fwd = sum(v for k, v in kern.items() if (k.startswith("k_draw") and "bwd" not in k) or k.startswith("k_seg_"))
     bwd = sum(v for k, v in kern.items() if k.startswith("k_draw_bwd"))
     out["draw_fwd_us"], out["draw_bwd_us"] = round(fwd, 1), round(bwd, 1)
     out["segment_path"] = "k_draw_seg" in kern
@@ -216,5 +401,7 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None):
                 out[k + "_over_pairs_scaled_iid"] = round(v / (r * iid_ref[k + "_us"]), 3)
     del P, us0, dl
     torch.cuda.empty_cache()
+    if train:     # the whole training step on this scene (render + loss + backward + Adam)
+        out["fwd_loss_bwd"], out["train_step"] = train_legs(sc, cam, dev, 8)
     return out
 

@@ -34,7 +34,7 @@ for it in range(2):
     ws = st.seg.cpu().numpy().view(np.int32)
     hdr = ws[:16]
     Tp = (T + 63) // 64 * 64
-    o = 64
+    o = 64 + 4096        # header + spare words + the plan's global bins (csrc/egs_raster.h SEG_PLAN_WORDS)
     seg_base = ws[o:o + T]; o += Tp
     walk = ws[o:o + T]; o += Tp
     items3 = ws[o:o + T]; o += Tp
