@@ -42,13 +42,16 @@ def host(t):
 # at 7.6e-3 still unflagged with 1.5e-4, 13 of 1.43 M large entries beyond 5e-3 left over as "outliers").  What decides
 # the size of a flip is how steep the Gaussian is where the threshold cuts it: d ln(alpha') = |cinv (u - p)| du, and the
 # centre u of a float32 Gaussian near x = 1900 is known to 1.2e-4 px -- 1e-3 in alpha' for a steep one (cinv ~ 3, three
-# sigma out), 1e-5 for an ordinary one.  Round 6: the oracle widens its margin PER PIXEL by that (``near_u_ulps``, two ulps
-# of the image width) on top of the default flat 1e-4, and the comparisons run with the default near_frac (0.02) and NO
-# outliers.  (A tau < 1e-4 stop cannot flip in these comparisons: the oracle's backward pass starts from the device's own
-# contrib / final_tau.)
-LIKE_MARGIN = 3e-5           # flat part: the rounding of alpha' itself (the centre's resolution is the per-pixel part below)
-LIKE_U_ULPS = 1.0             # float32 ulps of the centre's larger coordinate (1.2e-4 px at x ~ 1920)
-LIKE_NEAR_FRAC = 0.02
+# sigma out), 1e-5 for an ordinary one.  Round 6: the oracle widens its margin PER PIXEL by that (``near_u_ulps``: ulps of
+# the centre) on top of its default flat 1e-4, and the comparisons run with NO outliers.  (A tau < 1e-4 stop cannot flip
+# in these comparisons: the oracle's backward pass starts from the device's own contrib / final_tau.)
+LIKE_MARGIN = 1e-4           # the oracle's default flat margin
+LIKE_U_ULPS = 2.0            # float32 ulps of the centre's larger coordinate (2.4e-4 px at x ~ 1920)
+# How many rows that flags is a property of the margin (every Gaussian's footprint boundary crosses dozens of pixels:
+# the share with SOME pixel inside the margin grows with it), measured over all tiles of view 0: flat 3e-4 (round 5)
+# 2.3 % with 13 outliers left; 1e-4 + 2 ulps 3.4 % and NO outlier; 1e-4 + 1 ulp 2.1 %, 3e-5 + 1 ulp 1.6 % with 14
+# outliers again (worst 8e-3).  The setting without outliers is the one that names the flips; its count is bounded here.
+LIKE_NEAR_FRAC = 0.04
 
 
 def record_grad_error(name, got, ref, near=None):
@@ -306,11 +309,18 @@ def _splat_and_check(gsc, sc, policy="gsplatcu", opol=O.POLICY_G, with_backward=
     d_before = host(g["depths"]).copy(); a_before = host(g["areas"]).copy()
     # three calls: the first of a problem size reads P back before the draw stage, the later ones enqueue the draw
     # stage ahead of the read (capacity learnt from the first).  Every output must be the same, bit for bit.
+    # (On ONE of the two exact draw paths: which one a call takes follows the walks earlier calls of the problem size
+    # reported, a render or two late -- tests/test_gpu_segments.py compares the paths with each other.)
+    from easygaussiansplatting_amd import fused as _fused_mod
+    keep_seg, _fused_mod.SEGMENTS = _fused_mod.SEGMENTS, "0"
     outs = []
-    for rep in range(3):
-        d_in, a_in = dev(d_before), torch.from_numpy(a_before).cuda()
-        o = gsc.splat(cam.height, cam.width, g["us"], g["cinv2ds"], g["alphas"], d_in, g["colors"], a_in)
-        outs.append([host(x) for x in o] + [host(d_in), host(a_in)])
+    try:
+        for rep in range(3):
+            d_in, a_in = dev(d_before), torch.from_numpy(a_before).cuda()
+            o = gsc.splat(cam.height, cam.width, g["us"], g["cinv2ds"], g["alphas"], d_in, g["colors"], a_in)
+            outs.append([host(x) for x in o] + [host(d_in), host(a_in)])
+    finally:
+        _fused_mod.SEGMENTS = keep_seg
     for later in outs[1:]:
         for x, y in zip(outs[0], later):
             assert np.array_equal(x.view(np.uint8), y.view(np.uint8))
@@ -1105,14 +1115,54 @@ def test_full_size_every_gaussian_every_tile_gradients(gsc, big):
     o_us, o_ci, o_col, o_depths, J = _oracle_2d(sc, cam, None, True, np.float32)
     o = draw_backward_tiles(W, H, host(st.ranges), host(st.gaussian_ids()), o_us, o_ci, sc.alphas.astype(np.float64), o_col,
                             host(st.contrib), host(st.final_tau), dl.astype(np.float64), near_margin=LIKE_MARGIN,
-                            near_u_ulps=LIKE_U_ULPS)
+                            near_u_ulps=LIKE_U_ULPS, behind=True)
     og = O.chain_rule(o[0], o[1], o[2], o[3], cam.Rcw, J)
     want = dict(pws=og["dpws"], shs=og["dshs"], alphas=og["dalphas"][:, None], scales=og["dscales"], rots=og["drots"],
                 us=o[0])
     got = {k: host(v.grad) for k, v in P.items()} | {"us": host(us0.grad)}
     for k in want:
-        r = assert_grad_close_flips(got[k], want[k], o[4], "all_tiles_fused_f32_stages:" + k, near_frac=LIKE_NEAR_FRAC)
+        if k != "shs":
+            r = assert_grad_close_flips(got[k], want[k], o[4], "all_tiles_fused_f32_stages:" + k, near_frac=LIKE_NEAR_FRAC)
+            assert r["n_big"] > 20000, (k, r)
+            continue
+        # dL/dsh[g, 3 c + rgb] = dL/dcolour[g, rgb] * basis_c: 47.5 M entries, and a handful of the large ones differ by
+        # more than 5e-3 under EVERY flip margin (14 -- one colour channel of four Gaussians -- at flat 3e-4, at 1e-4 + 1
+        # ulp and at 1e-4 + 2 ulps alike; their own 2D Gaussians equal numpy's to 5e-7, no pixel of theirs is within 3e-4
+        # of the threshold, no block mask misses a block: tools/lab/outlier_rows.py).  They are not the Gaussians that
+        # flip but Gaussians IN FRONT of one: the backward pass recovers tau from the END of the walk, so an entry on the
+        # alpha' >= 0.002 threshold that one side divides out and the other skips moves tau by 0.2 % for everything in
+        # front of it at that pixel -- nothing for most, 0.5-0.8 % for a Gaussian whose pixel terms cancel
+        # (sum |t| / |sum t| = 11 .. 110 for the four).  The oracle measures exactly that (``behind_out``: sum |t| over
+        # the pixels with a near-threshold entry behind the Gaussian): every entry beyond the relative rule must lie within
+        # alpha_skip of it, plus the float32 accumulation bound (``abs_out``) -- counted, named, explained; none is merely
+        # tolerated.
+        r = assert_grad_close_flips(got[k], want[k], o[4], "all_tiles_fused_f32_stages:" + k, near_frac=LIKE_NEAR_FRAC,
+                                    outliers=64)
         assert r["n_big"] > 20000, (k, r)
+        big = np.abs(want[k]) >= 1e-2 * np.abs(want[k]).max()
+        err = np.abs(got[k] - want[k])
+        out = big & ~o[4][:, None] & (err > 5e-3 * np.abs(want[k]))
+        rows, cols = np.nonzero(out)
+        dcol, cabs, cbeh = o[3], o[5], o[6]
+        with np.errstate(all="ignore"):
+            basis = np.abs(want[k][rows, cols] / dcol[rows, cols % 3])          # |basis_c| of that Gaussian
+        bound = (1.5 * 0.002 * cbeh[rows, cols % 3] + 64 * 2.0 ** -24 * cabs[rows, cols % 3]) * basis
+        cancel = cabs[rows, cols % 3] / np.maximum(np.abs(dcol[rows, cols % 3]), 1e-300)
+        bad = err[rows, cols] > bound
+        import json, os
+        if os.environ.get("EGS_GRAD_STATS"):
+            with open(os.environ["EGS_GRAD_STATS"], "a") as f:
+                f.write(json.dumps(dict(name="all_tiles_fused_f32_stages:shs:outlier_rows", rows=rows.tolist(), cols=cols.tolist(),
+                                        err_over_bound=(err[rows, cols] / bound).tolist(), cancel=cancel.tolist(),
+                                        rel_err=(err[rows, cols] / np.abs(want[k][rows, cols])).tolist(),
+                                        alpha=sc.alphas[rows].tolist(), near=o[4][rows].tolist(),
+                                        dcolor=dcol[rows].tolist(), dcolor_abs=cabs[rows].tolist(), dcolor_behind=cbeh[rows].tolist(),
+                                        scales=sc.scales[rows].tolist())) + "\n")
+        assert not bad.any(), ("unexplained dL/dsh outliers", rows[bad][:8], "err / bound", (err[rows, cols] / bound)[bad][:8],
+                               "sum|t| / |sum t|", cancel[bad][:8], "rel err", (err[rows, cols] / np.abs(want[k][rows, cols]))[bad][:8],
+                               "alpha", sc.alphas[rows[bad][:8]], "near", o[4][rows[bad][:8]])
+        record_grad_error("all_tiles_fused_f32_stages:shs:cancelling_rows(%d entries, %d Gaussians, sum|t|/|sum t| >= %.0f)"
+                          % (rows.size, np.unique(rows).size, cancel.min() if rows.size else 0), got[k][rows], want[k][rows])
 
 
 def test_depth_key_bit_hint_protocol(gsc):
