@@ -32,7 +32,7 @@ $T rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d /tmp/s1 -- python $
 $T rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d /tmp/s2 -- python $R/tools/profile_step.py --steps 3 > /tmp/s2.log 2>&1
 python $R/tools/pmc_summary.py $(dirname $(find /tmp/s1 -name "*counter_collection.csv" | head -1)) $(dirname $(find /tmp/s2 -name "*counter_collection.csv" | head -1)) --all > $O/sq_counters.txt
 cp /tmp/pmc_summary.json $O/sq_counters.json
-cd $R && python tools/make_pmc_traffic.py $O/pmc_fetch_write.json $O/sq_counters.json - $O/pmc_traffic.json profiles/r5_valu_mix.json
+cd $R && python tools/make_pmc_traffic.py $O/pmc_fetch_write.json $O/sq_counters.json - $O/pmc_traffic.json profiles/r6_valu_mix.json
 tail -1 $O/bench.json | cut -c1-300
 tail -1 $O/bench_20_5.json | cut -c1-200
 head -14 $O/kernel_stats.csv | cut -c1-160

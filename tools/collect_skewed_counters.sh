@@ -18,7 +18,7 @@ $T rocprofv3 --kernel-trace --pmc $C1 --output-format csv -d /tmp/q3 -- $P > /tm
 $T rocprofv3 --kernel-trace --pmc $C2 --output-format csv -d /tmp/q4 -- $P > /tmp/q4.log 2>&1
 python $R/tools/pmc_summary.py $(dirname $(find /tmp/q3 -name "*counter_collection.csv" | head -1)) $(dirname $(find /tmp/q4 -name "*counter_collection.csv" | head -1)) --all > $O/sq_counters.txt
 cp /tmp/pmc_summary.json $O/sq_counters.json
-cd $R && python tools/make_pmc_traffic.py $O/pmc_fetch_write.json $O/sq_counters.json - $O/pmc_traffic.json profiles/r5_valu_mix.json skewed_reset
+cd $R && python tools/make_pmc_traffic.py $O/pmc_fetch_write.json $O/sq_counters.json - $O/pmc_traffic.json profiles/r6_valu_mix.json skewed_reset
 python - <<PY
 import json
 d=json.load(open("$O/pmc_traffic.json"))["kernels"]
