@@ -8,6 +8,8 @@ R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/prof; mkdir -p $O
 export PYTHONDONTWRITEBYTECODE=1
 T="timeout 240"
+# ONLY_COUNTERS=1: just the counter passes at the end (pmc_traffic.json), e.g. after tools/profile_step.py changed
+if [ -z "$ONLY_COUNTERS" ]; then
 # the default bench line (CPU baseline, seven-op figure, eight ring views, the two skewed scenes) and the driver's flags
 $T python $R/bench.py > $O/bench.json 2> $O/bench.err
 $T python $R/bench.py --steps 20 --warmup 5 --cpu-sample 0 > $O/bench_20_5.json 2>> $O/bench.err
@@ -21,6 +23,7 @@ EGS_SEGMENTS=0 $T python $R/bench.py --scene skewed_reset --steps 10 --cpu-sampl
 # one step as a timeline (no event brackets), after 150+ steps: steady-state clocks
 $T rocprofv3 --kernel-trace --output-format csv -d /tmp/tr -- python $R/tools/profile_step.py --steps 160 > /tmp/tr.log 2>&1
 python $R/tools/trace_timeline.py /tmp/tr > $O/step_timeline.txt
+fi
 # HBM traffic counters (separate passes, no tracing besides kernel-trace) and SQ counters of the fused step
 $T rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/p1 -- python $R/tools/profile_step.py --steps 3 > /tmp/p1.log 2>&1
 $T rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d /tmp/p2 -- python $R/tools/profile_step.py --steps 3 > /tmp/p2.log 2>&1

@@ -12,6 +12,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--steps", type=int, default=3)
+ap.add_argument("--warm", type=int, default=3,
+                help="steps in front, each waited for: the draw stage's path selection (fused._seg_decision) steers by what "
+                     "EARLIER renders reported, and a render's report reaches the host with the next render's binning "
+                     "stage -- without them a 3-step counter pass measures the first-sight path (round 6: the segment "
+                     "kernels on the bench scene), not the steady state")
 ap.add_argument("--gaussians", type=int, default=1_000_000)
 ap.add_argument("--width", type=int, default=1920)
 ap.add_argument("--height", type=int, default=1080)
@@ -48,7 +53,9 @@ if a.train:
     raw = raw_params_from_scene(sc, dev)
     opt = FusedAdam(adam_groups(raw), eps=1e-15)
     gt = torch.rand((3, a.height, a.width), device=dev)
-for _ in range(a.steps):
+for it in range(a.warm + a.steps):
+    if 0 < it <= a.warm:
+        torch.cuda.synchronize()
     if a.train:
         # what Trainer.step does for one view: deferred validation, the SH gradient factored and consumed by FusedAdam
         from easygaussiansplatting_amd import dist_views as DV, fused
