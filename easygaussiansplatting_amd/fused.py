@@ -388,7 +388,11 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     # SH coefficients (36 B written + read instead of a 4K-byte row re-read; EGS_SAVE_DCOLOR=0: A/B knob)
     S.dcw = torch.empty((n, 9), dtype=f32, device=dev) if (need_grad and n > 0 and SAVE_DCOLOR) else None
 
-    def draw_exact(patches):
+    def draw_exact(patches, redo=False):
+        # ``redo``: the draw stage of this render ran once already on truncated lists (more patches than the enqueue-ahead
+        # buffers held).  Its range kernel has published the PREVIOUS render's hint words; what that truncated draw
+        # raised in the walk word is nobody's longest walk: the second range kernel clears it without publishing
+        # (hint address withheld) -- otherwise a later render steers by (1189, 696) where the render walked (2063, 696)
         S.gsid = torch.empty(patches, dtype=i32, device=dev)
         ws_draw = torch.empty(lib.egs_splat_draw_ws_bytes(n, patches, W, H), dtype=torch.uint8, device=dev)
         if use_seg:
@@ -398,7 +402,8 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
                                               ws_draw.numel(), _ptr(image), _ptr(S.contrib), _ptr(S.final_tau),
                                               _ptr(S.ranges), _ptr(S.gsid), _ptr(S.order), _ptr(S.gpack), prev_work,
                                               order_ready, draw_flags, _ptr(S.seg),
-                                              S.seg.numel() if S.seg is not None else 0, seg_hint, _ptr(walk_word), None, st))
+                                              S.seg.numel() if S.seg is not None else 0,
+                                              None if (redo and walk_word is not None) else seg_hint, _ptr(walk_word), None, st))
 
     if raw:
         enqueue_bin = lambda hint, total: _lib.check(lib.egs_fused_forward_raw(
@@ -473,10 +478,10 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
     # scene's recent renders walk most of theirs -- the renders right after reset_alpha, gsmodel.py:320-324)
     cap = ctx.capacity.get(key, 0) if ENQUEUE_AHEAD else 0
 
-    def render_exact():
+    def render_exact(redo=False):
         """Synchronous form: read P back (8 bytes, as the reference does at gausplat.cu:67), then draw."""
         patches = _bin_stage(enqueue_bin, dev, key)
-        draw_exact(patches)
+        draw_exact(patches, redo)
         remember_order()
         S._patches = patches
         if n > 0:
@@ -554,9 +559,9 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         if t.patches >= 2**31:
             raise RuntimeError("splat: %d tile patches overflow int32 indexing" % t.patches)
         if t.hint < 32 and t.need > t.hint:           # stale depth-key hint: everything again
-            render_exact()
+            render_exact(redo=True)
         else:                                         # more patches than ever before: redo the draw stage
-            draw_exact(t.patches)
+            draw_exact(t.patches, redo=True)
     return image, mask, S
 
 

@@ -523,7 +523,8 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
             _lib.check(lib.egs_splat_bin(n, width, height, _ptr(us), _ptr(areas), _ptr(depths), pol, hint,
                                          _ptr(ws_bin), ws_bin_bytes, _ptr(total), st))
 
-    def draw_exact(patches):
+    def draw_exact(patches, redo=False):
+        # (``redo``: see fused.forward -- the second range kernel of a render clears the walk word without publishing it)
         gsid = torch.empty(patches, dtype=torch.int32, device=dev)
         walked = torch.empty(patches, dtype=torch.int32, device=dev) if masks else gsid
         ws_draw_bytes = lib.egs_splat_draw_ws_bytes(n, patches, width, height)
@@ -535,16 +536,17 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
                                               _ptr(ws_draw), ws_draw_bytes, _ptr(image), _ptr(contrib), _ptr(final_tau),
                                               _ptr(ranges), _ptr(walked), _ptr(order), _ptr(gpack), None, 0,
                                               flags | seg_flags, _ptr(seg_ws[0]),
-                                              seg_ws[0].numel() if use_seg else 0, seg_hint, _ptr(walk_word),
+                                              seg_ws[0].numel() if use_seg else 0,
+                                              None if (redo and walk_word is not None) else seg_hint, _ptr(walk_word),
                                               _ptr(gsid) if masks else None, st))
         if masks:
             lists[0] = walked
         return gsid
 
-    def render_exact():
+    def render_exact(redo=False):
         """The reference's sequence (gausplat.cu:50-105): bin, read P back, draw -- the GPU idles around the read."""
         patches = _bin_stage(enqueue_bin, dev, key)
-        return patches, draw_exact(patches)
+        return patches, draw_exact(patches, redo)
 
     # From the second call of a problem size on, the draw stage is enqueued BEHIND the binning stage before the
     # host has seen P: buffers sized by the largest count met so far (+6 %), the count taken from device memory,
@@ -600,9 +602,9 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         if t.patches >= 2**31:
             raise RuntimeError("splat: %d tile patches overflow int32 indexing" % t.patches)
         if t.hint < 32 and t.need > t.hint:  # stale depth-key hint: everything again (the stage is idempotent)
-            gsid = render_exact()[1]
+            gsid = render_exact(redo=True)[1]
         else:
-            gsid = draw_exact(t.patches)     # more patches than ever before
+            gsid = draw_exact(t.patches, redo=True)     # more patches than ever before
         return [image, contrib, final_tau, ranges, gsid], records(gsid)
     gsid = gsid_full[:t.patches]
     if masks:

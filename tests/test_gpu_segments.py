@@ -344,3 +344,72 @@ def test_segment_end_states_equal_the_oracles(fx, reset, spec):
     # (a pixel whose alpha' sits at the skip threshold, or whose tau crosses the stop one entry apart, differs in a
     # whole state: counted, as everywhere in the suite)
     assert n_bad <= 2e-3 * n_cmp, (n_bad, n_cmp, worst)
+
+
+def test_hint_words_are_a_completed_renders_pair_and_steer_the_path(fx):
+    """What the host steers the path by (fused._seg_decision): {longest list, longest walk} of ONE completed render,
+    published to the page-locked slot by the NEXT render's range kernel (csrc/egs_bin.hip k_tile_ranges; round 6 found the
+    earlier forms -- running maxima, words from two different cameras -- flipping the path mid-epoch).  Two cameras of
+    very different walks alternate; after every render the slot must hold exactly the previous render's pair, computed
+    here from that render's own ``ranges`` / ``contrib``; long walks select the segment kernels, short ones the unsplit
+    kernels, a problem size nothing is known about the segment kernels; ``expect_long_walks`` overrides a short record."""
+    fused, lib = fx
+    from easygaussiansplatting_amd import _lib
+    from easygaussiansplatting_amd.function import Camera
+    W, H = 320, 240
+    sc = S.small_scene(60_011, W, H, 3, seed=7)          # (a size of its own: no other test has left a hint for it)
+    sc.scales[:] = sc.scales * 2.2
+    lo = np.minimum(sc.alphas, 0.01).astype(np.float32)   # nothing saturates: every tile walks its whole list
+    hi = sc.alphas.astype(np.float32)                     # opaque: a few hundred entries, then the tau stop
+    cam_a = Camera.from_scene(sc.cam)
+    cam_b = Camera.from_scene(S.ring_cameras(sc.cam, 8)[3])
+    key = (sc.n, W, H)
+    d = torch.device("cuda", torch.cuda.current_device())
+    P = [dev(sc.pws), dev(sc.shs), None, dev(sc.scales), dev(sc.rots)]
+
+    def render(alphas, cam):
+        P[2] = dev(alphas).reshape(-1, 1)
+        with torch.no_grad():
+            _, _, st = fused.forward(*P, cam, need_grad=False)
+        torch.cuda.synchronize()
+        rg, ct = host(st.ranges), host(st.contrib)
+        return (int((rg[:, 1] - rg[:, 0]).max()), int(ct.max())), st.seg is not None
+
+    # the split threshold between the two regimes' walks, measured on a copy of the scene with one Gaussian less (a
+    # problem size of its own: the size under test stays unknown to the host)
+    keep_n = [t[:-1].contiguous() for t in (P[0], P[1], P[3], P[4])]
+    Pn = P
+    P = [keep_n[0], keep_n[1], None, keep_n[2], keep_n[3]]
+    fused.SEGMENTS = "0"
+    lo, hi = lo[:-1], hi[:-1]
+    w_lo = min(render(lo, cam_a)[0][1], render(lo, cam_b)[0][1])
+    w_hi = max(render(hi, cam_a)[0][1], render(hi, cam_b)[0][1])
+    assert w_hi + 64 < w_lo, (w_hi, w_lo)
+    split = (w_hi + w_lo) // 2
+    P = Pn
+    lo = np.minimum(sc.alphas, 0.01).astype(np.float32)
+    hi = sc.alphas.astype(np.float32)
+    fused.SEGMENTS = "auto"
+    _lib.check(lib.egs_seg_config(64, split, None))
+    assert fused.seg_hint(d, key) is None
+    pair0, seg0 = render(lo, cam_a)
+    assert seg0                                           # nothing known about this size: the segment kernels
+    assert pair0[1] > split
+    seen = [pair0]
+    path = []
+    for alphas, cam in ((hi, cam_b), (hi, cam_a), (lo, cam_b), (lo, cam_a), (hi, cam_b), (hi, cam_b), (hi, cam_b)):
+        pair, seg = render(alphas, cam)
+        # published by THIS render's range kernel: the previous render's words, both of them, nothing of this one's
+        assert fused.seg_hint(d, key) == seen[-1], (fused.seg_hint(d, key), seen)
+        seen.append(pair)
+        path.append(seg)
+    assert max(p[1] for p in seen[1:3]) < split < min(p[1] for p in seen[3:5]), seen     # (the scene does what it is for)
+    # a render decides by what was on record when it was enqueued = the render before the previous one:
+    #   render 1 (hi) sees nothing published yet -> unknown -> segments; render 2 sees render 0 (long) -> segments;
+    #   render 3 sees render 1 (short) -> unsplit; 4 sees 2 (short) -> unsplit; 5 sees 3 (long) -> segments;
+    #   6 sees 4 (long) -> segments; 7 sees 5 (short) -> unsplit
+    assert path == [True, True, False, False, True, True, False], (path, seen)
+    # the caller that KNOWS (DensityControl.reset_alpha): the next renders take the segment kernels whatever is on record
+    assert fused.seg_hint(d, key)[1] < split
+    fused.expect_long_walks(d, renders=2)
+    assert render(lo, cam_a)[1] and render(lo, cam_a)[1]
