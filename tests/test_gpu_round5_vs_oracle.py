@@ -20,7 +20,7 @@ import pytest
 
 from easygaussiansplatting_amd import scene as S
 from oracle import gs_oracle as O
-from tests.gradcheck import assert_grad_close_flips
+from tests.gradcheck import assert_grad_close, assert_grad_close_flips
 from tests.test_gpu_parity import (_oracle_2d, check_culled_lists, complete_inside, dev, host, window_tiles)
 
 pytestmark = pytest.mark.gpu
@@ -93,6 +93,22 @@ def test_skewed_reset_splatB_gradients_vs_oracle(fx, reset_scene, how):
         info = gsc.last_splatB_info()
         assert info["segments"] == (how != "unsplit"), info
         assert info["rebuilt"] == (how == "public"), info        # public: rebuilt; public_kept: the forward's states
+        if how == "public_kept":
+            assert info["kept_states"], info
+            # the kept states survive a backward pass (it reads them): the same call again finds them and gives the same
+            # gradients (float atomics in another order: 1e-6 of the maximum)
+            again = gsc.splatB(H, W, g["us"], g["cinv"], g["alphas"], d, g["col"], contrib, tau, ranges, gsid, dev(dl))
+            assert gsc.last_splatB_info()["kept_states"]
+            for x, y in zip(grads, again):
+                assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())
+            # an in-place write to one of the four tensors (a new version, whatever the values) and the states are
+            # nobody's: rebuilt from ``contrib``, same gradients
+            contrib.add_(0)
+            rebuilt = gsc.splatB(H, W, g["us"], g["cinv"], g["alphas"], d, g["col"], contrib, tau, ranges, gsid, dev(dl))
+            info2 = gsc.last_splatB_info()
+            assert info2["rebuilt"] and not info2["kept_states"], info2
+            for x, y, nm in zip(grads, rebuilt, ("dus", "dcinv", "dalpha", "dcolor")):
+                assert_grad_close(host(y), host(x), "kept_vs_rebuilt:" + nm)
     finally:
         gsc.set_pair_states(keep_states)
     rg, gs = host(ranges), host(gsid)
