@@ -413,3 +413,62 @@ def test_hint_words_are_a_completed_renders_pair_and_steer_the_path(fx):
     assert fused.seg_hint(d, key)[1] < split
     fused.expect_long_walks(d, renders=2)
     assert render(lo, cam_a)[1] and render(lo, cam_a)[1]
+
+
+def test_segment_path_on_several_streams_equals_one_stream(fx):
+    """Four ring views of ``scene.skewed_scene`` right after ``reset_alpha`` (the segment kernels, their per-(size,
+    stream) walk words, one hint slot shared by all lanes, a segment workspace per view in flight) as ONE step on three
+    HIP streams with deferred validation (``dist_views.ViewStreams``: what ``bench.py --views-per-rank`` and a trainer
+    with several views per step run) against the same views one after the other on one stream: same gradient sums
+    (float atomics in another order), for three steps in a row (first sight, then with the walks on record)."""
+    fused, lib = fx
+    from easygaussiansplatting_amd import dist_views as DV
+    from easygaussiansplatting_amd.function import Camera, GSFunction
+    GSFunction.mode = "fused"
+    sc = S.skewed_scene(reset_alpha=True)
+    W, H = sc.cam.width, sc.cam.height
+    V = 4
+    cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 8)[:V]]
+    dls = [dev(S.normal(5, 30 + v, (3, H, W)).astype(np.float32) / (3 * H * W)) for v in range(V)]
+    names = ("pws", "shs", "alphas", "scales", "rots")
+    P = dict(pws=dev(sc.pws), shs=dev(sc.shs), alphas=dev(sc.alphas).reshape(-1, 1), scales=dev(sc.scales), rots=dev(sc.rots))
+    fused.SEGMENTS = "auto"
+    fused.expect_long_walks(torch.device("cuda", torch.cuda.current_device()), renders=2 * V)
+    # one stream, one view after the other, autograd accumulates
+    leaves = [P[k].detach().requires_grad_(True) for k in names]
+    us0 = torch.zeros((sc.n, 2), device="cuda", requires_grad=True)
+    took_segments = 0
+    for v in range(V):
+        image, _ = GSFunction.apply(*leaves, us0, cams[v])
+        image.backward(dls[v])
+    torch.cuda.synchronize()
+    ref = [t.grad.clone() for t in leaves]
+    assert all(torch.isfinite(r).all() for r in ref)
+    # three streams
+    vleaves = [P[k].detach().requires_grad_(True) for k in names]
+    vs = DV.ViewStreams(vleaves, 3)
+    uss = [torch.zeros((sc.n, 2), device="cuda", requires_grad=True) for _ in range(3)]
+    for rep in range(3):
+        for t in vleaves:
+            t.grad = None
+        with torch.no_grad(), fused.deferred() as d0:      # which path the views of this step take (forward only)
+            st = fused.forward(*[t.detach() for t in vleaves], cams[rep % V])[2]
+            d0.commit()
+        took_segments += int(st.seg is not None)
+        redo = True
+        while redo:
+            for t in vleaves:
+                t.grad = None
+            with fused.deferred() as d:
+                vs.begin()
+                with fused.accumulate_in_kernel():
+                    for v in range(V):
+                        with vs.lane(v) as lv:
+                            image, _ = GSFunction.apply(*lv, uss[vs.lane_index(v)], cams[v])
+                            image.backward(dls[v])
+                vs.finish()
+                redo = bool(d.commit())                      # (a view outgrew the enqueue-ahead buffers: the step again)
+        torch.cuda.synchronize()
+        for k, t, r in zip(names, vleaves, ref):
+            assert float((t.grad - r).abs().max()) <= 2e-5 * float(r.abs().max()), (rep, k)
+    assert took_segments == 3
