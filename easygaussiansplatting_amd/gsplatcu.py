@@ -294,18 +294,23 @@ def _alphas(alphas, n):
 #     ``SplatRecords`` and ``splatB(..., records=handle)`` takes it back -- this package's GSFunction (mode "ops") does
 #     that with its own intermediates (us / cinv2ds / colors never leave the autograd node) and skips both the re-pack
 #     and the validation (21 + 10 us); the handle is checked by (data_ptr, _version, shape), policy, size and stream.
-#   * round 6, long lists only: when the public ``splat`` split its long tile lists over waves it keeps that
-#     draw's SEGMENT-END STATES (G_s, T_end per segment and pixel: ~6 KB per 256 entries of a split tile) with strong
-#     references to the four tensors it RETURNED -- contrib, final_tau, patch_range_per_tile, gsid_per_patch -- one entry
-#     per (device, stream), replaced by the next ``splat`` there.  A ``splatB`` that is handed exactly those four tensors
-#     (same memory -- they cannot have been freed --, same in-place version) and the same inputs (data_ptr, version)
-#     walks its segments from the kept states; anything else rebuilds them from ``contrib`` first (a forward draw's
-#     worth of work: 2.7 instead of 2.2 ms per step on scene.skewed_scene(reset_alpha=True)).  ``set_pair_states(False)``
-#     keeps nothing.  Scenes whose walks stay below the split threshold never create an entry.
+#   * round 6, long lists only, OPT-IN (``set_pair_states(True)``): when the public ``splat`` split its long tile lists
+#     over waves it keeps that draw's SEGMENT-END STATES (G_s, T_end per segment and pixel: ~6 KB per 256
+#     entries of a split tile) with strong references to the four tensors it RETURNED -- contrib, final_tau,
+#     patch_range_per_tile, gsid_per_patch -- one entry per (device, stream), replaced by the next ``splat`` there.  A
+#     ``splatB`` that is handed exactly those four tensors (same memory -- they cannot have been freed --, same in-place
+#     version) and the same inputs (data_ptr, version) walks its segments from the kept states; anything else rebuilds
+#     them from ``contrib`` first (the default: a forward draw's worth of work, 2.69 against 2.65 ms per step on
+#     scene.skewed_scene(reset_alpha=True)).  Opt-in for the same reason as the memo above, and one more: the states are
+#     matched by (data_ptr, version), the contract of the records handle -- a write through ``tensor.data`` between the
+#     two calls goes unseen and the states of the OLD values would be differentiated (the forced-segments sweep of the
+#     suite found exactly that in tests/test_gpu_memo.py's ``data_write`` case; the default path recomputes everything
+#     from the values it is handed, as the reference's drawB does).  Scenes whose walks stay below the split threshold
+#     never create an entry.
 _memo_enabled = False
 _splat_memo = {}        # (device, stream) -> SplatRecords, in order of last use
 MEMO_MAX = 8
-_pair_states_enabled = True
+_pair_states_enabled = False
 _pair_states = {}       # (device, stream) -> dict(outs, sig, in_sig, seg, lists, width, height, policy)
 _last_splatB = {"segments": False, "rebuilt": False, "kept_states": False}
 _pair_tls = threading.local()   # hands the segment workspace of a _splat call to the public splat() around it
@@ -334,8 +339,9 @@ def set_memo(on: bool) -> None:
 
 
 def set_pair_states(on: bool) -> bool:
-    """Keep the segment-end states of a public ``splat`` for the ``splatB`` of the tensors it returned (default: on; only
-    scenes with long tile lists ever hold any).  -> the previous setting."""
+    """Keep the segment-end states of a public ``splat`` for the ``splatB`` of the tensors it returned (default: OFF; only
+    scenes with long tile lists ever hold any; matched by data_ptr and in-place version -- for callers that do not write
+    through ``tensor.data`` between the two calls).  -> the previous setting."""
     global _pair_states_enabled
     prev, _pair_states_enabled = _pair_states_enabled, bool(on)
     if not on:

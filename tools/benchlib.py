@@ -401,6 +401,23 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None, train=False):
             once(o)
         torch.cuda.synchronize()
         out[key] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
+    if out["segment_path"]:     # the public pair with the forward's segment states kept for splatB (opt-in, gsplatcu.set_pair_states)
+        from easygaussiansplatting_amd import gsplatcu as _gsc
+        prev = _gsc.set_pair_states(True)
+        try:
+            o = RenderOptions(mode="ops", ops_use_records=False)
+            for _ in range(4):
+                once(o)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(8):
+                once(o)
+            torch.cuda.synchronize()
+            out["ops_public_pair_kept_states_ms_per_step"] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
+            out["ops_public_pair_kept_states_used"] = bool(_gsc.last_splatB_info().get("kept_states"))
+        finally:
+            _gsc.set_pair_states(prev)
+            _gsc.clear_memo()
     if iid_ref:
         r = out["pixel_gaussian_pairs"] / iid_ref["pairs"]
         out["pairs_ratio_to_iid"] = round(r, 3)
