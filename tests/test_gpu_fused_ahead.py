@@ -110,7 +110,7 @@ def test_deferred_backward_equals_immediate():
     from easygaussiansplatting_amd import fused
     from easygaussiansplatting_amd.function import GSFunction
     args, cam = _scene(5000, 160, 96, 9)
-    dl = torch.randn((3, 96, 160), device="cuda") / (3 * 96 * 160)
+    dl = torch.randn((3, 96, 160), device="cuda", generator=torch.Generator(device="cuda").manual_seed(21)) / (3 * 96 * 160)
 
     def grads(deferred):
         ps = [a.clone().requires_grad_(True) for a in args]
@@ -142,7 +142,7 @@ def test_second_backward_with_retain_graph():
     ps[2] = ps[2].detach().reshape(-1, 1).clone().requires_grad_(True)
     us = torch.zeros((3000, 2), device="cuda", requires_grad=True)
     img, _ = GSFunction.apply(ps[0], ps[1], ps[2], ps[3], ps[4], us, cam)
-    dl = torch.randn_like(img) / img.numel()
+    dl = torch.randn(img.shape, device="cuda", generator=torch.Generator(device="cuda").manual_seed(22)) / img.numel()
     img.backward(dl, retain_graph=True)
     g1 = ps[0].grad.clone()
     ps[0].grad = None
@@ -243,7 +243,7 @@ def test_backward_in_the_forward_dispatch_order(monkeypatch):
     from easygaussiansplatting_amd import fused
     from easygaussiansplatting_amd.function import GSFunction
     args, cam = _scene(20000, 640, 368, 13)
-    dl = torch.randn((3, 368, 640), device="cuda") / (3 * 368 * 640)
+    dl = torch.randn((3, 368, 640), device="cuda", generator=torch.Generator(device="cuda").manual_seed(23)) / (3 * 368 * 640)
 
     def grads():
         ps = [a.clone().requires_grad_(True) for a in args]
