@@ -79,3 +79,31 @@ def test_uhd_lists_image_and_gradients_vs_oracle():
     want = host(grads[3]).reshape(-1, 3) * 0.28209479177387814
     assert np.abs(sh0 - want).max() < 2e-4 * np.abs(want).max()
     assert all(torch.isfinite(p.grad).all() for p in P)
+
+
+def test_uhd_segment_path_equals_unsplit_kernels():
+    """The long-list split at 3840 x 2160 (32 400 tiles: beyond the dispatch-order kernel's table, 15 tile bits, 127 plan
+    workgroups): ``scene.skewed_scene`` right after ``reset_alpha`` through a camera of twice the focal length (lists to
+    ~8 300 entries, walks to ~4 400) -- segment path == unsplit kernels: lists, image, contributor counts, final
+    transmittance and all parameter gradients (tests/test_gpu_segments.py's comparison, default tolerance)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from easygaussiansplatting_amd import fused, gsplatcu as gsc
+    from easygaussiansplatting_amd.function import Camera
+    from tests.test_gpu_segments import compare, run
+    gsc.set_policy("gsplatcu")
+    W, H = 3840, 2160
+    sc = S.skewed_scene(reset_alpha=True)
+    sc.cam = S.Camera(W, H, 2 * sc.cam.fx, 2 * sc.cam.fy, W / 2.0, H / 2.0, sc.cam.Rcw, sc.cam.tcw)
+    dl = dev(S.normal(3, 22, (3, H, W)).astype(np.float32) / (3 * H * W))
+    keep = fused.SEGMENTS
+    try:
+        fused.SEGMENTS = "0"
+        ref = run(fused, sc, Camera.from_scene(sc.cam), dl)
+        fused.SEGMENTS = "auto"
+        got = run(fused, sc, Camera.from_scene(sc.cam), dl, 2)
+    finally:
+        fused.SEGMENTS = keep
+    lens = ref["ranges"][:, 1] - ref["ranges"][:, 0]
+    assert lens.size == 32400 and lens.max() > 5000 and ref["contrib"].max() > 3000 and got["seg"] and not ref["seg"]
+    compare(got, ref, "uhd_skewed_reset", flips=256)
