@@ -300,7 +300,7 @@ def _alphas(alphas, n):
 #     patch_range_per_tile, gsid_per_patch -- one entry per (device, stream), replaced by the next ``splat`` there.  A
 #     ``splatB`` that is handed exactly those four tensors (same memory -- they cannot have been freed --, same in-place
 #     version) and the same inputs (data_ptr, version) walks its segments from the kept states; anything else rebuilds
-#     them from ``contrib`` first (the default: a forward draw's worth of work, 2.69 against 2.65 ms per step on
+#     them from ``contrib`` first (the default: a forward draw's worth of work, 2.69 against 2.20 ms per step on
 #     scene.skewed_scene(reset_alpha=True)).  Opt-in for the same reason as the memo above, and one more: the states are
 #     matched by (data_ptr, version), the contract of the records handle -- a write through ``tensor.data`` between the
 #     two calls goes unseen and the states of the OLD values would be differentiated (the forced-segments sweep of the
@@ -425,7 +425,13 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
         kept = getattr(_pair_tls, "seg_of_last_call", None)
         _pair_tls.seg_of_last_call = None
         if kept is not None:
-            sig, in_sig = _memo_sig(out[1:5]), _memo_sig((us, cinv2ds, alphas, colors))
+            # (the inputs as splatB will see them: it normalises ``alphas`` [N,1] -> [N] before it forms its signature --
+            # through GSFunction, which hands both calls the [N,1] tensor, nothing ever matched before this line said so)
+            try:
+                in_sig = _memo_sig((us, cinv2ds, _alphas(alphas, us.shape[0]), colors))
+            except Exception:
+                in_sig = None
+            sig = _memo_sig(out[1:5])
             if sig is not None and in_sig is not None:
                 _pair_states[key] = dict(outs=tuple(out[1:5]), sig=sig, in_sig=in_sig, seg=kept[0], lists=kept[1],
                                          width=int(width), height=int(height), policy=_policy_name)

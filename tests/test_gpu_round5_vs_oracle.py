@@ -101,6 +101,13 @@ def test_skewed_reset_splatB_gradients_vs_oracle(fx, reset_scene, how):
             assert gsc.last_splatB_info()["kept_states"]
             for x, y in zip(grads, again):
                 assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())
+            # alphas as [N,1] -- what GSFunction hands both calls (gsmodel.py:36, 67): splatB normalises it to [N] before it
+            # forms its signature, and so must the entry (round 6: through GSFunction nothing ever matched)
+            a1 = g["alphas"].reshape(-1, 1)
+            d2, ar2 = g["depths"].clone(), g["areas"].clone()
+            o2 = gsc.splat(H, W, g["us"], g["cinv"], a1, d2, g["col"], ar2)
+            gsc.splatB(H, W, g["us"], g["cinv"], a1, d2, g["col"], o2[1], o2[2], o2[3], o2[4], dev(dl))
+            assert gsc.last_splatB_info()["kept_states"]
             # an in-place write to one of the four tensors (a new version, whatever the values) and the states are
             # nobody's: rebuilt from ``contrib``, same gradients
             contrib.add_(0)
