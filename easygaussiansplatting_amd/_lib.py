@@ -13,7 +13,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libegs_hip.so")
 CSRC = os.path.join(_HERE, "csrc")
-ABI_VERSION = 8
+ABI_VERSION = 9
 
 
 class EgsPolicy(C.Structure):
@@ -79,6 +79,7 @@ SIGNATURES = {
     "egs_sort_pairs": (_i, [_i64, _P, _P, _P, _P, _i, _i, _P, _sz, C.POINTER(C.c_int), _P]),
     "egs_scan_ws_bytes": (_sz, [_i64]),
     "egs_exclusive_scan_u32": (_i, [_i64, _P, _P, _P, _P, _P, _sz, _P]),
+    "egs_words_differ": (_i, [_P, _P, _i64, _P, _P]),
     "egs_chain_rule": (_i, [_i, _i] + [_P] * 16 + [_P]),
     "egs_fused_forward": (_i, [_i, _i] + [_P] * 8 + [_f] * 4 + [_i, _i, _PP] + [_P] * 8 + [_i, _i, _P, _sz, _P, _P, _P]),
     "egs_fused_forward_raw": (_i, [_i, _i] + [_P] * 9 + [_f] * 4 + [_i, _i, _PP] + [_P] * 8

@@ -4,6 +4,7 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
 #include <chrono>
 #include <map>
 #include <mutex>
@@ -122,6 +123,49 @@ extern "C" int egs_hbm_copy_probe(void* dst, const void* src, size_t bytes, void
   // MI355X_MICROARCH.md quotes 6.29 TB/s for its float4 copy)
   hipLaunchKernelGGL(egs::k_hbm_copy, dim3(256 * 4), dim3(256), 0, (hipStream_t)stream, (const egs::f4v*)src,
                      (egs::f4v*)dst, n4);
+  EGS_LAUNCH_OK();
+  return 0;
+}
+
+// ---- bitwise comparison of two device buffers (the public splat / splatB pair's content check, gsplatcu.py) -------------
+namespace egs {
+// flag |= 1 where a 32-bit word differs.  VEC: both buffers 16-B aligned (uint4 per lane and iteration, streaming loads:
+// each byte is read once); otherwise word by word.  One non-returning store per wave that saw a difference.
+typedef uint32_t uint4v __attribute__((ext_vector_type(4)));
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_words_differ(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                                                      size_t n, int32_t* __restrict__ flag) {
+  const size_t stride = (size_t)gridDim.x * 256;
+  uint32_t d = 0;
+  if (VEC) {
+    const uint4v* a4 = (const uint4v*)a;
+    const uint4v* b4 = (const uint4v*)b;
+    const size_t n4 = n / 4;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += stride) {
+      const uint4v x = __builtin_nontemporal_load(&a4[i]), y = __builtin_nontemporal_load(&b4[i]);
+      d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w);
+    }
+    const size_t t = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x;     // (the <= 3 words behind the last uint4)
+    if (t < n) d |= a[t] ^ b[t];
+  } else {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) d |= a[i] ^ b[i];
+  }
+  if (__any(d != 0) && (threadIdx.x & 63) == 0) *flag = 1;
+}
+}  // namespace egs
+
+extern "C" int egs_words_differ(const void* a, const void* b, int64_t n_words, int32_t* flag, void* stream) {
+  EGS_CHECK_ARG(flag && n_words >= 0 && (n_words == 0 || (a && b)) && ((((uintptr_t)a | (uintptr_t)b) & 3) == 0));
+  if (n_words == 0) return 0;
+  const bool vec = (((uintptr_t)a | (uintptr_t)b) & 15) == 0;
+  const size_t per = vec ? 4 * 256 : 256;
+  const int grid = (int)std::min<size_t>(256 * 8, ((size_t)n_words + per - 1) / per);
+  if (vec)
+    hipLaunchKernelGGL(egs::k_words_differ<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)a,
+                       (const uint32_t*)b, (size_t)n_words, flag);
+  else
+    hipLaunchKernelGGL(egs::k_words_differ<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, (const uint32_t*)a,
+                       (const uint32_t*)b, (size_t)n_words, flag);
   EGS_LAUNCH_OK();
   return 0;
 }

@@ -294,23 +294,29 @@ def _alphas(alphas, n):
 #     ``SplatRecords`` and ``splatB(..., records=handle)`` takes it back -- this package's GSFunction (mode "ops") does
 #     that with its own intermediates (us / cinv2ds / colors never leave the autograd node) and skips both the re-pack
 #     and the validation (21 + 10 us); the handle is checked by (data_ptr, _version, shape), policy, size and stream.
-#   * round 6, long lists only, OPT-IN (``set_pair_states(True)``): when the public ``splat`` split its long tile lists
-#     over waves it keeps that draw's SEGMENT-END STATES (G_s, T_end per segment and pixel: ~6 KB per 256
-#     entries of a split tile) with strong references to the four tensors it RETURNED -- contrib, final_tau,
-#     patch_range_per_tile, gsid_per_patch -- one entry per (device, stream), replaced by the next ``splat`` there.  A
-#     ``splatB`` that is handed exactly those four tensors (same memory -- they cannot have been freed --, same in-place
-#     version) and the same inputs (data_ptr, version) walks its segments from the kept states; anything else rebuilds
-#     them from ``contrib`` first (the default: a forward draw's worth of work, 2.69 against 2.20 ms per step on
-#     scene.skewed_scene(reset_alpha=True)).  Opt-in for the same reason as the memo above, and one more: the states are
-#     matched by (data_ptr, version), the contract of the records handle -- a write through ``tensor.data`` between the
-#     two calls goes unseen and the states of the OLD values would be differentiated (the forced-segments sweep of the
-#     suite found exactly that in tests/test_gpu_memo.py's ``data_write`` case; the default path recomputes everything
-#     from the values it is handed, as the reference's drawB does).  Scenes whose walks stay below the split threshold
-#     never create an entry.
+#   * round 6, long lists only: when the public ``splat`` split its long tile lists over waves it keeps that
+#     draw's SEGMENT-END STATES (G_s, T_end per segment and pixel: ~6 KB per 256 entries of a split tile), one entry per
+#     (device, stream), replaced by the next ``splat`` there -- without them ``splatB`` rebuilds them from ``contrib``
+#     first, a forward draw's worth of work (2.69 ms per step on scene.skewed_scene(reset_alpha=True)).  Three settings
+#     (``set_pair_states``):
+#       "content" (default)  the states AND one snapshot buffer of the eight tensors the pair shares (us, cinv2ds, alphas,
+#                 colors in; contrib, final_tau, patch_range_per_tile, gsid_per_patch out: 4 (9 N + 2 HW + 2 T + P) bytes,
+#                 112 MB on that scene).  ``splatB`` enqueues a bitwise comparison of what it was HANDED with the snapshot
+#                 (egs_words_differ: one pass), then the backward pass of the SNAPSHOT from the kept states -- self-
+#                 consistent whatever happened to the caller's tensors --, and only then looks at the verdict (one
+#                 page-locked word; the GPU is busy with the backward kernels meanwhile).  Equal: done, 2.31 ms.  Any value
+#                 differs (a write through ``tensor.data``, which no version counter sees; other tensors): everything again
+#                 from the handed tensors, as with nothing kept.  The pair stays a pure function of its arguments; clones
+#                 holding the same values find the states too.
+#       True      states only, matched by (data_ptr, in-place version) of the eight tensors, the contract of the records
+#                 handle: nothing is compared (2.21 ms), a write through ``.data`` between the two calls goes unseen --
+#                 the forced-segments sweep of the suite found exactly that in tests/test_gpu_memo.py's ``data_write``.
+#       False     nothing kept.
+#     Scenes whose walks stay below the split threshold never create an entry.
 _memo_enabled = False
 _splat_memo = {}        # (device, stream) -> SplatRecords, in order of last use
 MEMO_MAX = 8
-_pair_states_enabled = False
+_pair_states_enabled = "content"     # "content" (default) | True (identity + version, unvalidated) | False (nothing kept)
 _pair_states = {}       # (device, stream) -> dict(outs, sig, in_sig, seg, lists, width, height, policy)
 _last_splatB = {"segments": False, "rebuilt": False, "kept_states": False}
 _pair_tls = threading.local()   # hands the segment workspace of a _splat call to the public splat() around it
@@ -338,15 +344,49 @@ def set_memo(on: bool) -> None:
         _splat_memo.clear()
 
 
-def set_pair_states(on: bool) -> bool:
-    """Keep the segment-end states of a public ``splat`` for the ``splatB`` of the tensors it returned (default: OFF; only
-    scenes with long tile lists ever hold any; matched by data_ptr and in-place version -- for callers that do not write
-    through ``tensor.data`` between the two calls).  -> the previous setting."""
+def set_pair_states(on):
+    """What the public ``splat`` keeps of a draw that split its long tile lists (only such scenes ever hold anything) for
+    the ``splatB`` that follows.  ``"content"`` (default): the segment-end states AND a snapshot of the eight tensors the
+    pair shares (four inputs, four outputs; 4 (9 N + 2 HW + 2 T + P) bytes); ``splatB`` differentiates that snapshot from
+    the kept states at once, compares what it was HANDED with the snapshot on the device meanwhile, and only if a value
+    differs (a write through ``.data``, other tensors) does everything again from the tensors it was handed, as by
+    default before: a pure function of its arguments either way.  ``True``: states only, matched by data_ptr and in-place
+    version (nothing compared: for callers that never write through ``tensor.data`` between the two calls; 0.1 ms less).
+    ``False``: nothing kept, ``splatB`` always rebuilds the states from ``contrib``.  -> the previous setting."""
     global _pair_states_enabled
-    prev, _pair_states_enabled = _pair_states_enabled, bool(on)
-    if not on:
-        _pair_states.clear()
+    prev = _pair_states_enabled
+    _pair_states_enabled = "content" if on == "content" else bool(on)
+    _pair_states.clear()
     return prev
+
+
+_pair_flags = {}        # (device, stream) -> page-locked bool[1] the verdict of a content comparison lands in
+
+
+def _pair_flag(key):
+    f = _pair_flags.get(key)
+    if f is None:
+        while len(_pair_flags) >= 4 * MEMO_MAX:
+            _pair_flags.pop(next(iter(_pair_flags)))
+        f = _pair_flags[key] = torch.empty(1, dtype=torch.int32).pin_memory()
+    return f
+
+
+def _snapshot(tensors):
+    """One int32 buffer holding the bits of ``tensors`` (4-byte dtypes, contiguous), every piece 16-B aligned (the
+    comparison then reads sixteen bytes per lane), + the views of it in their shapes."""
+    flat, pad = [], torch.zeros(3, dtype=torch.int32, device=tensors[0].device)
+    for t in tensors:
+        f = t.reshape(-1).view(torch.int32)
+        flat.append(f)
+        if f.numel() % 4:
+            flat.append(pad[:4 - f.numel() % 4])
+    buf = torch.cat(flat)
+    views, at = [], 0
+    for t in tensors:
+        views.append(buf[at:at + t.numel()].view(t.dtype).reshape(t.shape))
+        at += (t.numel() + 3) // 4 * 4
+    return buf, views
 
 
 def last_splatB_info() -> dict:
@@ -432,9 +472,22 @@ def splat(height, width, us, cinv2ds, alphas, depths, colors, areas):
             except Exception:
                 in_sig = None
             sig = _memo_sig(out[1:5])
-            if sig is not None and in_sig is not None:
-                _pair_states[key] = dict(outs=tuple(out[1:5]), sig=sig, in_sig=in_sig, seg=kept[0], lists=kept[1],
-                                         width=int(width), height=int(height), policy=_policy_name)
+            ent = None
+            if _pair_states_enabled == "content":
+                try:     # the eight tensors as splatB will be handed them (alphas [N]; all 4-byte types, contiguous)
+                    n_ = us.shape[0]
+                    eight = (_chk(us, "us", torch.float32, (n_, 2)), _chk(cinv2ds, "cinv2ds", torch.float32, (n_, 3)),
+                             _alphas(alphas, n_), _chk(colors, "colors", torch.float32, (n_, 3)),
+                             out[1], out[2], out[3], out[4])
+                    buf, views = _snapshot(eight)
+                    ent = dict(snap=buf, views=views, flag=_pair_flag(key))
+                except Exception:
+                    ent = None
+            elif sig is not None and in_sig is not None:
+                ent = dict(outs=tuple(out[1:5]), sig=sig, in_sig=in_sig)
+            if ent is not None:
+                ent.update(seg=kept[0], lists=kept[1], width=int(width), height=int(height), policy=_policy_name)
+                _pair_states[key] = ent
                 while len(_pair_states) > MEMO_MAX:
                     _pair_states.pop(next(iter(_pair_states)))
     if _memo_enabled:
@@ -688,9 +741,36 @@ def splatB(height, width, us, cinv2ds, alphas, depths, colors, contrib, final_ta
             # the public pair: the states the splat of exactly these tensors left (same four outputs by memory and
             # version -- held alive by the entry --, same inputs by memory and version, same policy and size)
             e = _pair_states.get((dev.index, int(st.value or 0)))
-            if (e is not None and e["width"] == width and e["height"] == height and e["policy"] == _policy_name
-                    and _memo_sig((contrib, final_tau, ranges, gsid)) == e["sig"] and _memo_sig(e["outs"]) == e["sig"]
-                    and _memo_sig((us, cinv2ds, alphas, colors)) == e["in_sig"]):
+            if e is not None and not (e["width"] == width and e["height"] == height and e["policy"] == _policy_name):
+                e = None
+            if e is not None and "snap" in e:
+                # CONTENT mode: differentiate the snapshot of that splat from its own states at once (self-consistent
+                # whatever the caller did to the tensors since), compare what was handed in with the snapshot on the
+                # device, look at the verdict once everything is enqueued (the GPU is busy with the backward kernels while
+                # the host waits for one byte) and redo from the handed tensors only if a value differs
+                mine = (us, cinv2ds, alphas, colors, contrib, final_tau, ranges, gsid)
+                if all(a.shape == b.shape and a.dtype == b.dtype for a, b in zip(mine, e["views"])):
+                    differ = torch.zeros(1, dtype=torch.int32, device=dev)
+                    for a, b in zip(mine, e["views"]):          # (one pass over each byte: egs_words_differ)
+                        _lib.check(lib.egs_words_differ(_ptr(a), _ptr(b), a.numel(), _ptr(differ), st))
+                    e["flag"].copy_(differ, non_blocking=True)
+                    verdict = torch.cuda.Event()
+                    verdict.record(torch.cuda.current_stream(dev))
+                    v = e["views"]
+                    lists_ok = e["lists"] is not None and e["lists"].shape[0] >= gsid.shape[0]
+                    _lib.check(lib.egs_splat_bwd_seg(n, gsid.shape[0], width, height, _ptr(v[0]), _ptr(v[1]), _ptr(v[2]),
+                                                     _ptr(v[3]), None, C.byref(pol), _ptr(v[4]), _ptr(v[5]), _ptr(v[6]),
+                                                     _ptr(e["lists"] if lists_ok else v[7]), _ptr(dl), _ptr(ws), ws_bytes,
+                                                     None, None, _ptr(d_us), _ptr(d_cinv), _ptr(d_alpha), _ptr(d_color),
+                                                     2 if lists_ok else 0, _ptr(e["seg"]), e["seg"].numel(), 0,
+                                                     seg_hint, st))
+                    verdict.synchronize()
+                    if not bool(e["flag"][0]):
+                        _last_splatB.update(segments=True, rebuilt=False, kept_states=True)
+                        return [d_us, d_cinv, d_alpha, d_color]
+                    _pair_states.pop((dev.index, int(st.value or 0)), None)     # (not this call's tensors: again, below)
+            elif (e is not None and _memo_sig((contrib, final_tau, ranges, gsid)) == e["sig"]
+                    and _memo_sig(e["outs"]) == e["sig"] and _memo_sig((us, cinv2ds, alphas, colors)) == e["in_sig"]):
                 seg, kept_states = e["seg"], True
                 if walked is None and e["lists"] is not None and e["lists"].shape[0] >= gsid.shape[0]:
                     walked = e["lists"]          # the same entries with their exact block masks

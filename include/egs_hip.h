@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define EGS_ABI_VERSION 8
+#define EGS_ABI_VERSION 9
 
 #define EGS_ERR_BAD_ARG 10001
 #define EGS_ERR_WORKSPACE 10002
@@ -200,6 +200,11 @@ int egs_pack_records_validate(int n, int width, int height, const float* us, con
                               const float* alphas, const float* colors, const EgsPolicy* pol, void* rec,
                               const uint32_t* stamp_a, uint32_t* stamp_b, int64_t patches, void* kept,
                               const int32_t* plain, void* stream);
+/* *flag = 1 if any of the n_words 32-bit words of the device buffers a and b differs (never cleared: the caller zeroes
+ * it and may run several comparisons into one flag); 4-byte aligned pointers, 16-byte aligned ones are compared sixteen
+ * bytes per lane.  The host layer's content check of the public splat / splatB pair (ext.cpp:10-32 are two independent
+ * calls; what splat keeps for splatB is used only if splatB is handed the same VALUES): ABI 9. */
+int egs_words_differ(const void* a, const void* b, int64_t n_words, int32_t* flag, void* stream);
 /* plain[i] = masked[i] & 0x0FFFFFFF for i < min(count, *count_dev) (count_dev nullable: a device-side patch count
  * the host has not read yet): gsid_per_patch as the reference returns it (gausplat.cu:108-111). */
 int egs_strip_list_masks(int64_t count, const uint32_t* count_dev, const void* masked, int32_t* plain, void* stream);

@@ -293,3 +293,38 @@ def test_two_forwards_then_two_backwards_through_the_public_pair(gsc):
         torch.cuda.synchronize()
         _same(g1, _truth(gsc, first, out1))
         _same(g2, _truth(gsc, second, out2))
+
+
+def test_words_differ_kernel(gsc):
+    """egs_words_differ (ABI 9): bitwise, every position, vector and word paths, the <= 3 words behind the last uint4."""
+    import ctypes as C
+    from easygaussiansplatting_amd import _lib
+    lib = _lib.load()
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    p = lambda t: C.c_void_p(t.data_ptr())
+    g = torch.Generator(device="cuda").manual_seed(4)
+    for n in (1, 3, 4, 5, 1023, 4099, 1_000_003):
+        base = torch.randint(-2**31, 2**31 - 1, (n + 8,), dtype=torch.int32, device="cuda", generator=g)
+        for off_a, off_b in ((0, 0), (4, 0), (1, 1), (0, 3)):          # 16-B aligned pairs and misaligned ones
+            a = base[off_a:off_a + n]
+            b = a.clone() if off_b == 0 else torch.cat([base[:off_b], a])[off_b:]
+            assert b.data_ptr() % 16 == (0 if off_b == 0 else 4 * off_b % 16)
+            flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+            _lib.check(lib.egs_words_differ(p(a), p(b), n, p(flag), st))
+            assert int(flag) == 0, (n, off_a, off_b)
+            for pos in sorted({0, n // 2, n - 1, max(0, n - 2), min(n - 1, 4 * (n // 4))}):
+                c = b.clone() if off_b == 0 else torch.cat([base[:off_b], b])[off_b:]
+                c[pos] ^= 1 << (pos % 31)
+                flag.zero_()
+                _lib.check(lib.egs_words_differ(p(a), p(c), n, p(flag), st))
+                assert int(flag) == 1, (n, off_a, off_b, pos)
+    # NaNs compare by their bits (a float comparison would call equal NaNs different and -0.0 == 0.0 equal)
+    x = torch.tensor([float("nan"), -0.0, 1.0, 2.0], device="cuda")
+    y = x.clone()
+    flag = torch.zeros(1, dtype=torch.int32, device="cuda")
+    _lib.check(lib.egs_words_differ(p(x), p(y), 4, p(flag), st))
+    assert int(flag) == 0
+    y[1] = 0.0
+    _lib.check(lib.egs_words_differ(p(x), p(y), 4, p(flag), st))
+    assert int(flag) == 1
+    _lib.check(lib.egs_words_differ(None, None, 0, p(flag), st))          # nothing to compare: untouched

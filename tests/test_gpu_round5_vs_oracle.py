@@ -68,7 +68,7 @@ def _windows(rg, gx, gy):
                                      window_tiles(gx, gy, gx // 5, gy - 1)]))
 
 
-@pytest.mark.parametrize("how", ["unsplit", "handle", "public", "public_kept"])
+@pytest.mark.parametrize("how", ["unsplit", "handle", "public", "public_kept", "public_content"])
 def test_skewed_reset_splatB_gradients_vs_oracle(fx, reset_scene, how):
     fused, gsc = fx
     from tests.oracle_parallel import draw_backward_tiles
@@ -76,7 +76,9 @@ def test_skewed_reset_splatB_gradients_vs_oracle(fx, reset_scene, how):
     W, H = sc.cam.width, sc.cam.height
     dl = S.normal(3, 22, (3, H, W)).astype(np.float32) / (3 * H * W)
     fused.SEGMENTS = "0" if how == "unsplit" else "auto"
-    keep_states = gsc.set_pair_states(how == "public_kept")
+    # public: nothing kept (splatB rebuilds the states); public_kept: states matched by identity + version; public_content
+    # (the default): states + a snapshot, what splatB is handed compared with it on the device
+    keep_states = gsc.set_pair_states({"public_kept": True, "public_content": "content"}.get(how, False))
     try:
         out = None
         for _ in range(2):      # (the second call finds the walks of the first in the hint words: the steady state)
@@ -93,6 +95,26 @@ def test_skewed_reset_splatB_gradients_vs_oracle(fx, reset_scene, how):
         info = gsc.last_splatB_info()
         assert info["segments"] == (how != "unsplit"), info
         assert info["rebuilt"] == (how == "public"), info        # public: rebuilt; public_kept: the forward's states
+        if how == "public_content":
+            assert info["kept_states"] and not info["rebuilt"], info
+            # the pair is a pure function of the VALUES it is handed: clones of all eight tensors find the states too ...
+            cl = [t.clone() for t in (g["us"], g["cinv"], g["alphas"], g["col"], contrib, tau, ranges, gsid)]
+            again = gsc.splatB(H, W, cl[0], cl[1], cl[2], d, cl[3], cl[4], cl[5], cl[6], cl[7], dev(dl))
+            assert gsc.last_splatB_info()["kept_states"]
+            for x, y in zip(grads, again):
+                assert float((x - y).abs().max()) <= 2e-6 * float(x.abs().max())
+            # ... and a write through .data (no version counter moves) is SEEN: everything again from the handed tensors,
+            # equal to what a splatB that keeps nothing gives for them
+            us2 = g["us"].clone()
+            us2.data[::7] += 0.25
+            got = gsc.splatB(H, W, us2, g["cinv"], g["alphas"], d, g["col"], contrib, tau, ranges, gsid, dev(dl))
+            info2 = gsc.last_splatB_info()
+            assert info2["rebuilt"] and not info2["kept_states"], info2
+            gsc.set_pair_states(False)
+            want = gsc.splatB(H, W, us2, g["cinv"], g["alphas"], d, g["col"], contrib, tau, ranges, gsid, dev(dl))
+            gsc.set_pair_states("content")
+            for x, y in zip(want, got):          # (the same kernels on the same data: the order of the float atomics)
+                assert float((x - y).abs().max()) <= 1e-5 * float(x.abs().max())
         if how == "public_kept":
             assert info["kept_states"], info
             # the kept states survive a backward pass (it reads them): the same call again finds them and gives the same

@@ -401,23 +401,27 @@ def scene_leg(name, sc, dev, lib, steps, iid_ref=None, train=False):
             once(o)
         torch.cuda.synchronize()
         out[key] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
-    if out["segment_path"]:     # the public pair with the forward's segment states kept for splatB (opt-in, gsplatcu.set_pair_states)
+    if out["segment_path"]:
+        # the public pair's three settings (gsplatcu.set_pair_states): the default above keeps the forward's segment
+        # states and compares the values splatB is handed with a snapshot on the device; True matches by identity and
+        # version only; False keeps nothing (splatB rebuilds the states from contrib)
         from easygaussiansplatting_amd import gsplatcu as _gsc
-        prev = _gsc.set_pair_states(True)
-        try:
-            o = RenderOptions(mode="ops", ops_use_records=False)
-            for _ in range(4):
-                once(o)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(8):
-                once(o)
-            torch.cuda.synchronize()
-            out["ops_public_pair_kept_states_ms_per_step"] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
-            out["ops_public_pair_kept_states_used"] = bool(_gsc.last_splatB_info().get("kept_states"))
-        finally:
-            _gsc.set_pair_states(prev)
-            _gsc.clear_memo()
+        out["ops_public_pair_states"] = dict(_gsc.last_splatB_info())
+        o = RenderOptions(mode="ops", ops_use_records=False)
+        for key, mode in (("ops_public_pair_identity_matched_ms_per_step", True),
+                          ("ops_public_pair_rebuilding_ms_per_step", False)):
+            prev = _gsc.set_pair_states(mode)
+            try:
+                for _ in range(4):
+                    once(o)
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(8):
+                    once(o)
+                torch.cuda.synchronize()
+                out[key] = round((time.perf_counter() - t0) / 8 * 1e3, 4)
+            finally:
+                _gsc.set_pair_states(prev)
     if iid_ref:
         r = out["pixel_gaussian_pairs"] / iid_ref["pairs"]
         out["pairs_ratio_to_iid"] = round(r, 3)
