@@ -126,6 +126,20 @@ def _grow(p):
     return p + p // 16 + 4096
 
 
+SIZE_TABLE_MAX = 1024    # problem sizes (N, W, H) a process remembers a patch capacity / depth-key hint for
+
+
+def _learn_capacity(ctx, key, patches):
+    """Raise the enqueue-ahead patch capacity of a problem size (ctx.lock held by the caller or not needed: one dict
+    store); the table is bounded -- a process that meets ever new sizes (a densifying trainer: one per densification; a
+    server rendering many scenes) forgets the sizes it met first."""
+    cap = ctx.capacity
+    val = max(cap.pop(key, 0), _grow(min(patches, 2**31 - 1)))
+    cap[key] = val                                      # (re-inserted: most recently learnt)
+    while len(cap) > SIZE_TABLE_MAX:
+        cap.pop(next(iter(cap)), None)
+
+
 def _settle(t: _Ticket, blocking: bool) -> bool:
     """Look at the read-back of one render: True once it has been validated (either way)."""
     ctx = t.ctx
@@ -164,7 +178,7 @@ def _settle(t: _Ticket, blocking: bool) -> bool:
         ok = t.patches <= t.cap and not (t.hint < 32 and t.need > t.hint) and t.patches < 2**31
         # what the next render of this size starts from
         _gsc._learn_key_bits(ctx.index, t.key, t.need, missed=(t.hint < 32 and t.need > t.hint))
-        ctx.capacity[t.key] = max(ctx.capacity.get(t.key, 0), _grow(min(t.patches, 2**31 - 1)))
+        _learn_capacity(ctx, t.key, t.patches)
         t.status = _Ticket.OK if ok else _Ticket.FAILED
         S = t.state
         if S is not None:
@@ -486,7 +500,7 @@ def forward(pws, shs, alphas, scales, rots, cam, high_shs=None, need_grad=False)
         S._patches = patches
         if n > 0:
             with ctx.lock:
-                ctx.capacity[key] = max(ctx.capacity.get(key, 0), _grow(patches))
+                _learn_capacity(ctx, key, patches)
 
     if cap == 0 or n == 0:
         render_exact()                               # first render of this size

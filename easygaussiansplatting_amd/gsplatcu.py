@@ -222,6 +222,10 @@ def _learn_key_bits(dev_index, key, need, missed=False) -> None:
     the hint to 32 for the redo; the first success after that adopts need + 1."""
     k = (dev_index, key)
     target = min(32, int(need) + 1)
+    while len(_key_bits) > 1024:          # (bounded like the capacity table: fused.SIZE_TABLE_MAX)
+        old = next(iter(_key_bits))
+        _key_bits.pop(old, None)
+        _key_low.pop(old, None)
     if missed:
         _key_bits[k] = 32
         _key_low.pop(k, None)
@@ -627,7 +631,7 @@ def _splat(height, width, us, cinv2ds, alphas, depths, colors, areas, keep):
         patches, gsid = render_exact()
         if n > 0:
             with ctx.lock:
-                ctx.capacity[key] = max(ctx.capacity.get(key, 0), _fused._grow(patches))
+                _fused._learn_capacity(ctx, key, patches)
         return [image, contrib, final_tau, ranges, gsid], records(gsid)
     t = _fused._Ticket()
     t.ctx, t.key, t.cap, t.state, t.status, t.collected, t.slot = ctx, key, cap, None, _fused._Ticket.PENDING, True, slot
