@@ -127,3 +127,37 @@ for cap in (64, 1000, 30_000):
     step(sc, cam, reps=1)
 total += check("overflowing enqueue-ahead capacity")
 print("TOTAL buffers with a touched guard band:", total)
+
+# ---- the training-loop pieces (loss, FusedAdam, densification row moves, factored SH exchange buffers, k-NN, viewer prep):
+# the same proxy on their modules, a Trainer over a densifying run
+import importlib                                                    # noqa: E402
+mods = []
+for name in ("loss", "optim", "density", "dist_views", "knn", "viewer", "trainer", "function"):
+    m = importlib.import_module("easygaussiansplatting_amd." + name)
+    if hasattr(m, "torch"):
+        m.torch = Proxy(name)
+        mods.append(m)
+from easygaussiansplatting_amd.function import render               # noqa: E402
+from easygaussiansplatting_amd.trainer import Trainer               # noqa: E402
+sc = S.small_scene(40_000, 320, 180, 48, seed=1)
+cams = [Camera.from_scene(c) for c in S.ring_cameras(sc.cam, 4, radius=5.0)]
+with torch.no_grad():
+    gts = [render(dev(sc.pws), dev(sc.shs), dev(sc.alphas), dev(sc.scales), dev(sc.rots), c)[0] for c in cams]
+start = S.small_scene(40_000, 320, 180, 48, seed=1)
+start.shs[:, :3] += 0.6 * S.normal(5, 3, (start.n, 3)).astype(np.float32)
+tr = Trainer(start, cams, gts, max_steps=500, scene_size=4.0)
+tr.density.grad_threshold = 2e-7
+for epoch in range(6):
+    for v in range(4):
+        tr.step([v], sync=False)
+    tr.step([0, 1, 2, 3], sync=False)
+    if epoch % 2 == 1:
+        tr.densify()
+    if epoch == 3:
+        tr.reset_alpha()
+total += check("Trainer: loss, Adam, densify, reset_alpha, 1 and 4 views per step")
+from easygaussiansplatting_amd import knn, viewer                    # noqa: E402
+pts = dev(S.normal(2, 9, (30_000, 3)))
+knn.nearest_sqdist(pts) if hasattr(knn, "nearest_sqdist") else None
+total += check("k-NN") if bands else 0
+print("TOTAL (with the training-loop pieces):", total)
